@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the dense-retrieval hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+    encode a 1k-query batch (32 tokens each) with the BERT-large-shape encoder  +  exact top-100 search of
+    those 1k query vectors over the GPU-resident corpus shard (BASELINE config 2: 1M x 1024 per GPU).
+Inputs (token ids, corpus embeddings, weights) are resident in HBM before the timed region.
+With --gpus N every rank owns a 1M-row shard (weak scaling: 1M rows per GPU), searches the same query batch,
+and the per-shard top-100 are all-gathered over RCCL and merged.
+
+Prints ONE JSON line on rank 0 (see the round brief for the contract) including
+    "roofline"      for the dominant kernel (the MFMA coarse scan k_coarse), timed live with HIP events
+    "cpu_baseline"  the oracle's fp32 sgemm + top-k stand-in for faiss.IndexFlatIP, timed on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_MFMA_DENSE_16BIT = 2.5e15   # MI355X_MICROARCH.md: bf16/f16 dense MFMA peak
+HBM_PEAK = 8.0e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--topk", type=int, default=100)
+    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--query-tokens", type=int, default=32)
+    ap.add_argument("--coarse-dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--no-encoder", action="store_true", help="search-only step (query vectors pre-computed)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, q_host):
+    """faiss.IndexFlatIP stand-in (oracle.search_np.search_sgemm: fp32 BLAS sgemm + argpartition, 1024-query
+    blocks as retriever/index.py:39-47) on a bounded row sample of the same synthetic corpus, scaled linearly."""
+    import torch
+    from oracle import search_np as S
+    rows = min(args.cpu_sample_rows, args.rows_per_gpu)
+    rng = np.random.Generator(np.random.PCG64(3))
+    xs = rng.standard_normal((rows, args.dim), dtype=np.float32)
+    xs /= np.linalg.norm(xs, axis=1, keepdims=True)
+    S.search_sgemm(q_host[:64], xs[:4096], min(args.topk, 4096))      # warm BLAS threads
+    t0 = time.perf_counter()
+    S.search_sgemm(q_host, xs, args.topk)
+    dt = time.perf_counter() - t0
+    scale = args.rows_per_gpu / rows
+    return {"value": len(q_host) / (dt * scale), "unit": "queries/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"search only: {len(q_host)} queries x {rows} of {args.rows_per_gpu} rows fp32 sgemm+argpartition top-{args.topk}, "
+                      f"{dt:.2f}s measured, time scaled x{scale:.0f} to the full shard",
+            "nproc": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (kirag_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from kirag_amd import _lib
+    from kirag_amd.retriever.index import FlatIPIndex
+    from kirag_amd.parallel import ShardedSearcher
+
+    n, d, nq, k = args.rows_per_gpu, args.dim, args.queries, args.topk
+    g = torch.Generator(device=dev); g.manual_seed(3 + rank)
+    index = FlatIPIndex(d, device=local_rank, coarse_dtype=args.coarse_dtype)
+    index.reserve(n)
+    chunk = 250_000
+    for s0 in range(0, n, chunk):            # synthetic unit-norm corpus rows, generated on the device
+        m = min(chunk, n - s0)
+        x = torch.nn.functional.normalize(torch.randn(m, d, generator=g, device=dev), dim=1)
+        if s0 == 0:
+            head = x[:nq].clone()
+        index.add(x)
+        del x
+    gq = torch.Generator(device=dev); gq.manual_seed(2)
+    # query vectors: near-duplicates of corpus rows of rank 0's generator family (known neighbours on rank 0)
+    q_vec = torch.nn.functional.normalize(head + 0.05 * torch.randn(nq, d, generator=gq, device=dev), dim=1)
+    if world > 1:
+        dist.broadcast(q_vec, src=0)
+
+    encoder = None
+    if not args.no_encoder:
+        try:
+            from kirag_amd.bench_support import make_bench_encoder
+            encoder, tok_ids, tok_mask = make_bench_encoder(dev, nq, args.query_tokens)
+        except ImportError:
+            encoder = None
+    searcher = ShardedSearcher(index, row_offset=rank * n, world=world)
+
+    def step():
+        if encoder is not None:
+            qv = encoder(tok_ids, tok_mask)
+        else:
+            qv = q_vec
+        return searcher.search(qv, k)
+
+    for _ in range(args.warmup):
+        step()
+    index.stats(reset=True)
+    coarse_ms = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        coarse_ms.append(index.stats()["last_coarse_ms"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        st = index.stats()
+        ms_step = dt / args.steps * 1e3
+        coarse = float(np.mean(coarse_ms)) * 1e-3           # seconds per coarse scan (sum of its round launches)
+        flops = 2.0 * nq * n * d                             # algorithmic: every query against every row of the shard
+        out = {
+            "metric": "queries/sec (encode + exact top-100 search), e5-large-v2 shape, 1M x 1024 corpus rows per GPU",
+            "value": nq * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.coarse_dtype + " MFMA coarse scan / fp64 exact re-rank",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config 2: {n}x{d} {args.coarse_dtype}+fp32 corpus per GPU in HBM, {nq}-query batch "
+                                   f"({args.query_tokens} tokens), brute-force top-{k}",
+                       "rows_per_gpu": n, "dim": d, "queries": nq, "topk": k, "total_rows": n * world,
+                       "encoder_in_step": encoder is not None,
+                       "parallelism": f"row-sharded x{world}, all-gather top-k + host merge"},
+            "roofline": {"bound": "mfma", "achieved": flops / coarse / 1e12, "peak": PEAK_MFMA_DENSE_16BIT / 1e12, "unit": "TFLOP/s",
+                         "frac": flops / coarse / PEAK_MFMA_DENSE_16BIT, "traffic": None, "kernel": "k_coarse",
+                         "launch_ms": coarse * 1e3,
+                         "note": "one 'launch' = one coarse scan of the shard = the sum of its 3-5 k_coarse round launches; "
+                                 "algorithmic FLOPs = 2*nq*rows*dim"},
+            "search_stats": {kk: st[kk] for kk in ("queries", "certified", "fallback", "overflow", "reranked_rows", "coarse_rounds")},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, q_vec.cpu().numpy())
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+/*
+ * kirag_amd — C ABI of the MI355X-native dense-retrieval core (libkirag_amd.so).
+ *
+ * The reference (jyfang6/kirag) is pure Python and has no FFI of its own: its boundary for this path is the
+ * duck-typed Python surface of retriever/{encoders,index,retrievers,e5}.py, underneath which the arithmetic is
+ * done by third-party libraries (HF BertModel.forward, faiss.IndexFlatIP).  Each entry point below names the
+ * reference call it replaces (paths relative to the reference root).  The Python shims in kirag_amd/ bind these
+ * through ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative KR_E* code; it never throws across the ABI;
+ *     kr_last_error() returns a thread-local message for the last failure on the calling thread.
+ *   - data pointers may be HOST or DEVICE pointers (hipMemcpyDefault semantics); device pointers must belong to
+ *     the handle's device.  The caller owns every I/O buffer; handles own their device allocations.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls on one handle are serialised
+ *     by the caller (one thread per rank, as in the reference).
+ *   - there is NO CPU fallback: without a gfx950 device every compute call fails with KR_ENODEV.
+ */
+#ifndef KIRAG_AMD_H
+#define KIRAG_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KR_OK 0
+#define KR_EINVAL (-22)   /* bad argument (shape, k, dtype, unknown weight name ...) */
+#define KR_ENOMEM (-12)   /* hipMalloc failed */
+#define KR_ENODEV (-19)   /* no usable HIP device */
+#define KR_EHIP (-5)      /* a HIP runtime call failed; see kr_last_error() */
+#define KR_ESTATE (-1)    /* handle not ready (e.g. encoder weights missing) */
+
+#define KR_ABI_VERSION 1
+int kr_abi_version(void);
+const char* kr_last_error(void);
+int kr_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Flat inner-product index — replaces faiss.IndexFlatIP behind retriever/index.py (Indexer, :17-83).
+ * Stores, per row, the fp32 master (exact re-rank) and a 16-bit copy (MFMA coarse scan); rows live in HBM.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct kr_index kr_index;
+
+#define KR_METRIC_INNER_PRODUCT 0  /* retriever/index.py:13  FAISSINDEX_DICT["inner_product"] */
+#define KR_COARSE_BF16 0
+#define KR_COARSE_F16 1
+
+/* Indexer.__init__ (index.py:19-24): faiss.IndexFlatIP(vector_sz).  d % 4 == 0, 4 <= d <= 4096. */
+int kr_index_create(int d, int metric, int coarse_dtype, int device, kr_index** out);
+void kr_index_destroy(kr_index* ix);
+/* capacity hint (rows); avoids regrowth copies when the final size is known (faiss_index_corpus.py:42-45 loop) */
+int kr_index_reserve(kr_index* ix, int64_t n_rows);
+/* Indexer.index_data -> index.add(embeddings.astype('float32')) (index.py:26-34): append n fp32 rows [n,d]. */
+int kr_index_add(kr_index* ix, const float* x, int64_t n, void* stream);
+/* index.ntotal (index.py:75,79) */
+int64_t kr_index_ntotal(const kr_index* ix);
+int kr_index_dim(const kr_index* ix);
+/* read back fp32 rows [start, start+n) (serialisation: index.py:55-64 writes the flat storage) */
+int kr_index_get_rows(kr_index* ix, int64_t start, int64_t n, float* out, void* stream);
+
+/* Indexer.search_knn -> index.search(q, top_docs) (index.py:47): exact inner-product top-k.
+ *   q       [nq,d] fp32;  scores [nq,k] fp32 (descending);  rows [nq,k] int64 = internal row numbers
+ *   (the caller maps them through index_id_to_db_id exactly as index.py:49 does).
+ * Result definition (identical to oracle/search_c.c): score = fp64-accumulated inner product in the canonical
+ * order rounded once to fp32; ranking by (score desc, row asc).  0 < k <= ntotal, else KR_EINVAL.
+ * `mode`: 0 = auto (MFMA coarse scan + certified exact re-rank, exact-scan fallback for uncertified queries),
+ *         1 = force the exact full scan (slow; used by tests as an on-device cross-check). */
+int kr_index_search(kr_index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int mode, void* stream);
+
+typedef struct {
+    int64_t queries;          /* queries answered since creation / last reset */
+    int64_t certified;        /* answered by the fast path with the exactness certificate holding */
+    int64_t fallback;         /* re-answered by the exact full scan */
+    int64_t overflow;         /* candidate-buffer overflows (subset of fallback) */
+    int64_t reranked_rows;    /* fp32 rows gathered by the re-rank kernel */
+    int64_t coarse_rounds;    /* coarse GEMM launches */
+    double last_coarse_ms;    /* device time of the coarse launches of the last search call (HIP events) */
+    double last_total_ms;     /* device time of the whole last search call */
+} kr_search_stats;
+int kr_index_stats(kr_index* ix, kr_search_stats* out, int reset);
+
+/* Host-side final merge of per-shard results (north_star: "host-side final merge" after the RCCL all-gather).
+ *   scores [nshards,nq,k], ids [nshards,nq,k] (GLOBAL ids) -> out_scores/out_ids [nq,k] by (score desc, id asc).
+ *   Host pointers only. */
+int kr_topk_merge(const float* scores, const int64_t* ids, int nshards, int nq, int k, float* out_scores, int64_t* out_ids);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * BERT-family sentence encoder — replaces HF BertModel.forward + pooling + F.normalize behind
+ * retriever/encoders.py (E5Encoder.forward :67-77, BGEEncoder.forward :106-118) and retriever/e5.py:51-61.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct kr_encoder kr_encoder;
+
+typedef struct {
+    int hidden;        /* H   (1024 for e5-large-v2 / bge-large-en) */
+    int layers;        /* L   (24) */
+    int heads;         /* 16; hidden / heads must be 64 */
+    int intermediate;  /* FF  (4096) */
+    int vocab;         /* 30522 */
+    int max_pos;       /* 512 */
+    int type_vocab;    /* 2 */
+    float ln_eps;      /* 1e-12 */
+} kr_bert_cfg;
+
+#define KR_POOL_MEAN 0 /* E5: average_pool (encoders.py:56-58) then F.normalize */
+#define KR_POOL_CLS 1  /* BGE: last_hidden[:,0] (encoders.py:116) then F.normalize */
+
+int kr_encoder_create(const kr_bert_cfg* cfg, int device, kr_encoder** out);
+void kr_encoder_destroy(kr_encoder* enc);
+/* one call per HF state_dict tensor of BertModel ("embeddings.word_embeddings.weight",
+ * "encoder.layer.3.attention.self.query.bias", ...), fp32, numel checked; "pooler.*" / "*position_ids" ignored. */
+int kr_encoder_load_weight(kr_encoder* enc, const char* hf_name, const float* data, int64_t numel);
+/* verifies every tensor was supplied and builds the fused/packed device copies */
+int kr_encoder_finalize(kr_encoder* enc);
+/* forward(input_ids, attention_mask) (encoders.py:67-77 / :106-118); token_type_ids are 0 as in every caller.
+ *   input_ids, attention_mask [B,S] int64 (S <= max_pos), out [B,hidden] fp32 L2-normalised.
+ *   A sequence whose mask is all zero yields NaN (mean pool) exactly like the reference. */
+int kr_encoder_forward(kr_encoder* enc, const int64_t* input_ids, const int64_t* attention_mask, int B, int S,
+                       int pool, float* out, void* stream);
+/* debugging / parity: last_hidden_state of the previous forward, fp32 [B*S_packed...] see DESIGN.md */
+int kr_encoder_last_hidden(kr_encoder* enc, float* out /* [B,S,hidden] */, int B, int S);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KIRAG_AMD_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of libkirag_amd.so (include/kirag_amd.h).
+
+The library is built in-tree by ``kirag_amd/csrc/Makefile`` (``__graft_entry__.build()``).  There is no
+CPU fallback anywhere in this package: if the shared object is missing or a call fails, an exception is
+raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkirag_amd.so")
+ABI_VERSION = 1
+
+
+class KiragAmdError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libkirag_amd error {code}: {msg}")
+        self.code = code
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("queries", C.c_int64), ("certified", C.c_int64), ("fallback", C.c_int64), ("overflow", C.c_int64),
+                ("reranked_rows", C.c_int64), ("coarse_rounds", C.c_int64), ("last_coarse_ms", C.c_double),
+                ("last_total_ms", C.c_double)]
+
+
+class BertCfg(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("layers", C.c_int), ("heads", C.c_int), ("intermediate", C.c_int),
+                ("vocab", C.c_int), ("max_pos", C.c_int), ("type_vocab", C.c_int), ("ln_eps", C.c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/kirag_amd.h declares
+SIGNATURES = {
+    "kr_abi_version": (C.c_int, []),
+    "kr_last_error": (C.c_char_p, []),
+    "kr_device_count": (C.c_int, []),
+    "kr_index_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "kr_index_destroy": (None, [C.c_void_p]),
+    "kr_index_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
+    "kr_index_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "kr_index_ntotal": (C.c_int64, [C.c_void_p]),
+    "kr_index_dim": (C.c_int, [C.c_void_p]),
+    "kr_index_get_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "kr_index_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "kr_index_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
+    "kr_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "kr_encoder_create": (C.c_int, [C.POINTER(BertCfg), C.c_int, C.POINTER(C.c_void_p)]),
+    "kr_encoder_destroy": (None, [C.c_void_p]),
+    "kr_encoder_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "kr_encoder_finalize": (C.c_int, [C.c_void_p]),
+    "kr_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "kr_encoder_last_hidden": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared object (once).  Raises if it is missing — the HIP path is the only path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C kirag_amd/csrc` (or __graft_entry__.build()). "
+            "kirag_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the build does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.kr_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"libkirag_amd ABI {v} != expected {ABI_VERSION}: rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().kr_last_error()
+        raise KiragAmdError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def current_stream_ptr() -> int:
+    """hipStream_t of torch's current stream on the current device (0 = default stream)."""
+    import torch
+    if not torch.cuda.is_available():
+        return 0
+    return int(torch.cuda.current_stream().cuda_stream)

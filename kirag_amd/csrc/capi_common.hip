@@ -1,0 +1,52 @@
+// Error plumbing and device selection shared by every entry point of libkirag_amd.so.
+#include "common.hpp"
+
+#include <cstring>
+
+namespace kr {
+
+std::string& last_error_ref() {
+    static thread_local std::string e;
+    return e;
+}
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+int select_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(KR_ENODEV, "no HIP device available (%s); libkirag_amd has no CPU fallback", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(KR_EINVAL, "device %d out of range [0,%d)", device, n);
+    static thread_local int checked = -1;
+    if (checked != device) {
+        hipDeviceProp_t p;
+        e = hipGetDeviceProperties(&p, device);
+        if (e != hipSuccess) return fail(KR_EHIP, "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+        if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+            return fail(KR_ENODEV, "device %d is %s; this library is built for gfx950 (MI355X) only", device, p.gcnArchName);
+        checked = device;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(KR_EHIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace kr
+
+extern "C" {
+int kr_abi_version(void) { return KR_ABI_VERSION; }
+const char* kr_last_error(void) { return kr::last_error_ref().c_str(); }
+int kr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+}

@@ -1,0 +1,227 @@
+"""Drop-in for the reference's ``retriever/index.py`` (``Indexer`` :17-83) with the flat inner-product index
+living in MI355X HBM (``libkirag_amd.so``: MFMA coarse scan + certified exact fp64 re-rank) instead of
+``faiss.IndexFlatIP`` on host cores.
+
+Same surface: ``Indexer(vector_sz, metric="inner_product", n_subquantizers=0, n_bits=8)``,
+``index_data(ids, embeddings)``, ``search_knn(query_vectors, top_docs, index_batch_size=1024, verbose=True)``
+-> ``List[Tuple[List[str], np.ndarray(float32)[k]]]``, ``serialize(dir)``, ``deserialize_from(dir)``,
+attributes ``index.ntotal`` and ``index_id_to_db_id`` (``np.int64``).
+
+Differences, all deliberate and documented in DESIGN.md:
+  * scores are the canonical score (fp64-accumulated, rounded once to fp32) and ties are broken by internal
+    row number — faiss leaves both to its BLAS; results are deterministic here.
+  * ``top_docs > ntotal`` raises ``ValueError`` (faiss pads with label -1, which ``index.py:49`` would silently
+    map to the LAST id).
+  * ``metric="l2"`` and ``n_subquantizers > 0`` (``IndexPQ``) raise ``NotImplementedError``: no caller in the
+    reference uses them (``faiss_index_corpus.py:29``, ``retrieve.py:109`` pass ``metric="inner_product"``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import os
+import pickle
+import struct
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from .. import _lib
+
+logger = logging.getLogger()
+
+_IO_CHUNK_ROWS = 1 << 18
+
+
+class FlatIPIndex:
+    """The object behind ``Indexer.index`` — the subset of ``faiss.IndexFlatIP`` the reference touches
+    (``ntotal``, ``d``, ``is_trained``, ``add``, ``search``) backed by a ``kr_index`` handle."""
+
+    is_trained = True
+
+    def __init__(self, d: int, device: Optional[int] = None, coarse_dtype: str = "bf16"):
+        lib = _lib.load()
+        if device is None:
+            device = int(os.environ.get("KIRAG_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        self.d = int(d)
+        self.device = int(device)
+        self.coarse_dtype = coarse_dtype
+        h = C.c_void_p()
+        _lib.check(lib.kr_index_create(self.d, 0, {"bf16": 0, "f16": 1}[coarse_dtype], self.device, C.byref(h)))
+        self._h = h
+        self._lib = lib
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._lib.kr_index_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    @property
+    def ntotal(self) -> int:
+        return int(self._lib.kr_index_ntotal(self._h))
+
+    def reserve(self, n_rows: int) -> None:
+        _lib.check(self._lib.kr_index_reserve(self._h, int(n_rows)))
+
+    @staticmethod
+    def _ptr(a):
+        """(pointer, keepalive) for a numpy array or a torch tensor (host or device)."""
+        if isinstance(a, np.ndarray):
+            return a.ctypes.data, a
+        return int(a.data_ptr()), a  # torch.Tensor
+
+    def add(self, x) -> None:
+        if isinstance(x, np.ndarray):
+            x = np.ascontiguousarray(x, dtype=np.float32)
+        else:
+            x = x.detach().float().contiguous()
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"expected [n,{self.d}] embeddings, got {tuple(x.shape)}")
+        p, keep = self._ptr(x)
+        _lib.check(self._lib.kr_index_add(self._h, p, int(x.shape[0]), None))
+
+    def search(self, q, k: int, mode: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        """(scores float32 [nq,k] descending, internal rows int64 [nq,k]) — faiss's (D, I)."""
+        if isinstance(q, np.ndarray):
+            q = np.ascontiguousarray(q, dtype=np.float32)
+        else:
+            q = q.detach().float().contiguous()
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError(f"expected [nq,{self.d}] queries, got {tuple(q.shape)}")
+        k = int(k)
+        if not 0 < k <= self.ntotal:
+            raise ValueError(f"top_docs={k} must satisfy 0 < k <= ntotal={self.ntotal}")
+        nq = int(q.shape[0])
+        scores = np.empty((nq, k), np.float32)
+        rows = np.empty((nq, k), np.int64)
+        p, keep = self._ptr(q)
+        _lib.check(self._lib.kr_index_search(self._h, p, nq, k, scores.ctypes.data, rows.ctypes.data, int(mode), None))
+        return scores, rows
+
+    def search_into(self, q, k: int, scores_out, rows_out, mode: int = 0) -> None:
+        """Same as ``search`` but writes into caller-provided torch tensors (host or device):
+        ``scores_out`` float32 [nq,k], ``rows_out`` int64 [nq,k], both contiguous."""
+        q = q.detach().float().contiguous() if not isinstance(q, np.ndarray) else np.ascontiguousarray(q, dtype=np.float32)
+        nq, k = int(q.shape[0]), int(k)
+        if not 0 < k <= self.ntotal:
+            raise ValueError(f"top_docs={k} must satisfy 0 < k <= ntotal={self.ntotal}")
+        assert tuple(scores_out.shape) == (nq, k) and tuple(rows_out.shape) == (nq, k)
+        assert scores_out.is_contiguous() and rows_out.is_contiguous()
+        p, keep = self._ptr(q)
+        _lib.check(self._lib.kr_index_search(self._h, p, nq, k, int(scores_out.data_ptr()), int(rows_out.data_ptr()), int(mode), None))
+
+    def reconstruct_n(self, start: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.d), np.float32)
+        _lib.check(self._lib.kr_index_get_rows(self._h, int(start), int(n), out.ctypes.data, None))
+        return out
+
+    def stats(self, reset: bool = False) -> dict:
+        st = _lib.SearchStats()
+        _lib.check(self._lib.kr_index_stats(self._h, C.byref(st), int(reset)))
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
+
+class Indexer(object):
+
+    def __init__(self, vector_sz, metric="inner_product", n_subquantizers=0, n_bits=8, device=None, coarse_dtype="bf16"):
+        if n_subquantizers > 0:
+            raise NotImplementedError("IndexPQ (n_subquantizers > 0) is not part of the MI355X path; no reference caller uses it")
+        if metric != "inner_product":
+            raise NotImplementedError(f"metric={metric!r}: only 'inner_product' (IndexFlatIP) is implemented")
+        self.index = FlatIPIndex(vector_sz, device=device, coarse_dtype=coarse_dtype)
+        self.index_id_to_db_id = np.empty((0), dtype=np.int64)
+
+    def index_data(self, ids, embeddings):
+        # reference order: id map first, then astype('float32'), then add (index.py:28-32)
+        self._update_id_mapping(ids)
+        if isinstance(embeddings, np.ndarray):
+            embeddings = embeddings.astype('float32')
+        self.index.add(embeddings)
+        logger.info(f'Total data indexed {len(self.index_id_to_db_id)}')
+
+    def search_knn(self, query_vectors, top_docs: int, index_batch_size=1024, verbose: bool = True) -> List[Tuple[List[object], List[float]]]:
+        if isinstance(query_vectors, np.ndarray):
+            query_vectors = query_vectors.astype('float32')
+        result = []
+        nbatch = (len(query_vectors) - 1) // index_batch_size + 1
+        for k in range(nbatch):
+            start_idx = k * index_batch_size
+            end_idx = min((k + 1) * index_batch_size, len(query_vectors))
+            q = query_vectors[start_idx: end_idx]
+            scores, indexes = self.index.search(q, top_docs)
+            # convert to external ids (vectorised form of index.py:49)
+            ext = self.index_id_to_db_id[indexes]
+            db_ids = [[str(v) for v in row] for row in ext.tolist()]
+            result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
+        return result
+
+    # ---- on-disk formats (index.py:55-79) --------------------------------------------------------------
+    def serialize(self, dir_path):
+        index_file = os.path.join(dir_path, "index.faiss")
+        meta_file = os.path.join(dir_path, "index_meta.faiss")
+        logger.info(f'Serializing index to {index_file}, meta data to {meta_file}')
+        write_faiss_flat_ip(self.index, index_file)
+        with open(meta_file, mode='wb') as f:
+            pickle.dump(self.index_id_to_db_id, f)
+
+    def deserialize_from(self, dir_path):
+        index_file = os.path.join(dir_path, "index.faiss")
+        meta_file = os.path.join(dir_path, "index_meta.faiss")
+        logger.info(f'Loading index from {index_file}, meta data from {meta_file}')
+        self.index = read_faiss_flat_ip(index_file, device=self.index.device, coarse_dtype=self.index.coarse_dtype)
+        logger.info('Loaded index of type %s and size %d', type(self.index), self.index.ntotal)
+        with open(meta_file, "rb") as reader:
+            self.index_id_to_db_id = pickle.load(reader)
+        assert len(
+            self.index_id_to_db_id) == self.index.ntotal, 'Deserialized index_id_to_db_id should match faiss index size'
+
+    def _update_id_mapping(self, db_ids: List):
+        new_ids = np.array(db_ids, dtype=np.int64)
+        self.index_id_to_db_id = np.concatenate((self.index_id_to_db_id, new_ids), axis=0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# faiss flat-index file layout.  faiss is a third-party dependency of the reference (requirements.txt:10) and
+# its source is not on disk here: the layout below restates faiss 1.8 `write_index` for IndexFlat from its
+# published io code (impl/index_write.cpp: fourcc, write_index_header, WRITEXBVECTOR) and is UNVERIFIED
+# against a real faiss build in this environment.
+#   u32  fourcc "IxFI"
+#   i32  d ; i64 ntotal ; i64 dummy (1<<20) ; i64 dummy (1<<20) ; u8 is_trained ; i32 metric_type (0 = IP)
+#   u64  number of float32 values (= ntotal * d) ; float32[ntotal * d] row-major
+# ---------------------------------------------------------------------------------------------------------
+_FOURCC_IXFI = struct.unpack("<I", b"IxFI")[0]
+
+
+def write_faiss_flat_ip(index: FlatIPIndex, path: str) -> None:
+    n, d = index.ntotal, index.d
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", _FOURCC_IXFI))
+        f.write(struct.pack("<iqqqBi", d, n, 1 << 20, 1 << 20, 1, 0))
+        f.write(struct.pack("<Q", n * d))
+        for s in range(0, n, _IO_CHUNK_ROWS):
+            m = min(_IO_CHUNK_ROWS, n - s)
+            f.write(index.reconstruct_n(s, m).tobytes())
+
+
+def read_faiss_flat_ip(path: str, device: Optional[int] = None, coarse_dtype: str = "bf16") -> FlatIPIndex:
+    with open(path, "rb") as f:
+        (fourcc,) = struct.unpack("<I", f.read(4))
+        if fourcc != _FOURCC_IXFI:
+            raise ValueError(f"{path}: not a faiss IndexFlatIP file (fourcc {struct.pack('<I', fourcc)!r})")
+        d, n, _, _, _trained, metric = struct.unpack("<iqqqBi", f.read(4 + 8 * 3 + 1 + 4))
+        if metric != 0:
+            raise ValueError(f"{path}: metric_type {metric} is not METRIC_INNER_PRODUCT")
+        (nfloat,) = struct.unpack("<Q", f.read(8))
+        if nfloat != n * d:
+            raise ValueError(f"{path}: payload {nfloat} floats != ntotal*d = {n * d}")
+        index = FlatIPIndex(d, device=device, coarse_dtype=coarse_dtype)
+        index.reserve(n)
+        for s in range(0, n, _IO_CHUNK_ROWS):
+            m = min(_IO_CHUNK_ROWS, n - s)
+            buf = np.frombuffer(f.read(m * d * 4), dtype=np.float32).reshape(m, d)
+            index.add(buf)
+    return index

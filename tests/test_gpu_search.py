@@ -1,0 +1,209 @@
+"""GPU parity tests of the index path (through the C ABI, via kirag_amd.retriever.index) against the oracle.
+Bar: internal rows identical and scores bit-identical to oracle.search_np.search_canonical."""
+import numpy as np
+import pytest
+
+from oracle import search_np as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def _mk(d, x, **kw):
+    from kirag_amd.retriever.index import Indexer
+    ix = Indexer(d, **kw)
+    ix.index_data([str(i) for i in range(len(x))], x)
+    return ix
+
+
+def _queries_near(rng, x, nq, noise=0.05):
+    pick = rng.choice(len(x), nq, replace=len(x) < nq)
+    q = x[pick] + noise * rng.standard_normal((nq, x.shape[1])).astype(np.float32) / np.sqrt(x.shape[1]) * 8
+    return (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32), pick
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(1000, 64, 32, 10), (1000, 1024, 32, 10), (300, 128, 5, 300), (4097, 256, 17, 100),
+                                      (129, 1024, 3, 1), (5000, 768, 40, 20)])
+def test_small_exact_vs_canonical(n, d, nq, k):
+    rng = np.random.default_rng(n + d)
+    x = _unit(rng, n, d)
+    q, _ = _queries_near(rng, x, nq)
+    ix = _mk(d, x)
+    s, i = ix.index.search(q, k)
+    so, io = S.search_canonical(q, x, k)
+    assert np.array_equal(i, io)
+    assert np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    # exact-scan mode must agree too
+    s2, i2 = ix.index.search(q, k, mode=1)
+    assert np.array_equal(i2, io) and np.array_equal(s2.view(np.uint32), so.view(np.uint32))
+
+
+def test_multi_round_vs_canonical_config1_shape():
+    """20k x 1024, 200 queries, top-100: two coarse rounds + certified re-rank, bit-exact vs the C oracle."""
+    rng = np.random.default_rng(7)
+    x = _unit(rng, 20000, 1024)
+    q, pick = _queries_near(rng, x, 200)
+    ix = _mk(1024, x)
+    s, i = ix.index.search(q, 100)
+    so, io = S.search_canonical(q, x, 100)
+    assert np.array_equal(i, io)
+    assert np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    assert np.array_equal(i[:, 0], pick)
+    st = ix.index.stats()
+    assert st["queries"] == 200 and st["certified"] + st["fallback"] == 200
+    assert st["certified"] >= 190, st      # the certificate must hold for (nearly) all random-data queries
+
+
+@pytest.mark.parametrize("coarse", ["bf16", "f16"])
+def test_three_rounds_vs_f64_and_exact_mode(coarse):
+    rng = np.random.default_rng(8)
+    x = _unit(rng, 150_000, 256)
+    q, pick = _queries_near(rng, x, 64)
+    ix = _mk(256, x, coarse_dtype=coarse)
+    s, i = ix.index.search(q, 100)
+    so, io = S.search_f64(q, x, 100)
+    assert np.array_equal(i, io)
+    np.testing.assert_array_equal(s, so)
+    s1, i1 = ix.index.search(q[:8], 100, mode=1)
+    assert np.array_equal(i1, io[:8]) and np.array_equal(s1, so[:8])
+
+
+def test_search_knn_surface_ids_and_block_boundary():
+    rng = np.random.default_rng(9)
+    x = _unit(rng, 3000, 128)
+    ids = [str(10_000_000_000 + 3 * j) for j in range(3000)]      # int64-only ids, returned as str
+    from kirag_amd.retriever.index import Indexer
+    ix = Indexer(128)
+    ix.index_data(ids[:1000], x[:1000]); ix.index_data(ids[1000:], x[1000:].astype(np.float64))
+    assert ix.index.ntotal == 3000 and ix.index_id_to_db_id.dtype == np.int64
+    q = _unit(rng, 1030, 128)                                     # crosses the 1024-query block (index.py:39-46)
+    res = ix.search_knn(q, 7, verbose=False)
+    so, io = S.search_f64(q, x, 7)
+    assert len(res) == 1030
+    for r in (0, 511, 1023, 1024, 1029):
+        assert res[r][0] == [ids[j] for j in io[r]] and all(isinstance(v, str) for v in res[r][0])
+        assert res[r][1].dtype == np.float32 and np.array_equal(res[r][1], so[r])
+    with pytest.raises(ValueError):
+        ix.search_knn(q[:2], 3001, verbose=False)
+    with pytest.raises(NotImplementedError):
+        Indexer(128, metric="l2")
+
+
+def test_duplicates_tie_rule_and_k_equals_n():
+    rng = np.random.default_rng(10)
+    x = _unit(rng, 500, 64)
+    x[100] = x[7]; x[333] = x[7]; x[499] = x[7]
+    ix = _mk(64, x)
+    s, i = ix.index.search(x[[7]], 5)
+    assert list(i[0, :4]) == [7, 100, 333, 499] and len(set(s[0, :4].tolist())) == 1
+    s_all, i_all = ix.index.search(x[[7, 8]], 500)
+    so, io = S.search_canonical(x[[7, 8]], x, 500)
+    assert np.array_equal(i_all, io) and np.array_equal(s_all, so)
+
+
+def test_dense_cluster_forces_exact_fallback():
+    """Rows closer together than the bf16 error bound: the certificate must refuse and the exact scan answer."""
+    rng = np.random.default_rng(11)
+    base = _unit(rng, 1, 256)
+    x = base + 2e-4 * rng.standard_normal((6000, 256)).astype(np.float32)
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    q = _unit(rng, 6, 256) * 0.2 + base
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    ix = _mk(256, x)
+    s, i = ix.index.search(q, 50)
+    so, io = S.search_canonical(q, x, 50)
+    assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    assert ix.index.stats()["fallback"] > 0
+
+
+def test_nan_rows_are_never_returned():
+    rng = np.random.default_rng(12)
+    x = _unit(rng, 700, 64)
+    x[5] = np.nan                                                  # an all-masked passage encodes to NaN (encoders.py:56-58)
+    q = _unit(rng, 4, 64)
+    ix = _mk(64, x)
+    s, i = ix.index.search(q, 20)
+    assert not (i == 5).any() and np.isfinite(s).all()
+    keep = np.ones(700, bool); keep[5] = False
+    so, io = S.search_canonical(q, x[keep], 20)
+    remap = np.nonzero(keep)[0]
+    assert np.array_equal(i, remap[io]) and np.array_equal(s, so)
+
+
+def test_shard_merge_equals_unsharded_on_gpu():
+    import ctypes as C
+    from kirag_amd import _lib
+    rng = np.random.default_rng(13)
+    x = _unit(rng, 9000, 128); q = _unit(rng, 33, 128)
+    x[8000] = x[50]
+    full = _mk(128, x)
+    s, i = full.index.search(q, 30)
+    bounds = [0, 2000, 4500, 9000]
+    ss, ii = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        sh = _mk(128, x[a:b])
+        s_, i_ = sh.index.search(q, 30)
+        ss.append(s_); ii.append(i_ + a)
+    sc = np.ascontiguousarray(np.stack(ss)); ic = np.ascontiguousarray(np.stack(ii))
+    ms = np.empty((33, 30), np.float32); mi = np.empty((33, 30), np.int64)
+    _lib.check(_lib.load().kr_topk_merge(sc.ctypes.data, ic.ctypes.data, 3, 33, 30, ms.ctypes.data, mi.ctypes.data))
+    assert np.array_equal(mi, i) and np.array_equal(ms, s)
+    om, oi = S.merge_shards(ss, ii, 30)
+    assert np.array_equal(oi, mi) and np.array_equal(om, ms)
+
+
+def test_serialize_roundtrip(tmp_path):
+    rng = np.random.default_rng(14)
+    x = _unit(rng, 1234, 64)
+    from kirag_amd.retriever.index import Indexer
+    ix = Indexer(64); ix.index_data([str(5 * j) for j in range(1234)], x)
+    ix.serialize(str(tmp_path))
+    iy = Indexer(64); iy.deserialize_from(str(tmp_path))
+    assert iy.index.ntotal == 1234 and np.array_equal(iy.index_id_to_db_id, ix.index_id_to_db_id)
+    assert np.array_equal(iy.index.reconstruct_n(0, 1234), x)
+    q = _unit(rng, 3, 64)
+    a = ix.search_knn(q, 5, verbose=False); b = iy.search_knn(q, 5, verbose=False)
+    assert all(a[r][0] == b[r][0] and np.array_equal(a[r][1], b[r][1]) for r in range(3))
+
+
+def test_full_size_config2_properties():
+    """BASELINE config 2: 1M x 1024, 1000 queries, top-100 — size-independent properties + on-device exact cross-check."""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    n, d, nq, k = 1_000_000, 1024, 1000, 100
+    x = torch.randn(n, d, generator=g, device="cuda", dtype=torch.float32)
+    x = torch.nn.functional.normalize(x, dim=1)
+    pick = torch.randint(0, n, (nq,), generator=g, device="cuda")
+    q = torch.nn.functional.normalize(x[pick] + 0.05 * torch.randn(nq, d, generator=g, device="cuda"), dim=1)
+    from kirag_amd.retriever.index import FlatIPIndex
+    ix = FlatIPIndex(d); ix.reserve(n)
+    for s0 in range(0, n, 250_000):
+        ix.add(x[s0:s0 + 250_000])
+    s, i = ix.search(q, k)
+    assert np.array_equal(i[:, 0], pick.cpu().numpy())                 # planted neighbour first
+    assert (np.diff(s, axis=1) <= 0).all()                               # descending
+    assert all(len(set(r)) == k for r in i.tolist())                     # no duplicate rows
+    st = ix.stats()
+    assert st["certified"] >= 0.99 * nq, st
+    # exact full scan of a few queries on the device must agree bit for bit
+    s1, i1 = ix.search(q[:6], k, mode=1)
+    assert np.array_equal(i1, i[:6]) and np.array_equal(s1, s[:6])
+    # scores equal the canonical score of the returned rows (C oracle on gathered rows)
+    rows = torch.from_numpy(i[:4]).cuda()
+    xs = x[rows.reshape(-1)].cpu().numpy()
+    sc = S.scores_at(q[:4].cpu().numpy(), xs, (np.arange(4 * k).reshape(4, k)).astype(np.int64))
+    assert np.array_equal(sc, s[:4])
+    # shard-merge == unsharded (two 500k shards)
+    from kirag_amd import _lib
+    halves = []
+    for a, b in ((0, 500_000), (500_000, n)):
+        sh = FlatIPIndex(d); sh.reserve(b - a); sh.add(x[a:b])
+        s_, i_ = sh.search(q[:64], k); halves.append((s_, i_ + a)); del sh
+    sc2 = np.ascontiguousarray(np.stack([h[0] for h in halves])); ic2 = np.ascontiguousarray(np.stack([h[1] for h in halves]))
+    ms = np.empty((64, k), np.float32); mi = np.empty((64, k), np.int64)
+    _lib.check(_lib.load().kr_topk_merge(sc2.ctypes.data, ic2.ctypes.data, 2, 64, k, ms.ctypes.data, mi.ctypes.data))
+    assert np.array_equal(mi, i[:64]) and np.array_equal(ms, s[:64])
