@@ -63,6 +63,14 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch wheels bundle their own libamdhip64.so.7; whichever HIP runtime is loaded first serves the whole
+    # process (same SONAME).  Import torch FIRST so that its runtime is the one: tensors handed to this library
+    # and this library's own allocations then live in one runtime.  (Loading this library first made torch fail
+    # with "no ROCm-capable device is detected".)  A process that never imports torch uses /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C kirag_amd/csrc` (or __graft_entry__.build()). "

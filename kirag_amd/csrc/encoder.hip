@@ -1,11 +1,699 @@
-// placeholder until the encoder kernels land (next commit): every entry point fails loudly.
-#include "common.hpp"
-using namespace kr;
-extern "C" {
-int kr_encoder_create(const kr_bert_cfg*, int, kr_encoder** out) { if (out) *out = nullptr; return fail(KR_ESTATE, "encoder not built yet"); }
-void kr_encoder_destroy(kr_encoder*) {}
-int kr_encoder_load_weight(kr_encoder*, const char*, const float*, int64_t) { return fail(KR_ESTATE, "encoder not built yet"); }
-int kr_encoder_finalize(kr_encoder*) { return fail(KR_ESTATE, "encoder not built yet"); }
-int kr_encoder_forward(kr_encoder*, const int64_t*, const int64_t*, int, int, int, float*, void*) { return fail(KR_ESTATE, "encoder not built yet"); }
-int kr_encoder_last_hidden(kr_encoder*, float*, int, int) { return fail(KR_ESTATE, "encoder not built yet"); }
+// BERT-family sentence encoder forward on MI355X — replaces HF BertModel.forward + pooling + F.normalize behind
+// retriever/encoders.py (E5Encoder.forward :67-77, BGEEncoder.forward :106-118; retriever/e5.py:51-61).
+//
+// Layout.  The [B,S] batch is PACKED on the device: only positions with attention_mask != 0 become token rows
+// (sequence b owns rows [off_b, off_b + nq_b), off_b % 4 == 0; absolute position ids are kept per token), so the
+// projections run on sum(len) rows instead of B*S.  No host round trip: grids are sized for B*(S+4) rows and blocks
+// beyond the device-side total exit.  Residual stream fp32 (xf), MFMA operands bf16 (xb, q, k, vT, ctx, h),
+// fp32 accumulation everywhere.
+//
+// Per layer (post-LN BERT):  [Wq/8|Wk|Wv] x -> q, k (row-major) and v TRANSPOSED [H, T] (so that attention reads
+// V^T fragments contiguously); attention = one wave per (sequence, head, 32 queries), swapped QK^T so the softmax
+// reductions are in-lane, P^T fed from the accumulator straight into the V^T.P^T MFMA (no LDS);  Wo ctx + b +
+// residual -> LayerNorm;  W1 x + b -> erf-GELU;  W2 h + b + residual -> LayerNorm.  Pooling (masked mean or CLS)
+// + L2 normalisation produce out[B,H] fp32.
+#include "gemm_nt.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace kr {
+
+using ShapeE = GemmShape<128, 128, 2, 2>;   // rows = output features, cols = tokens
+
+struct LayerW {
+    uint16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;   // bf16 [out, in]
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+};
+
+struct Encoder {
+    kr_bert_cfg cfg{};
+    int device = 0;
+    float *word = nullptr, *pos = nullptr, *type = nullptr, *elng = nullptr, *elnb = nullptr;
+    std::vector<LayerW> L;
+    std::vector<uint8_t> got;     // 5 + 16*layers flags
+    bool ready = false;
+    float* stage = nullptr; size_t stage_elems = 0;   // fp32 upload staging for load_weight
+    // workspace
+    int64_t capT = 0; int capB = 0; int64_t capBS = 0; int64_t ldv = 0;
+    int64_t *d_ids = nullptr, *d_mask = nullptr;
+    int *seq_off = nullptr, *seq_nk = nullptr, *seq_nq = nullptr, *seq_cls = nullptr, *seq_has0 = nullptr, *d_T = nullptr, *d_err = nullptr;
+    int *tok_id = nullptr, *tok_pos = nullptr;
+    float *xf = nullptr, *y = nullptr, *out = nullptr;
+    uint16_t *xb = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *ctx = nullptr, *h = nullptr;
+    int lastB = 0, lastS = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_f32_to_bf16(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = BF16::from_f32(src[i] * scale);
 }
+__global__ void k_scale_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] * scale;
+}
+
+// one wave per sequence: number of attended positions and whether position 0 is attended
+__global__ __launch_bounds__(64) void k_seq_len(const int64_t* __restrict__ mask, int B, int S, int* __restrict__ nk, int* __restrict__ has0) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int c = 0;
+    for (int p = lane; p < S; p += 64) c += (mask[(int64_t)b * S + p] != 0) ? 1 : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if (lane == 0) { nk[b] = c; has0[b] = (mask[(int64_t)b * S] != 0) ? 1 : 0; }
+}
+
+// one wave: nq = nk (+1 query-only row for position 0 when CLS pooling needs it), offsets = exclusive scan of round_up(nq,4)
+__global__ __launch_bounds__(64) void k_seq_scan(const int* __restrict__ nk, const int* __restrict__ has0, int B, int pool, int* __restrict__ nq,
+                                                 int* __restrict__ off, int* __restrict__ cls, int* __restrict__ T, int* __restrict__ err) {
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < B; base += 64) {
+        const int b = base + lane;
+        int n = 0;
+        if (b < B) {
+            n = nk[b] + ((pool == KR_POOL_CLS && !has0[b]) ? 1 : 0);
+            nq[b] = n;
+            cls[b] = has0[b] ? 0 : nk[b];
+        }
+        const int padded = (n + 3) & ~3;
+        int incl = padded;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (b < B) off[b] = carry + incl - padded;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) { *T = carry; *err = 0; }
+}
+
+// one wave per sequence: packed token list (attended positions in order; the optional query-only row for position 0 last)
+__global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int S, int vocab,
+                                                    const int* __restrict__ off, const int* __restrict__ nk, const int* __restrict__ nq,
+                                                    int* __restrict__ tok_id, int* __restrict__ tok_pos, int* __restrict__ err) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int o = off[b];
+    int run = 0;
+    for (int base = 0; base < S; base += 64) {
+        const int p = base + lane;
+        const bool v = (p < S) && (mask[(int64_t)b * S + p] != 0);
+        const unsigned long long bal = __ballot(v);
+        if (v) {
+            const int r = run + __popcll(bal & ((1ull << lane) - 1ull));
+            int64_t id = ids[(int64_t)b * S + p];
+            if (id < 0 || id >= vocab) { *err = 1; id = 0; }
+            tok_id[o + r] = (int)id; tok_pos[o + r] = p;
+        }
+        run += __popcll(bal);
+    }
+    const int n = nq[b];
+    if (lane == 0 && n > nk[b]) {
+        int64_t id = ids[(int64_t)b * S];
+        if (id < 0 || id >= vocab) { *err = 1; id = 0; }
+        tok_id[o + nk[b]] = (int)id; tok_pos[o + nk[b]] = 0;
+    }
+    const int padded = (n + 3) & ~3;
+    if (lane < padded - n) { tok_id[o + n + lane] = 0; tok_pos[o + n + lane] = 0; }
+}
+
+// LayerNorm of one row held as up to 8 float4 per lane (H <= 2048); writes fp32 and bf16 copies
+__device__ __forceinline__ void ln_row_store(float4 (&v)[8], int H, int lane, const float* __restrict__ g, const float* __restrict__ bta, float eps,
+                                             float* __restrict__ xf_row, uint16_t* __restrict__ xb_row) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (lane * 4 + j * 256 < H) s += v[j].x + v[j].y + v[j].z + v[j].w;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    const float mu = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (lane * 4 + j * 256 < H) {
+            const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+            q += a * a + b * b + c * c + d * d;
+        }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = lane * 4 + j * 256;
+        if (i < H) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + i);
+            const float4 bb = *reinterpret_cast<const float4*>(bta + i);
+            float4 o;
+            o.x = (v[j].x - mu) * rstd * gg.x + bb.x; o.y = (v[j].y - mu) * rstd * gg.y + bb.y;
+            o.z = (v[j].z - mu) * rstd * gg.z + bb.z; o.w = (v[j].w - mu) * rstd * gg.w + bb.w;
+            *reinterpret_cast<float4*>(xf_row + i) = o;
+            ushort4 ob;
+            ob.x = BF16::from_f32(o.x); ob.y = BF16::from_f32(o.y); ob.z = BF16::from_f32(o.z); ob.w = BF16::from_f32(o.w);
+            *reinterpret_cast<ushort4*>(xb_row + i) = ob;
+        }
+    }
+}
+
+// embeddings: word[id] + position[pos] + token_type[0] -> LayerNorm       (one wave per token)
+__global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id, const int* __restrict__ tok_pos, const int* __restrict__ Tp,
+                                                  const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
+                                                  const float* __restrict__ g, const float* __restrict__ bta, float eps, int H,
+                                                  float* __restrict__ xf, uint16_t* __restrict__ xb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= *Tp) return;
+    const float* w = word + (int64_t)tok_id[t] * H;
+    const float* p = pos + (int64_t)tok_pos[t] * H;
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = lane * 4 + j * 256;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < H) {
+            const float4 a = *reinterpret_cast<const float4*>(w + i);
+            const float4 b = *reinterpret_cast<const float4*>(p + i);
+            const float4 c = *reinterpret_cast<const float4*>(type + i);
+            v[j] = make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
+        }
+    }
+    ln_row_store(v, H, lane, g, bta, eps, xf + t * H, xb + t * H);
+}
+
+// LayerNorm(y) -> xf, xb     (one wave per token; y already holds dense + bias + residual)
+__global__ __launch_bounds__(256) void k_ln(const float* __restrict__ y, const int* __restrict__ Tp, const float* __restrict__ g,
+                                            const float* __restrict__ bta, float eps, int H, float* __restrict__ xf, uint16_t* __restrict__ xb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= *Tp) return;
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = lane * 4 + j * 256;
+        v[j] = (i < H) ? *reinterpret_cast<const float4*>(y + t * H + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    ln_row_store(v, H, lane, g, bta, eps, xf + t * H, xb + t * H);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// projections: C^T[feature, token] = W[feature, :] . X[token, :]   (rows = features so that a lane's 4 consecutive
+// accumulator registers are 4 consecutive features of ONE token -> 8/16-byte stores)
+// ---------------------------------------------------------------------------------------------------------
+struct ProjArgs {
+    const uint16_t* W; const uint16_t* X; const int* Tp; int F; int K; int H;
+    const float* bias;
+    uint16_t* out0; uint16_t* out1; uint16_t* outT; int64_t ldT;   // QKV: q, k row-major [T,H]; vT [H, ldT]
+    const float* resid; float* outf;                               // residual epilogue: outf[t,F] = acc + bias + resid[t,F]
+};
+
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2 };
+
+// XCD-aware map: XCD x owns feature tiles {x, x+8, ...} (its weight slice stays in that L2) and walks all token tiles
+__device__ __forceinline__ bool proj_tile_map(int bid, int tm_count, int tn_count, int& tm, int& tn) {
+    const int xcd = bid & 7, j = bid >> 3;
+    const int per = (tm_count + 7) >> 3;
+    tm = xcd + 8 * (j % per);
+    tn = j / per;
+    return tm < tm_count && tn < tn_count;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a, int tn_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tm, tn;
+    if (!proj_tile_map(blockIdx.x, a.F / ShapeE::BM, tn_count, tm, tn)) return;
+    const int T = *a.Tp;
+    const int m0 = tm * ShapeE::BM, n0 = tn * ShapeE::BN;
+    if (n0 >= T) return;
+    gemm_nt_block<BF16, ShapeE>(a.W, a.K, a.F, a.X, a.K, T, a.K, m0, n0, smem, [&](AccTile<ShapeE>& acc) {
+#pragma unroll
+        for (int ni = 0; ni < ShapeE::TN; ++ni) {
+            const int t = n0 + acc.col(ni);
+            if (t >= T) continue;
+#pragma unroll
+            for (int mi = 0; mi < ShapeE::TM; ++mi) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int f = m0 + acc.m_wave + mi * 32 + 8 * gq + 4 * (acc.lane >> 5);
+                    const float4 b = *reinterpret_cast<const float4*>(a.bias + f);
+                    float v0 = acc.v[mi][ni][4 * gq + 0] + b.x, v1 = acc.v[mi][ni][4 * gq + 1] + b.y;
+                    float v2 = acc.v[mi][ni][4 * gq + 2] + b.z, v3 = acc.v[mi][ni][4 * gq + 3] + b.w;
+                    if constexpr (EPI == EPI_QKV) {
+                        const int which = m0 / a.H;   // block-uniform: H % 128 == 0
+                        if (which < 2) {
+                            ushort4 o;
+                            o.x = BF16::from_f32(v0); o.y = BF16::from_f32(v1); o.z = BF16::from_f32(v2); o.w = BF16::from_f32(v3);
+                            uint16_t* dst = (which == 0 ? a.out0 : a.out1) + (int64_t)t * a.H + (f - which * a.H);
+                            *reinterpret_cast<ushort4*>(dst) = o;
+                        } else {
+                            uint16_t* dst = a.outT + (int64_t)(f - 2 * a.H) * a.ldT + t;
+                            dst[0] = BF16::from_f32(v0); dst[a.ldT] = BF16::from_f32(v1);
+                            dst[2 * a.ldT] = BF16::from_f32(v2); dst[3 * a.ldT] = BF16::from_f32(v3);
+                        }
+                    } else if constexpr (EPI == EPI_RESID) {
+                        const float4 r = *reinterpret_cast<const float4*>(a.resid + (int64_t)t * a.F + f);
+                        *reinterpret_cast<float4*>(a.outf + (int64_t)t * a.F + f) = make_float4(v0 + r.x, v1 + r.y, v2 + r.z, v3 + r.w);
+                    } else {
+                        ushort4 o;   // HF ACT2FN["gelu"]: 0.5 x (1 + erf(x / sqrt 2))
+                        o.x = BF16::from_f32(0.5f * v0 * (1.f + erff(v0 * 0.70710678118654752f)));
+                        o.y = BF16::from_f32(0.5f * v1 * (1.f + erff(v1 * 0.70710678118654752f)));
+                        o.z = BF16::from_f32(0.5f * v2 * (1.f + erff(v2 * 0.70710678118654752f)));
+                        o.w = BF16::from_f32(0.5f * v3 * (1.f + erff(v3 * 0.70710678118654752f)));
+                        *reinterpret_cast<ushort4*>(a.out0 + (int64_t)t * a.F + f) = o;
+                    }
+                }
+            }
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// attention: one wave per (sequence, head, 32 queries); d_h = 64; softmax(Q K^T + key mask) V   (1/sqrt(d_h) is in Wq)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)BF16::from_f32(lo) | ((uint32_t)BF16::from_f32(hi) << 16); }
+
+__global__ __launch_bounds__(256) void k_attn(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vT, int64_t ldv,
+                                              const int* __restrict__ seq_off, const int* __restrict__ seq_nk, const int* __restrict__ seq_nq,
+                                              int H, int heads, uint16_t* __restrict__ ctx) {
+    const int lane = threadIdx.x & 63;
+    const int head = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * 32;
+    const int nq = seq_nq[b];
+    if (head >= heads || q0 >= nq) return;
+    const int nk = seq_nk[b];
+    const int64_t off = seq_off[b];
+    const int c = lane & 31, hf = lane >> 5;
+    // Q^T as the B operand: lane (c, hf) holds Q[q0 + c][16 s + 8 hf .. +7], s = 0..3
+    uint4 qf[4];
+    {
+        const int qi = (q0 + c < nq) ? (q0 + c) : (nq - 1);
+        const uint16_t* qrow = q + (off + qi) * H + head * 64;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(qrow + 16 * s + 8 * hf);
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const float LOG2E = 1.4426950408889634f;
+    const uint16_t* vrow0 = vT + (int64_t)(head * 64 + c) * ldv + off;        // V^T rows d = c and d = 32 + c of this head
+    const uint16_t* vrow1 = vrow0 + 32 * ldv;
+    for (int k0 = 0; k0 < nk; k0 += 32) {
+        // S^T tile [32 keys x 32 queries] = K_tile . Q^T
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        {
+            const int ki = (k0 + c < nk) ? (k0 + c) : (nk - 1);
+            const uint16_t* krow = k + (off + ki) * H + head * 64;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(krow + 16 * s + 8 * hf);
+                st = BF16::mfma(kf, qf[s], st);
+            }
+        }
+        // register r of this lane is key k0 + (r&3) + 8 (r>>2) + 4 hf, query q0 + c
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            st[r] = (key < nk) ? st[r] : -INFINITY;
+            tmax = fmaxf(tmax, st[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(m, tmax);
+        const float mref = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = exp2f((m - mref) * LOG2E);
+        float psum = 0.f;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = exp2f((st[r] - mref) * LOG2E); psum += p[r]; }
+        psum += __shfl_xor(psum, 32, 64);
+        l = l * alpha + psum;
+        m = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        // O^T += V^T . P^T : P^T comes from the accumulator (B operand, k-step s2 = registers 8 s2 .. 8 s2 + 7, whose
+        // element j is key 16 s2 + 8 (j>>2) + 4 hf + (j&3)); the V^T fragment must use the same key order:
+        // elements 0..3 = keys kb .. kb+3, elements 4..7 = keys kb+8 .. kb+11 with kb = k0 + 16 s2 + 4 hf
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 pf;
+            pf.x = pack_bf16x2(p[8 * s2 + 0], p[8 * s2 + 1]); pf.y = pack_bf16x2(p[8 * s2 + 2], p[8 * s2 + 3]);
+            pf.z = pack_bf16x2(p[8 * s2 + 4], p[8 * s2 + 5]); pf.w = pack_bf16x2(p[8 * s2 + 6], p[8 * s2 + 7]);
+            const int kb = k0 + 16 * s2 + 4 * hf;
+            uint2 a0 = *reinterpret_cast<const uint2*>(vrow0 + kb), a1 = *reinterpret_cast<const uint2*>(vrow0 + kb + 8);
+            uint2 b0 = *reinterpret_cast<const uint2*>(vrow1 + kb), b1 = *reinterpret_cast<const uint2*>(vrow1 + kb + 8);
+            if (k0 + 32 > nk) {   // last tile: rows past nk belong to padding / the next sequence -> zero them (0 * NaN guard)
+                const uint32_t m00 = (kb + 0 < nk ? 0xffffu : 0u) | (kb + 1 < nk ? 0xffff0000u : 0u);
+                const uint32_t m01 = (kb + 2 < nk ? 0xffffu : 0u) | (kb + 3 < nk ? 0xffff0000u : 0u);
+                const uint32_t m10 = (kb + 8 < nk ? 0xffffu : 0u) | (kb + 9 < nk ? 0xffff0000u : 0u);
+                const uint32_t m11 = (kb + 10 < nk ? 0xffffu : 0u) | (kb + 11 < nk ? 0xffff0000u : 0u);
+                a0.x &= m00; a0.y &= m01; a1.x &= m10; a1.y &= m11;
+                b0.x &= m00; b0.y &= m01; b1.x &= m10; b1.y &= m11;
+            }
+            o0 = BF16::mfma(make_uint4(a0.x, a0.y, a1.x, a1.y), pf, o0);
+            o1 = BF16::mfma(make_uint4(b0.x, b0.y, b1.x, b1.y), pf, o1);
+        }
+    }
+    if (q0 + c < nq) {
+        // a query with no attendable key (all-masked sequence) is 0/0 = NaN, as under HF's -inf masking
+        const float inv = 1.0f / l;
+        uint16_t* dst = ctx + (off + q0 + c) * H + head * 64;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int d = 8 * gq + 4 * hf;
+            uint2 w0, w1;
+            w0.x = pack_bf16x2(o0[4 * gq + 0] * inv, o0[4 * gq + 1] * inv); w0.y = pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
+            w1.x = pack_bf16x2(o1[4 * gq + 0] * inv, o1[4 * gq + 1] * inv); w1.y = pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
+            *reinterpret_cast<uint2*>(dst + d) = w0;
+            *reinterpret_cast<uint2*>(dst + 32 + d) = w1;
+        }
+    }
+}
+
+// pooling + L2 normalisation: one block per sequence
+__global__ __launch_bounds__(256) void k_pool(const float* __restrict__ xf, const int* __restrict__ seq_off, const int* __restrict__ seq_nk,
+                                              const int* __restrict__ seq_cls, int H, int pool, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t off = seq_off[b];
+    const int nk = seq_nk[b];
+    float v[8];   // H <= 2048
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = tid + j * 256;
+        v[j] = 0.f;
+        if (i < H) {
+            if (pool == KR_POOL_CLS) {
+                v[j] = xf[(off + seq_cls[b]) * H + i];
+            } else {
+                float s = 0.f;
+                for (int t = 0; t < nk; ++t) s += xf[(off + t) * H + i];
+                v[j] = s / (float)nk;   // nk == 0 -> 0/0 = NaN like average_pool (encoders.py:56-58)
+            }
+            ss += v[j] * v[j];
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float den = fmaxf(nrm, 1e-12f);   // F.normalize eps; NaN norm stays NaN (fmaxf would drop it)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = tid + j * 256;
+        if (i < H) out[(int64_t)b * H + i] = (nrm == nrm) ? v[j] / den : NAN;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+template <class P>
+static int dmalloc(P** p, size_t bytes) {
+    KR_HIP(hipMalloc(reinterpret_cast<void**>(p), bytes));
+    return 0;
+}
+
+static void free_ws(Encoder* e) {
+    void* ptrs[] = {e->d_ids, e->d_mask, e->seq_off, e->seq_nk, e->seq_nq, e->seq_cls, e->seq_has0, e->tok_id, e->tok_pos, e->xf, e->y, e->out,
+                    e->xb, e->q, e->k, e->vT, e->ctx, e->h};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    e->d_ids = e->d_mask = nullptr; e->seq_off = e->seq_nk = e->seq_nq = e->seq_cls = e->seq_has0 = nullptr; e->tok_id = e->tok_pos = nullptr;
+    e->xf = e->y = e->out = nullptr; e->xb = e->q = e->k = e->vT = e->ctx = e->h = nullptr;
+    e->capT = 0; e->capB = 0; e->capBS = 0;
+}
+
+static int ensure_ws(Encoder* e, int B, int S) {
+    const int64_t maxT = (int64_t)B * (S + 4);
+    const int H = e->cfg.hidden, FF = e->cfg.intermediate;
+    if (!e->d_T) { KR_TRY(dmalloc(&e->d_T, sizeof(int))); KR_TRY(dmalloc(&e->d_err, sizeof(int))); }
+    if (maxT <= e->capT && B <= e->capB && (int64_t)B * S <= e->capBS) return 0;
+    free_ws(e);
+    const int64_t capT = round_up(maxT, 128), capB = B, capBS = (int64_t)B * S;
+    KR_TRY(dmalloc(&e->d_ids, capBS * 8)); KR_TRY(dmalloc(&e->d_mask, capBS * 8));
+    KR_TRY(dmalloc(&e->seq_off, capB * 4)); KR_TRY(dmalloc(&e->seq_nk, capB * 4)); KR_TRY(dmalloc(&e->seq_nq, capB * 4)); KR_TRY(dmalloc(&e->seq_cls, capB * 4)); KR_TRY(dmalloc(&e->seq_has0, capB * 4));
+    KR_TRY(dmalloc(&e->tok_id, capT * 4)); KR_TRY(dmalloc(&e->tok_pos, capT * 4));
+    KR_TRY(dmalloc(&e->xf, capT * H * 4)); KR_TRY(dmalloc(&e->y, capT * H * 4)); KR_TRY(dmalloc(&e->out, (size_t)capB * H * 4));
+    KR_TRY(dmalloc(&e->xb, capT * H * 2)); KR_TRY(dmalloc(&e->q, capT * H * 2)); KR_TRY(dmalloc(&e->k, capT * H * 2));
+    e->ldv = capT + 64;   // slack: the last key tile of the last sequence may read up to 43 columns past T
+    KR_TRY(dmalloc(&e->vT, (size_t)H * e->ldv * 2));
+    KR_HIP(hipMemset(e->vT, 0, (size_t)H * e->ldv * 2));
+    KR_TRY(dmalloc(&e->ctx, capT * H * 2)); KR_TRY(dmalloc(&e->h, capT * FF * 2));
+    e->capT = capT; e->capB = (int)capB; e->capBS = capBS;
+    return 0;
+}
+
+// tensor slot ids: 0..4 embeddings, then 16 per layer
+enum { T_WORD = 0, T_POS, T_TYPE, T_ELNG, T_ELNB, T_LAYER0 };
+enum { L_QW = 0, L_QB, L_KW, L_KB, L_VW, L_VB, L_OW, L_OB, L_LN1G, L_LN1B, L_IW, L_IB, L_FW, L_FB, L_LN2G, L_LN2B, L_COUNT };
+
+static int parse_name(const Encoder* e, const char* name, int& slot, int64_t& numel) {
+    std::string s(name);
+    size_t p = s.find("embeddings.");
+    size_t pl = s.find("encoder.layer.");
+    const int64_t H = e->cfg.hidden, FF = e->cfg.intermediate;
+    if (s.find("position_ids") != std::string::npos || s.find("pooler.") != std::string::npos) { slot = -1; return 0; }
+    if (pl != std::string::npos) {
+        const char* c = s.c_str() + pl + strlen("encoder.layer.");
+        char* end = nullptr;
+        const long l = strtol(c, &end, 10);
+        if (end == c || *end != '.' || l < 0 || l >= e->cfg.layers) return fail(KR_EINVAL, "bad layer index in '%s'", name);
+        const std::string r(end + 1);
+        static const struct { const char* n; int id; } tbl[] = {
+            {"attention.self.query.weight", L_QW}, {"attention.self.query.bias", L_QB}, {"attention.self.key.weight", L_KW},
+            {"attention.self.key.bias", L_KB}, {"attention.self.value.weight", L_VW}, {"attention.self.value.bias", L_VB},
+            {"attention.output.dense.weight", L_OW}, {"attention.output.dense.bias", L_OB},
+            {"attention.output.LayerNorm.weight", L_LN1G}, {"attention.output.LayerNorm.bias", L_LN1B},
+            {"intermediate.dense.weight", L_IW}, {"intermediate.dense.bias", L_IB}, {"output.dense.weight", L_FW}, {"output.dense.bias", L_FB},
+            {"output.LayerNorm.weight", L_LN2G}, {"output.LayerNorm.bias", L_LN2B}};
+        for (const auto& t : tbl)
+            if (r == t.n) {
+                slot = T_LAYER0 + (int)l * L_COUNT + t.id;
+                switch (t.id) {
+                    case L_QW: case L_KW: case L_VW: case L_OW: numel = H * H; break;
+                    case L_IW: case L_FW: numel = H * FF; break;
+                    case L_IB: numel = FF; break;
+                    default: numel = H;
+                }
+                return 0;
+            }
+        return fail(KR_EINVAL, "unknown layer tensor '%s'", name);
+    }
+    if (p != std::string::npos) {
+        const std::string r = s.substr(p + strlen("embeddings."));
+        if (r == "word_embeddings.weight") { slot = T_WORD; numel = (int64_t)e->cfg.vocab * H; return 0; }
+        if (r == "position_embeddings.weight") { slot = T_POS; numel = (int64_t)e->cfg.max_pos * H; return 0; }
+        if (r == "token_type_embeddings.weight") { slot = T_TYPE; numel = (int64_t)e->cfg.type_vocab * H; return 0; }
+        if (r == "LayerNorm.weight") { slot = T_ELNG; numel = H; return 0; }
+        if (r == "LayerNorm.bias") { slot = T_ELNB; numel = H; return 0; }
+    }
+    return fail(KR_EINVAL, "unknown tensor name '%s'", name);
+}
+
+static void launch_proj(int epi, const ProjArgs& a, int tn_count, hipStream_t st) {
+    const int tm_count = a.F / ShapeE::BM;
+    const int per = (tm_count + 7) / 8;
+    const unsigned grid = (unsigned)(8 * per * tn_count);
+    if (epi == EPI_QKV) hipLaunchKernelGGL(k_proj<EPI_QKV>, dim3(grid), dim3(ShapeE::NTHREADS), ShapeE::LDS_BYTES, st, a, tn_count);
+    else if (epi == EPI_RESID) hipLaunchKernelGGL(k_proj<EPI_RESID>, dim3(grid), dim3(ShapeE::NTHREADS), ShapeE::LDS_BYTES, st, a, tn_count);
+    else hipLaunchKernelGGL(k_proj<EPI_GELU>, dim3(grid), dim3(ShapeE::NTHREADS), ShapeE::LDS_BYTES, st, a, tn_count);
+}
+
+}  // namespace kr
+
+using namespace kr;
+
+extern "C" {
+
+int kr_encoder_create(const kr_bert_cfg* cfg, int device, kr_encoder** out) {
+    if (!out || !cfg) return fail(KR_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (cfg->hidden <= 0 || cfg->hidden % 128 != 0 || cfg->hidden > 2048) return fail(KR_EINVAL, "hidden=%d unsupported (multiple of 128, <= 2048)", cfg->hidden);
+    if (cfg->heads <= 0 || cfg->hidden != cfg->heads * 64) return fail(KR_EINVAL, "hidden/heads must be 64 (got %d/%d)", cfg->hidden, cfg->heads);
+    if (cfg->intermediate <= 0 || cfg->intermediate % 128 != 0) return fail(KR_EINVAL, "intermediate=%d must be a multiple of 128", cfg->intermediate);
+    if (cfg->layers <= 0 || cfg->vocab <= 0 || cfg->max_pos <= 0 || cfg->type_vocab <= 0) return fail(KR_EINVAL, "bad BERT config");
+    KR_TRY(select_device(device));
+    Encoder* e = new Encoder();
+    e->cfg = *cfg; e->device = device;
+    e->L.resize(cfg->layers);
+    e->got.assign(T_LAYER0 + (size_t)cfg->layers * L_COUNT, 0);
+    const size_t H = cfg->hidden, FF = cfg->intermediate;
+    int rc = 0;
+    auto A = [&](auto** p, size_t bytes) { if (!rc) rc = dmalloc(p, bytes); };
+    A(&e->word, (size_t)cfg->vocab * H * 4); A(&e->pos, (size_t)cfg->max_pos * H * 4); A(&e->type, (size_t)cfg->type_vocab * H * 4);
+    A(&e->elng, H * 4); A(&e->elnb, H * 4);
+    for (auto& l : e->L) {
+        A(&l.wqkv, 3 * H * H * 2); A(&l.wo, H * H * 2); A(&l.w1, FF * H * 2); A(&l.w2, H * FF * 2);
+        A(&l.bqkv, 3 * H * 4); A(&l.bo, H * 4); A(&l.b1, FF * 4); A(&l.b2, H * 4);
+        A(&l.ln1g, H * 4); A(&l.ln1b, H * 4); A(&l.ln2g, H * 4); A(&l.ln2b, H * 4);
+    }
+    if (rc) { kr_encoder_destroy(reinterpret_cast<kr_encoder*>(e)); return rc; }
+    *out = reinterpret_cast<kr_encoder*>(e);
+    return 0;
+}
+
+void kr_encoder_destroy(kr_encoder* h) {
+    if (!h) return;
+    Encoder* e = reinterpret_cast<Encoder*>(h);
+    (void)hipSetDevice(e->device);
+    free_ws(e);
+    void* ptrs[] = {e->word, e->pos, e->type, e->elng, e->elnb, e->stage, e->d_T, e->d_err};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& l : e->L) {
+        void* lp[] = {l.wqkv, l.wo, l.w1, l.w2, l.bqkv, l.bo, l.b1, l.b2, l.ln1g, l.ln1b, l.ln2g, l.ln2b};
+        for (void* p : lp) if (p) (void)hipFree(p);
+    }
+    delete e;
+}
+
+int kr_encoder_load_weight(kr_encoder* h, const char* hf_name, const float* data, int64_t numel) {
+    if (!h || !hf_name || !data) return fail(KR_EINVAL, "NULL argument");
+    Encoder* e = reinterpret_cast<Encoder*>(h);
+    KR_TRY(select_device(e->device));
+    int slot = -1; int64_t want = 0;
+    KR_TRY(parse_name(e, hf_name, slot, want));
+    if (slot < 0) return 0;   // pooler.* / position_ids: not used by the encoders (encoders.py:74,115 take last_hidden_state)
+    if (numel != want) return fail(KR_EINVAL, "tensor '%s' has %lld elements, expected %lld", hf_name, (long long)numel, (long long)want);
+    if ((size_t)numel > e->stage_elems) {
+        if (e->stage) (void)hipFree(e->stage);
+        e->stage = nullptr; e->stage_elems = 0;
+        KR_TRY(dmalloc(&e->stage, (size_t)numel * 4));
+        e->stage_elems = (size_t)numel;
+    }
+    KR_HIP(hipMemcpy(e->stage, data, (size_t)numel * 4, hipMemcpyDefault));
+    const int64_t H = e->cfg.hidden;
+    const unsigned grid = (unsigned)((numel + 255) / 256);
+    auto to_bf16 = [&](uint16_t* dst, float scale) { hipLaunchKernelGGL(k_f32_to_bf16, dim3(grid), dim3(256), 0, 0, e->stage, dst, numel, scale); };
+    auto to_f32 = [&](float* dst, float scale) { hipLaunchKernelGGL(k_scale_copy, dim3(grid), dim3(256), 0, 0, e->stage, dst, numel, scale); };
+    if (slot < T_LAYER0) {
+        float* dst[] = {e->word, e->pos, e->type, e->elng, e->elnb};
+        to_f32(dst[slot], 1.f);
+    } else {
+        LayerW& l = e->L[(slot - T_LAYER0) / L_COUNT];
+        switch ((slot - T_LAYER0) % L_COUNT) {
+            // 1/sqrt(d_h) = 1/8 is folded into the query projection (exact: power of two)
+            case L_QW: to_bf16(l.wqkv, 0.125f); break;
+            case L_QB: to_f32(l.bqkv, 0.125f); break;
+            case L_KW: to_bf16(l.wqkv + H * H, 1.f); break;
+            case L_KB: to_f32(l.bqkv + H, 1.f); break;
+            case L_VW: to_bf16(l.wqkv + 2 * H * H, 1.f); break;
+            case L_VB: to_f32(l.bqkv + 2 * H, 1.f); break;
+            case L_OW: to_bf16(l.wo, 1.f); break;
+            case L_OB: to_f32(l.bo, 1.f); break;
+            case L_LN1G: to_f32(l.ln1g, 1.f); break;
+            case L_LN1B: to_f32(l.ln1b, 1.f); break;
+            case L_IW: to_bf16(l.w1, 1.f); break;
+            case L_IB: to_f32(l.b1, 1.f); break;
+            case L_FW: to_bf16(l.w2, 1.f); break;
+            case L_FB: to_f32(l.b2, 1.f); break;
+            case L_LN2G: to_f32(l.ln2g, 1.f); break;
+            case L_LN2B: to_f32(l.ln2b, 1.f); break;
+        }
+    }
+    KR_HIP(hipGetLastError());
+    KR_HIP(hipDeviceSynchronize());
+    e->got[slot] = 1;
+    e->ready = false;
+    return 0;
+}
+
+int kr_encoder_finalize(kr_encoder* h) {
+    if (!h) return fail(KR_EINVAL, "NULL argument");
+    Encoder* e = reinterpret_cast<Encoder*>(h);
+    for (size_t i = 0; i < e->got.size(); ++i)
+        if (!e->got[i]) return fail(KR_ESTATE, "weight slot %zu (layer %d, tensor %d) was never loaded", i,
+                                    i < T_LAYER0 ? -1 : (int)((i - T_LAYER0) / L_COUNT), i < T_LAYER0 ? (int)i : (int)((i - T_LAYER0) % L_COUNT));
+    if (e->stage) { (void)hipFree(e->stage); e->stage = nullptr; e->stage_elems = 0; }
+    e->ready = true;
+    return 0;
+}
+
+int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* attention_mask, int B, int S, int pool, float* out, void* stream) {
+    if (!h) return fail(KR_EINVAL, "encoder is NULL");
+    Encoder* e = reinterpret_cast<Encoder*>(h);
+    if (!e->ready) return fail(KR_ESTATE, "encoder weights incomplete: call kr_encoder_finalize after loading every tensor");
+    if (B < 0 || S <= 0 || (B > 0 && (!input_ids || !attention_mask || !out))) return fail(KR_EINVAL, "bad input pointers / shape");
+    if (S > e->cfg.max_pos) return fail(KR_EINVAL, "sequence length %d exceeds max_position_embeddings %d", S, e->cfg.max_pos);
+    if (pool != KR_POOL_MEAN && pool != KR_POOL_CLS) return fail(KR_EINVAL, "pool must be 0 (mean) or 1 (cls)");
+    if (B == 0) return 0;
+    if (B > 65535) return fail(KR_EINVAL, "at most 65535 sequences per call");
+    KR_TRY(select_device(e->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    KR_TRY(ensure_ws(e, B, S));
+    const int H = e->cfg.hidden, FF = e->cfg.intermediate, heads = e->cfg.heads;
+    const float eps = e->cfg.ln_eps;
+    KR_HIP(hipMemcpyAsync(e->d_ids, input_ids, (size_t)B * S * 8, hipMemcpyDefault, st));
+    KR_HIP(hipMemcpyAsync(e->d_mask, attention_mask, (size_t)B * S * 8, hipMemcpyDefault, st));
+    hipLaunchKernelGGL(k_seq_len, dim3(B), dim3(64), 0, st, e->d_mask, B, S, e->seq_nk, e->seq_has0);
+    hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(64), 0, st, e->seq_nk, e->seq_has0, B, pool, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->d_err);
+    hipLaunchKernelGGL(k_fill_tokens, dim3(B), dim3(64), 0, st, e->d_ids, e->d_mask, S, e->cfg.vocab, e->seq_off, e->seq_nk, e->seq_nq, e->tok_id,
+                       e->tok_pos, e->d_err);
+    const int64_t maxT = (int64_t)B * (S + 4);
+    const unsigned row_grid = (unsigned)((maxT + 3) / 4);
+    const int tn_count = (int)((maxT + ShapeE::BN - 1) / ShapeE::BN);
+    hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
+                       e->xf, e->xb);
+    const dim3 attn_grid((unsigned)((S + 1 + 31) / 32), (unsigned)((heads + 3) / 4), (unsigned)B);
+    for (const LayerW& l : e->L) {
+        ProjArgs a{};
+        a.Tp = e->d_T; a.H = H;
+        // q | k | v^T
+        a.W = l.wqkv; a.X = e->xb; a.F = 3 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k; a.outT = e->vT; a.ldT = e->ldv;
+        launch_proj(EPI_QKV, a, tn_count, st);
+        hipLaunchKernelGGL(k_attn, attn_grid, dim3(256), 0, st, e->q, e->k, e->vT, e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, e->ctx);
+        // attention.output.dense + residual -> LayerNorm
+        a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo; a.resid = e->xf; a.outf = e->y;
+        launch_proj(EPI_RESID, a, tn_count, st);
+        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln1g, l.ln1b, eps, H, e->xf, e->xb);
+        // intermediate.dense + GELU
+        a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h;
+        launch_proj(EPI_GELU, a, tn_count, st);
+        // output.dense + residual -> LayerNorm
+        a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.resid = e->xf; a.outf = e->y;
+        launch_proj(EPI_RESID, a, tn_count, st);
+        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln2g, l.ln2b, eps, H, e->xf, e->xb);
+    }
+    hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xf, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);
+    KR_HIP(hipGetLastError());
+    KR_HIP(hipMemcpyAsync(out, e->out, (size_t)B * H * 4, hipMemcpyDefault, st));
+    int err = 0;
+    KR_HIP(hipMemcpyAsync(&err, e->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    KR_HIP(hipStreamSynchronize(st));
+    e->lastB = B; e->lastS = S;
+    if (err) return fail(KR_EINVAL, "input_ids contain a token id outside [0, %d)", e->cfg.vocab);
+    return 0;
+}
+
+// last_hidden_state of the previous forward, un-packed to [B,S,H]; rows of non-attended positions are zero
+int kr_encoder_last_hidden(kr_encoder* h, float* out, int B, int S) {
+    if (!h || !out) return fail(KR_EINVAL, "NULL argument");
+    Encoder* e = reinterpret_cast<Encoder*>(h);
+    if (B != e->lastB || S != e->lastS || B == 0) return fail(KR_ESTATE, "no forward of shape [%d,%d] to read back", B, S);
+    KR_TRY(select_device(e->device));
+    const int H = e->cfg.hidden;
+    std::vector<int> off(B), nq(B);
+    int T = 0;
+    KR_HIP(hipMemcpy(off.data(), e->seq_off, B * 4, hipMemcpyDeviceToHost));
+    KR_HIP(hipMemcpy(nq.data(), e->seq_nq, B * 4, hipMemcpyDeviceToHost));
+    KR_HIP(hipMemcpy(&T, e->d_T, 4, hipMemcpyDeviceToHost));
+    std::vector<int> pos(T);
+    std::vector<float> x((size_t)T * H);
+    KR_HIP(hipMemcpy(pos.data(), e->tok_pos, (size_t)T * 4, hipMemcpyDeviceToHost));
+    KR_HIP(hipMemcpy(x.data(), e->xf, (size_t)T * H * 4, hipMemcpyDeviceToHost));
+    std::vector<float> full((size_t)B * S * H, 0.f);
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < nq[b]; ++i)
+            std::memcpy(&full[((size_t)b * S + pos[off[b] + i]) * H], &x[(size_t)(off[b] + i) * H], (size_t)H * 4);
+    KR_HIP(hipMemcpy(out, full.data(), full.size() * 4, hipMemcpyDefault));
+    return 0;
+}
+
+}  // extern "C"

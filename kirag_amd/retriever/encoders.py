@@ -1,0 +1,170 @@
+"""Drop-in for the reference's ``retriever/encoders.py``: ``E5Encoder`` (:61-77, BertModel -> masked mean-pool
+-> L2 normalise) and ``BGEEncoder`` (:100-118, BertModel -> [:,0] -> L2 normalise) whose inference forward runs
+in ``libkirag_amd.so`` (hand-written HIP for gfx950: packed tokens, bf16 MFMA projections, fused attention).
+
+Both classes still ARE ``transformers.BertModel`` subclasses — ``from_pretrained`` / ``save_pretrained`` /
+``config.hidden_size`` / ``named_parameters()`` / ``.to()`` / ``.eval()`` keep working exactly as the callers
+expect (``retriever/retrievers.py:29,62-69,124-128``).
+
+Which path runs:
+  * ``model.eval()`` (every inference caller: ``compute_corpus_embeddings.py:56``, ``retrievers.py:168``,
+    ``e5.py:28``): the HIP path, whether or not ``torch.no_grad()`` is active (``cal_doc_embeddings`` does not
+    use it, ``compute_corpus_embeddings.py:81``).  The output carries no autograd history.  Parameters must be
+    on a GPU; there is NO CPU fallback — a CPU model in eval mode raises.
+  * ``model.train()`` (Aligner fine-tuning, ``trainer/aligner_trainer.py:25-30``): the inherited PyTorch
+    autograd forward, unchanged — backward is outside the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+from transformers import BertModel
+
+from .. import _lib
+
+POOL_MEAN, POOL_CLS = 0, 1
+
+
+def average_pool(last_hidden_states: Tensor, attention_mask: Tensor) -> Tensor:
+    """retriever/encoders.py:56-58 (used by the training path only; the HIP path pools in-kernel)."""
+    last_hidden = last_hidden_states.masked_fill(~attention_mask[..., None].bool(), 0.0)
+    return last_hidden.sum(dim=1) / attention_mask.sum(dim=1)[..., None]
+
+
+class HipBertForward:
+    """Owns a ``kr_encoder`` handle and keeps its weight copy in sync with an ``nn.Module``'s parameters."""
+
+    def __init__(self, config, device_index: int):
+        lib = _lib.load()
+        if getattr(config, "hidden_act", "gelu") != "gelu":
+            raise NotImplementedError(f"hidden_act={config.hidden_act!r}: the HIP encoder implements erf-GELU only")
+        if getattr(config, "position_embedding_type", "absolute") != "absolute":
+            raise NotImplementedError("only absolute position embeddings are implemented")
+        cfg = _lib.BertCfg(config.hidden_size, config.num_hidden_layers, config.num_attention_heads, config.intermediate_size,
+                           config.vocab_size, config.max_position_embeddings, config.type_vocab_size, float(config.layer_norm_eps))
+        h = C.c_void_p()
+        _lib.check(lib.kr_encoder_create(C.byref(cfg), device_index, C.byref(h)))
+        self._lib, self._h, self.device_index = lib, h, device_index
+        self.hidden = config.hidden_size
+        self.fingerprint = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._lib.kr_encoder_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def sync(self, module: torch.nn.Module) -> None:
+        params = [(n, p) for n, p in module.named_parameters() if not n.startswith("pooler.")]
+        fp = tuple((p.data_ptr(), p._version) for _, p in params)
+        if fp == self.fingerprint:
+            return
+        for name, p in params:
+            t = p.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.float().contiguous()
+            _lib.check(self._lib.kr_encoder_load_weight(self._h, name.encode(), t.data_ptr(), t.numel()))
+        _lib.check(self._lib.kr_encoder_finalize(self._h))
+        self.fingerprint = fp
+
+    def load_state(self, state: dict) -> None:
+        """Load weights from a mapping HF-state-dict-name -> numpy array / tensor (host or device)."""
+        import numpy as np
+        for name, w in state.items():
+            if isinstance(w, np.ndarray):
+                w = np.ascontiguousarray(w, dtype=np.float32)
+                ptr, n = w.ctypes.data, w.size
+            else:
+                w = w.detach().float().contiguous()
+                ptr, n = w.data_ptr(), w.numel()
+            _lib.check(self._lib.kr_encoder_load_weight(self._h, name.encode(), ptr, n))
+        _lib.check(self._lib.kr_encoder_finalize(self._h))
+        self.fingerprint = None
+
+    def forward_np(self, input_ids, attention_mask, pool: int):
+        """numpy in / numpy out (host pointers straight through the C ABI)."""
+        import numpy as np
+        ids = np.ascontiguousarray(input_ids, dtype=np.int64); mask = np.ascontiguousarray(attention_mask, dtype=np.int64)
+        B, S = ids.shape
+        out = np.empty((B, self.hidden), np.float32)
+        _lib.check(self._lib.kr_encoder_forward(self._h, ids.ctypes.data, mask.ctypes.data, B, S, pool, out.ctypes.data, None))
+        return out
+
+    def forward(self, input_ids: Tensor, attention_mask: Tensor, pool: int) -> Tensor:
+        ids = input_ids.to(torch.int64).contiguous()
+        mask = attention_mask.to(device=ids.device, dtype=torch.int64).contiguous()
+        B, S = ids.shape
+        out = torch.empty((B, self.hidden), dtype=torch.float32, device=ids.device)
+        _lib.check(self._lib.kr_encoder_forward(self._h, ids.data_ptr(), mask.data_ptr(), B, S, pool, out.data_ptr(),
+                                                _lib.current_stream_ptr() if ids.is_cuda else None))
+        return out
+
+    def last_hidden(self, B: int, S: int) -> Tensor:
+        out = torch.empty((B, S, self.hidden), dtype=torch.float32)
+        _lib.check(self._lib.kr_encoder_last_hidden(self._h, out.data_ptr(), B, S))
+        return out
+
+
+class _HipSentenceEncoder(BertModel):
+    _pool = POOL_MEAN
+
+    def __init__(self, config, add_pooling_layer=True, **kwargs):
+        super().__init__(config, add_pooling_layer)
+        self.kwargs = kwargs
+        self._hip: Optional[HipBertForward] = None
+
+    def _hip_forward(self, input_ids, attention_mask, token_type_ids):
+        p = next(self.parameters())
+        if not p.is_cuda:
+            raise RuntimeError(
+                f"{type(self).__name__} in eval mode runs on the MI355X HIP path only; its parameters are on {p.device}. "
+                "Move the model to a GPU (kirag_amd has no CPU fallback).")
+        if token_type_ids is not None and bool((token_type_ids != 0).any()):
+            raise NotImplementedError("token_type_ids != 0 is not used by any KiRAG caller and is not implemented on the HIP path")
+        if input_ids.dim() != 2:
+            raise ValueError(f"input_ids must be [B,S], got {tuple(input_ids.shape)}")
+        idx = p.device.index if p.device.index is not None else torch.cuda.current_device()
+        if self._hip is None or self._hip.device_index != idx:
+            self._hip = HipBertForward(self.config, idx)
+        self._hip.sync(self)
+        with torch.cuda.device(idx):
+            return self._hip.forward(input_ids.to(p.device), attention_mask, self._pool)
+
+    def _torch_pooled(self, input_ids, attention_mask, token_type_ids):
+        out = BertModel.forward(self, input_ids=input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, return_dict=True)
+        return out.last_hidden_state
+
+    def hip_last_hidden_state(self, B: int, S: int) -> Tensor:
+        """last_hidden_state [B,S,H] (CPU, fp32) of the previous HIP forward; rows of masked positions are zero."""
+        return self._hip.last_hidden(B, S)
+
+
+class E5Encoder(_HipSentenceEncoder):
+    _pool = POOL_MEAN
+
+    def forward(self, input_ids, attention_mask, token_type_ids=None, **kwargs):
+        if not self.training:
+            return self._hip_forward(input_ids, attention_mask, token_type_ids)
+        last_hidden_states = self._torch_pooled(input_ids, attention_mask, token_type_ids)
+        embeddings = average_pool(last_hidden_states, attention_mask)
+        embeddings = F.normalize(embeddings, p=2, dim=1)
+        return embeddings
+
+
+class BGEEncoder(_HipSentenceEncoder):
+    _pool = POOL_CLS
+
+    def forward(self, input_ids, attention_mask, token_type_ids=None, **kwargs):
+        if not self.training:
+            return self._hip_forward(input_ids, attention_mask, token_type_ids)
+        last_hidden_states = self._torch_pooled(input_ids, attention_mask, token_type_ids)
+        embeddings = last_hidden_states[:, 0]
+        embeddings = F.normalize(embeddings, p=2, dim=1)
+        return embeddings

@@ -1,0 +1,148 @@
+"""GPU parity tests of the encoder path (through the C ABI) against vectors produced by the reference's own
+E5Encoder / BGEEncoder (tests/golden, tools/make_golden.py) and against the numpy oracle.
+
+Tolerances.  The reference computes in fp32; the HIP path feeds bf16 operands to the MFMAs (fp32 accumulate,
+fp32 residual stream).  north_star: cosine scores within 1e-3.  Bars used here, on unit-norm outputs:
+  * element-wise |out - ref| <= 4e-3 (tiny configs) / 3e-3 (full size),  1 - cos(out, ref) <= 2e-5
+  * inner-product scores between encoded queries and passages within 1e-3 of the fp32 reference scores."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from oracle import encoder_np as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(arr):
+    H, L, heads, FF, vocab, max_pos = [int(v) for v in arr]
+    return SimpleNamespace(hidden_size=H, num_hidden_layers=L, num_attention_heads=heads, intermediate_size=FF, vocab_size=vocab,
+                           max_position_embeddings=max_pos, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+
+
+def _hip(cfg, weights):
+    from kirag_amd.retriever.encoders import HipBertForward
+    h = HipBertForward(cfg, 0)
+    h.load_state(weights)
+    return h
+
+
+def _check(out, ref, atol, tag=""):
+    assert out.shape == ref.shape
+    err = np.abs(out - ref).max()
+    cos = (out * ref).sum(1) / (np.linalg.norm(out, axis=1) * np.linalg.norm(ref, axis=1))
+    assert err <= atol, f"{tag}: max abs err {err:.2e} > {atol}"
+    assert (1 - cos).max() <= 2e-5, f"{tag}: 1-cos {float((1 - cos).max()):.2e}"
+    np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
+    return err
+
+
+@pytest.mark.parametrize("name", ["t128", "t256"])
+def test_g1_tiny_configs_match_reference(golden, name):
+    g = golden("g1_encoder_tiny.npz")
+    cfg = _cfg(g[f"cfg.{name}"])
+    w = E.synth_weights(cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
+                        seed=int(g["weight_seed"]))
+    h = _hip(cfg, w)
+    worst = 0.0
+    for tag, pool in (("e5", 0), ("bge", 1)):
+        for ci in range(7):
+            key = f"{name}.{tag}.c{ci}"
+            out = h.forward_np(g[key + ".ids"], g[key + ".mask"], pool)
+            worst = max(worst, _check(out, g[key + ".out"], 4e-3, key))
+    print(f"[{name}] worst abs err vs reference fp32: {worst:.2e}")
+
+
+def test_g1_last_hidden_state(golden):
+    g = golden("g1_encoder_tiny.npz")
+    cfg = _cfg(g["cfg.t256"])
+    w = E.synth_weights(cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
+                        seed=int(g["weight_seed"]))
+    h = _hip(cfg, w)
+    for ci in (1, 3):
+        key = f"t256.e5.c{ci}"
+        ids, mask, hid = g[key + ".ids"], g[key + ".mask"], g[key + ".hidden"]
+        h.forward_np(ids, mask, 0)
+        lh = h.last_hidden(*ids.shape).numpy()
+        keep = mask.astype(bool)
+        assert np.abs(lh[keep] - hid[-1][keep]).max() <= 3e-2          # LayerNorm outputs are O(1)
+        assert (lh[~keep] == 0).all()
+
+
+def test_g2_full_size_e5_and_bge(golden):
+    g = golden("g2_encoder_large.npz")
+    cfg = _cfg(g["cfg"])
+    w = E.synth_weights(cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
+                        seed=int(g["weight_seed"]))
+    h = _hip(cfg, w)
+    outs = {}
+    for key, pool in (("e5.c0", 0), ("e5.c1", 0), ("e5.c2", 0), ("bge.c0", 1)):
+        out = h.forward_np(g[key + ".ids"], g[key + ".mask"], pool)
+        err = _check(out, g[key + ".out"], 3e-3, key)
+        outs[key] = out
+        print(f"[{key}] max abs err {err:.2e}")
+    # scores: queries (c2: 32-token) x passages (c1), vs the fp32 reference scores   (north_star: within 1e-3)
+    s_hip = outs["e5.c2"] @ outs["e5.c1"].T
+    s_ref = g["e5.c2.out"] @ g["e5.c1.out"].T
+    assert np.abs(s_hip - s_ref).max() <= 1e-3, float(np.abs(s_hip - s_ref).max())
+
+
+def test_batch_invariance_and_padding_layouts(golden):
+    """Same sequences alone / in a batch / left-padded / with interior mask holes give the oracle's answer."""
+    g = golden("g1_encoder_tiny.npz")
+    cfg = _cfg(g["cfg.t128"])
+    w = E.synth_weights(cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
+                        seed=int(g["weight_seed"]))
+    h = _hip(cfg, w)
+    rng = np.random.default_rng(0)
+    ids = rng.integers(5, cfg.vocab_size, (6, 40)); mask = np.ones((6, 40), np.int64)
+    mask[1, 25:] = 0                    # right padded
+    mask[2, :13] = 0                    # left padded (truncate_to_max_sequence's other branch, collators.py:38-44)
+    mask[3, 5:9] = 0; mask[3, 30:] = 0  # holes
+    mask[4, :] = 0                      # nothing attended -> NaN (encoders.py:56-58)
+    mask[5, 1:] = 0                     # a single token
+    for pool, fn in ((0, E.e5_encode), (1, E.bge_encode)):
+        out = h.forward_np(ids, mask, pool)
+        ref = fn(w, ids, mask, cfg.num_attention_heads)
+        assert np.isnan(out[4]).all() and np.isnan(ref[4]).all()
+        ok = [0, 1, 2, 3, 5]
+        _check(out[ok], ref[ok], 4e-3, f"pool{pool}")
+        single = h.forward_np(ids[[2]], mask[[2]], pool)
+        np.testing.assert_allclose(single[0], out[2], atol=2e-6)       # batch composition does not change a row
+    with pytest.raises(Exception) as ei:
+        bad = ids.copy(); bad[0, 3] = cfg.vocab_size
+        h.forward_np(bad, mask, 0)
+    assert "token id" in str(ei.value)
+
+
+def test_module_surface_eval_hip_train_torch():
+    """E5Encoder/BGEEncoder as nn.Modules: eval -> HIP path, train -> autograd path, CPU eval -> loud failure."""
+    import torch
+    from transformers import BertConfig
+    from kirag_amd.retriever.encoders import BGEEncoder, E5Encoder
+    cfg = BertConfig(vocab_size=500, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+                     max_position_embeddings=64)
+    torch.manual_seed(0)
+    for cls in (E5Encoder, BGEEncoder):
+        m = cls(cfg, add_pooling_layer=False)
+        m.eval()
+        ids = torch.randint(5, 500, (4, 19)); mask = torch.ones(4, 19, dtype=torch.long); mask[1, 7:] = 0
+        with pytest.raises(RuntimeError):
+            m(ids, mask)                                   # CPU + eval: no fallback
+        m = m.cuda()
+        out = m(ids.cuda(), mask.cuda())
+        assert out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (4, 128) and not out.requires_grad
+        m.train()
+        ref = m(ids.cuda(), mask.cuda())                   # PyTorch fp32 autograd path of the same weights
+        assert ref.requires_grad
+        assert (out - ref.detach()).abs().max().item() <= 4e-3
+        # weights changed in place -> the HIP copy must follow
+        with torch.no_grad():
+            for p in m.parameters():
+                p.mul_(1.01)
+        m.eval()
+        out2 = m(ids.cuda(), mask.cuda())
+        m.train(); ref2 = m(ids.cuda(), mask.cuda()).detach(); m.eval()
+        assert (out2 - ref2).abs().max().item() <= 4e-3
+        assert m.config.hidden_size == 128 and len(list(m.named_parameters())) > 0
