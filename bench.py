@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--query-tokens", type=int, default=32)
+    ap.add_argument("--passages", type=int, default=1024, help="passages per encode-throughput measurement batch")
+    ap.add_argument("--passage-tokens", type=int, default=128)
     ap.add_argument("--coarse-dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-encoder", action="store_true", help="search-only step (query vectors pre-computed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,18 +106,14 @@ def main():
 
     encoder = None
     if not args.no_encoder:
-        try:
-            from kirag_amd.bench_support import make_bench_encoder
-            encoder, tok_ids, tok_mask = make_bench_encoder(dev, nq, args.query_tokens)
-        except ImportError:
-            encoder = None
+        from kirag_amd import bench_support as BS
+        encoder = BS.make_hip_encoder(dev)
+        tok_ids, tok_mask = BS.synthetic_tokens(dev, nq, args.query_tokens, seed=2)
+        pas_ids, pas_mask = BS.synthetic_tokens(dev, args.passages, args.passage_tokens, seed=1)
     searcher = ShardedSearcher(index, row_offset=rank * n, world=world)
 
     def step():
-        if encoder is not None:
-            qv = encoder(tok_ids, tok_mask)
-        else:
-            qv = q_vec
+        qv = encoder.forward(tok_ids, tok_mask, 0) if encoder is not None else q_vec   # [nq, d] fp32 on the device
         return searcher.search(qv, k)
 
     for _ in range(args.warmup):
@@ -138,6 +136,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    enc_info = None
+    if encoder is not None:
+        # passages-encoded/s leg of the metric (BASELINE config 1/2 passage shape: 128 tokens), same protocol
+        for _ in range(max(1, args.warmup)):
+            encoder.forward(pas_ids, pas_mask, 0)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            encoder.forward(pas_ids, pas_mask, 0)
+        torch.cuda.synchronize()
+        te = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        te = float(te.item())
+        fl = BS.encoder_flops(encoder.cfg, pas_mask.sum(1))
+        enc_info = {"passages_per_s": args.passages * world * args.steps / te, "batch": args.passages, "tokens": args.passage_tokens,
+                    "tflops_per_gpu": fl * args.steps / te / 1e12, "frac_of_mfma_peak": fl * args.steps / te / PEAK_MFMA_DENSE_16BIT,
+                    "algorithmic_gflop_per_passage": fl / args.passages / 1e9}
+
     if rank == 0:
         st = index.stats()
         ms_step = dt / args.steps * 1e3
@@ -159,6 +178,7 @@ def main():
                          "launch_ms": coarse * 1e3,
                          "note": "one 'launch' = one coarse scan of the shard = the sum of its 3-5 k_coarse round launches; "
                                  "algorithmic FLOPs = 2*nq*rows*dim"},
+            "encode": enc_info,
             "search_stats": {kk: st[kk] for kk in ("queries", "certified", "fallback", "overflow", "reranked_rows", "coarse_rounds")},
         }
         if not args.no_cpu_baseline:
