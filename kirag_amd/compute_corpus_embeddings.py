@@ -1,0 +1,133 @@
+"""MI355X counterpart of the reference's ``compute_corpus_embeddings.py`` (``cal_doc_embeddings`` :50-134, flags :25-47).
+
+Same flags, same output files — ``corpus_embeddings_{start}_{end}.pkl`` (fp32 ``torch.Tensor [n, hidden]``, rows in corpus-index
+order) and ``passage_id_list_{start}_{end}.pkl`` (``List[str]``), ``n <= --num_passage_per_index_file`` — readable by the
+reference's ``faiss_index_corpus.py`` and by ``kirag_amd.faiss_index_corpus``.
+
+Different by design: one process per GPU, rank r encodes the CONTIGUOUS corpus rows
+``[r*ceil(N/W), (r+1)*ceil(N/W))`` with large packed batches and writes its own shard files — no per-step ``dist.gather`` to
+rank 0, no barriers, no growing ``torch.cat`` on the host.  File boundaries therefore follow the rank shards (plus the
+per-file row cap) instead of fixed 1M blocks; the concatenation of all files in ``end``-index order is identical.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import pickle
+from typing import Optional
+
+import torch
+
+from .collators import COLLATOR_MAP
+from .retriever.retrievers import InBatchRetriever
+from .utils import to_device
+
+logger = logging.getLogger(__file__)
+
+
+def setup_parser(argv=None):
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument("--local_rank", "--local-rank", type=int, default=-1)
+    parser.add_argument("--corpus", type=str, default="2wikimultihopqa", help="the name of the corpus")
+    parser.add_argument("--query_maxlength", type=int, default=512, help="the maxinum number of query tokens")
+    parser.add_argument("--doc_maxlength", type=int, default=512, help="the maxinum number of doc tokens")
+    parser.add_argument("--retriever_name", type=str, default="E5Retriever", choices=["E5Retriever", "BGERetriever"], help="the name of the retriever")
+    parser.add_argument("--retriever_model_name_or_path", type=str, default="intfloat/e5-large-v2", help="the name or path of the retriever model")
+    parser.add_argument("--tokenizer_name_or_path", type=str, default="intfloat/e5-large-v2", help="the name or path of the tokenizer")
+    parser.add_argument("--save_dir", type=str, default="checkpoint")
+    parser.add_argument("--name", type=str, default="e5_retriever")
+    parser.add_argument("--index_folder", type=str, default="2wikimultihopqa")
+    parser.add_argument("--per_gpu_batch_size", type=int, default=8)
+    parser.add_argument("--num_passage_per_index_file", type=int, default=1000000)
+    # MI355X path: passages per encoder launch (rows are batch-invariant, so this changes speed only)
+    parser.add_argument("--encode_batch_size", type=int, default=512)
+    return parser.parse_args(argv)
+
+
+def shard_range(n: int, rank: int, world: int):
+    per = (n + world - 1) // world
+    return min(rank * per, n), min((rank + 1) * per, n)
+
+
+def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, world: int = 1, indexer=None, device: Optional[torch.device] = None):
+    """Encode this rank's contiguous shard of ``corpus_dataset`` (items ``{"index": int, "passage": str}`` plus
+    ``index_to_passage_id``), write the reference's shard files, and (optionally) add the rows to a resident ``indexer``.
+    Returns ``(start, end)`` of the rows handled."""
+    if device is None:
+        device = torch.device("cuda:0") if args.local_rank < 0 else torch.device(f"cuda:{args.local_rank}")
+    model = model.to(device)
+    model.eval()
+    folder = os.path.join(args.save_dir, args.name, args.index_folder)
+    os.makedirs(folder, exist_ok=True)
+    start, end = shard_range(len(corpus_dataset), rank, world)
+    bs = max(int(getattr(args, "encode_batch_size", 512)), int(args.per_gpu_batch_size))
+    cap = int(args.num_passage_per_index_file)
+    buf, buf_ids, file_start = [], [], start
+
+    def flush(upto):
+        nonlocal buf, buf_ids, file_start
+        if not buf_ids:
+            return
+        emb = torch.cat(buf, dim=0)
+        logger.info(f"Finished calculating embeddings from {file_start} to {upto - 1}. Saving embeddings to {folder} ...")
+        with open(os.path.join(folder, f"corpus_embeddings_{file_start}_{upto - 1}.pkl"), "wb") as f:
+            pickle.dump(emb, f)
+        with open(os.path.join(folder, f"passage_id_list_{file_start}_{upto - 1}.pkl"), "wb") as f:
+            pickle.dump(buf_ids, f)
+        buf, buf_ids, file_start = [], [], upto
+
+    for s in range(start, end, bs):
+        e = min(s + bs, end)
+        items = [corpus_dataset[i] for i in range(s, e)]
+        inputs = to_device(collator.encode_doc([it["passage"] for it in items]), device)
+        emb = model.doc(inputs).detach()                     # HIP path (eval mode), stays on the GPU
+        ids = [corpus_dataset.index_to_passage_id[it["index"]] for it in items]
+        if indexer is not None:
+            indexer.index_data(ids, emb)                     # device-to-device append into the resident shard
+        emb = emb.cpu()
+        while len(buf_ids) + len(ids) > cap:                 # respect the per-file row cap
+            take = cap - len(buf_ids)
+            buf.append(emb[:take]); buf_ids.extend(ids[:take])
+            flush(file_start + cap)
+            emb, ids = emb[take:], ids[take:]
+        buf.append(emb); buf_ids.extend(ids)
+        if len(buf_ids) == cap:
+            flush(file_start + cap)
+    flush(end)
+    return start, end
+
+
+def main(argv=None):
+    import torch.distributed as dist
+    from transformers import AutoTokenizer
+    args = setup_parser(argv)
+    world, rank = 1, 0
+    if args.local_rank >= 0 or "RANK" in os.environ:
+        if args.local_rank < 0:
+            args.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+        world, rank = dist.get_world_size(), dist.get_rank()
+    os.makedirs(os.path.join(args.save_dir, args.name), exist_ok=True)
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s: - %(message)s")
+    tokenizer = AutoTokenizer.from_pretrained(args.tokenizer_name_or_path)
+    if tokenizer.pad_token is None or tokenizer.pad_token_id is None:
+        logger.warning("Missing padding token, adding a new pad token!")
+        tokenizer.add_special_tokens({"pad_token": '[PAD]'})
+    collator = COLLATOR_MAP[args.retriever_name](tokenizer=tokenizer, query_maxlength=args.query_maxlength, doc_maxlength=args.doc_maxlength)
+    try:   # corpus datasets are the reference's own (dataset/corpus.py, out of scope): needs the reference on PYTHONPATH
+        from utils.const import CORPUS_MAP
+    except ImportError as e:
+        raise SystemExit("--corpus needs the KiRAG repository on PYTHONPATH (dataset/corpus.py, utils/const.py CORPUS_MAP)") from e
+    corpus_dataset = CORPUS_MAP[args.corpus](title_prefix="title: ", passage_prefix="text: ")
+    model = InBatchRetriever(retriever_name=args.retriever_name, model_name_or_path=args.retriever_model_name_or_path,
+                             local_rank=args.local_rank, temperature=0.01)
+    cal_doc_embeddings(args, model, corpus_dataset, collator, rank=rank, world=world)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

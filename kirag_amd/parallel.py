@@ -59,8 +59,8 @@ class ShardedSearcher:
             else:
                 s, i = self.index.search(q.cpu().numpy() if torch.is_tensor(q) else q, kl)
                 sc[:, :kl] = torch.from_numpy(s).to(dev); ids[:, :kl] = torch.from_numpy(i + self.row_offset).to(dev)
-        all_s = torch.empty((self.world, nq, k), dtype=torch.float32, device=dev)
-        all_i = torch.empty((self.world, nq, k), dtype=torch.int64, device=dev)
+        all_s = torch.empty((self.world * nq, k), dtype=torch.float32, device=dev)   # rank-major concatenation
+        all_i = torch.empty((self.world * nq, k), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(all_s, sc, group=self.group)
         dist.all_gather_into_tensor(all_i, ids, group=self.group)
-        return merge_topk(all_s.cpu().numpy(), all_i.cpu().numpy(), k)
+        return merge_topk(all_s.view(self.world, nq, k).cpu().numpy(), all_i.view(self.world, nq, k).cpu().numpy(), k)

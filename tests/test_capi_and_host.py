@@ -1,0 +1,250 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/kirag_amd.h declares, fails loudly without a
+GPU (no fallback), host-only entry points work, and the host-side mirrors of the reference surface behave as pinned by the
+golden vectors."""
+import ctypes as C
+import os
+import pickle
+import re
+import tempfile
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from kirag_amd import _lib
+from oracle import search_np as S
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NO_GPU = not torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "kirag_amd.h")).read()
+    declared = set(re.findall(r"\b(kr_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 19
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.kr_abi_version() == 1
+
+
+@pytest.mark.skipif(not NO_GPU, reason="checks the no-GPU failure mode")
+def test_compute_calls_fail_loudly_without_gpu():
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.kr_index_create(64, 0, 0, 0, C.byref(h))
+    assert rc == -19 and b"no CPU fallback" in lib.kr_last_error()
+    from kirag_amd.retriever.index import Indexer
+    with pytest.raises(_lib.KiragAmdError):
+        Indexer(64)
+    cfg = _lib.BertCfg(128, 2, 2, 512, 100, 64, 2, 1e-12)
+    assert lib.kr_encoder_create(C.byref(cfg), 0, C.byref(h)) == -19
+
+
+def test_argument_validation_before_any_device_work():
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.kr_index_create(63, 0, 0, 0, C.byref(h)) == -22 and b"vector size" in lib.kr_last_error()
+    assert lib.kr_index_create(64, 1, 0, 0, C.byref(h)) == -22          # l2 metric not implemented
+    cfg = _lib.BertCfg(100, 2, 2, 512, 100, 64, 2, 1e-12)               # hidden not a multiple of 128
+    assert lib.kr_encoder_create(C.byref(cfg), 0, C.byref(h)) == -22
+    from kirag_amd.retriever.index import Indexer
+    with pytest.raises(NotImplementedError):
+        Indexer(64, metric="l2")
+    with pytest.raises(NotImplementedError):
+        Indexer(64, n_subquantizers=8)
+
+
+def test_host_merge_matches_oracle():
+    from kirag_amd.parallel import merge_topk
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((900, 32)).astype(np.float32); q = rng.standard_normal((11, 32)).astype(np.float32)
+    x[700] = x[20]
+    so, io = S.search_canonical(q, x, 16)
+    ss, ii = [], []
+    for a, b in ((0, 300), (300, 310), (310, 900)):              # middle shard shorter than k -> padded with id -1
+        kk = min(16, b - a)
+        s_, i_ = S.search_canonical(q, x[a:b], kk)
+        s_ = np.pad(s_, ((0, 0), (0, 16 - kk)), constant_values=-np.inf); i_ = np.pad(i_ + a, ((0, 0), (0, 16 - kk)), constant_values=-1)
+        ss.append(s_); ii.append(i_)
+    ms, mi = merge_topk(np.stack(ss), np.stack(ii), 16)
+    assert np.array_equal(mi, io) and np.array_equal(ms, so)
+
+
+def _tiny_model_dir(td, golden):
+    from transformers import BertConfig
+    from kirag_amd.retriever.encoders import E5Encoder
+    from oracle import encoder_np as E
+    g = golden("g4_g8_retriever.npz")
+    H, L, heads, FF, vocab, max_pos = [int(v) for v in g["cfg"]]
+    cfg = BertConfig(vocab_size=vocab, hidden_size=H, num_hidden_layers=L, num_attention_heads=heads, intermediate_size=FF,
+                     max_position_embeddings=max_pos, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = E5Encoder(cfg, add_pooling_layer=False)
+    w = E.synth_weights(H, L, FF, vocab, max_pos, seed=int(g["weight_seed"]))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    m.save_pretrained(td)
+    with open(os.path.join(td, "vocab.txt"), "w") as f:
+        f.write("\n".join(str(v) for v in g["vocab"]) + "\n")
+    return g
+
+
+def test_collators_match_reference_golden(golden):
+    from transformers import BertTokenizerFast
+    from kirag_amd.collators import COLLATOR_MAP, BGECollator, E5Collator
+    g = golden("g4_g8_retriever.npz")
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "vocab.txt"), "w") as f:
+            f.write("\n".join(str(v) for v in g["vocab"]) + "\n")
+        tok = BertTokenizerFast(vocab_file=os.path.join(td, "vocab.txt"), do_lower_case=True)
+    queries = [str(v) for v in g["g7.queries"]]; docs = [str(v) for v in g["g7.docs"]]
+    for nm, col in (("e5", E5Collator(tok, 16, 24)), ("bge", BGECollator(tok, 24, 24))):
+        qa, da, q8 = col.encode_query(queries), col.encode_doc(docs), col.encode_query(queries, max_length=8)
+        assert np.array_equal(qa["input_ids"].numpy(), g[f"g7.{nm}.q.ids"]) and np.array_equal(qa["attention_mask"].numpy(), g[f"g7.{nm}.q.mask"])
+        assert np.array_equal(da["input_ids"].numpy(), g[f"g7.{nm}.d.ids"]) and np.array_equal(da["attention_mask"].numpy(), g[f"g7.{nm}.d.mask"])
+        assert np.array_equal(q8["input_ids"].numpy(), g[f"g7.{nm}.q8.ids"])
+    assert set(COLLATOR_MAP) == {"E5Retriever", "BGERetriever"}
+    with pytest.raises(ValueError):
+        E5Collator(tok, 16).encode_query([])
+
+
+def test_retriever_registry_logits_score_and_train_path(golden):
+    """RETRIEVER_MAP / load_retriever / BaseRetriever.compute_logits / score (G4), the training (autograd) forward of
+    InBatchRetriever against the reference's loss and scores (G6), and the loud failure of eval mode on CPU."""
+    from kirag_amd.retriever import retrievers as R
+    assert set(R.RETRIEVER_MAP) == {"E5Retriever", "BGERetriever"}
+    with pytest.raises(KeyError):
+        R.load_retriever("Contriever", "x")
+    with tempfile.TemporaryDirectory() as td:
+        g = _tiny_model_dir(td, golden)
+        ret = R.InBatchRetriever("E5Retriever", td, temperature=0.01)
+        assert ret.hidden_size == int(g["cfg"][0]) and ret.world_size == 1 and ret.device.type == "cpu"
+        T = torch.from_numpy
+        q1, d1, q2, d2, d3 = (T(g[f"g4.{k}"]) for k in ("q1", "d1", "q2", "d2", "d3"))
+        np.testing.assert_allclose(ret.compute_logits(q1, d1).numpy(), g["g4.l11"], rtol=1e-6)
+        np.testing.assert_allclose(ret.compute_logits(q1, d2).numpy(), g["g4.l12"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(ret.compute_logits(q2, d3).numpy(), g["g4.l23"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(ret.compute_logits(q2, d2).numpy(), g["g4.l22"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(ret.score(q2, d2).numpy(), g["g4.s22_t001"], rtol=1e-6, atol=1e-4)
+        ret.temperature = "sqrt"
+        np.testing.assert_allclose(ret.score(q2, d2).numpy(), g["g4.s22_sqrt"], rtol=1e-6, atol=1e-6)
+        ret.temperature = 0.01
+        with pytest.raises(ValueError) as ei:
+            ret.compute_logits(d3, d3)
+        assert str(ei.value) == str(g["g4.err"])
+        qa = {"input_ids": T(g["g7.e5.q.ids"]), "attention_mask": T(g["g7.e5.q.mask"])}
+        da = {"input_ids": T(g["g7.e5.d.ids"]), "attention_mask": T(g["g7.e5.d.mask"])}
+        ret.train()                                              # training = inherited PyTorch autograd path (CPU ok)
+        loss, scores, gq, gd = ret(qa, da, torch.tensor([0, 1, 2]))
+        assert loss.requires_grad
+        np.testing.assert_allclose(gq.detach().numpy(), g["g6.q"], atol=2e-5)
+        np.testing.assert_allclose(scores.detach().numpy(), g["g6.scores"], atol=5e-3)
+        assert abs(float(loss) - float(g["g6.loss"])) < 5e-3
+        a3 = {"input_ids": T(g["g5.ids"]), "attention_mask": T(g["g5.mask"])}
+        np.testing.assert_allclose(ret.doc(a3).detach().numpy(), g["g5.out"], atol=2e-5)       # G5: rank-3 input_ids
+        ret.eval()
+        if NO_GPU:
+            with pytest.raises(RuntimeError) as ei:
+                ret.query(qa)
+            assert "no CPU fallback" in str(ei.value)
+        ret.save_model(os.path.join(td, "resaved")); ret.load_model(os.path.join(td, "resaved"))
+        assert type(ret.encoder).__name__ == "E5Encoder"
+
+
+class _FakeRetriever(torch.nn.Module):
+    """Deterministic stand-in encoder for host-logic tests: embedding = normalised bag of token ids."""
+    def __init__(self, d=16):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.randn(200, d, generator=torch.Generator().manual_seed(0)))
+    @property
+    def device(self):
+        return self.w.device
+    def _e(self, a):
+        m = a["attention_mask"].unsqueeze(-1).float()
+        return torch.nn.functional.normalize((self.w[a["input_ids"] % 200] * m).sum(1), dim=-1)
+    def query(self, a, **k): return self._e(a)
+    def doc(self, a, **k): return self._e(a)
+
+
+class _WordTok:
+    """whitespace tokenizer with padding=True / truncation semantics, enough for collator + DenseRetriever plumbing"""
+    pad_token = "[PAD]"; pad_token_id = 0
+    def __call__(self, texts, max_length, padding, truncation, return_tensors):
+        rows = [[(hash(w) % 190) + 5 for w in t.split()][:max_length] for t in texts]
+        L = max_length if padding == "max_length" else max(len(r) for r in rows)
+        ids = torch.zeros(len(rows), L, dtype=torch.long); mask = torch.zeros_like(ids)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = torch.tensor(r); mask[i, :len(r)] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+class _OracleBackedIndexer(S.OracleIndexer):
+    pass
+
+
+def test_dense_retriever_result_structure_and_batch_invariance():
+    from kirag_amd.collators import E5Collator
+    from kirag_amd.retriever.retrievers import DenseRetriever
+    ret = _FakeRetriever(); col = E5Collator(_WordTok(), 12, 20)
+    docs = [f"title:  t{i}, text:  word{i} common tail {i % 7}" for i in range(60)]
+    ix = _OracleBackedIndexer(16)
+    dr = DenseRetriever(ret, col, indexer=None, corpus=None, batch_size=4, encode_batch_size=8)
+    demb = dr.calculate_document_embeddings(docs)
+    assert demb.device.type == "cpu" and tuple(demb.shape) == (60, 16)
+    dr2 = DenseRetriever(ret, col, batch_size=4, encode_batch_size=64)
+    torch.testing.assert_close(dr2.calculate_document_embeddings(docs), demb)          # chunking does not change rows
+    ix.index_data([str(1000 + i) for i in range(60)], demb.numpy())
+    with pytest.raises(AssertionError):
+        dr("q", 3)                                                                       # indexer missing
+    with pytest.raises(AssertionError):
+        dr.calculate_query_embeddings([])
+    dr.indexer = ix
+    out = dr(["word3 common", "word10"], topk=4)
+    assert len(out) == 2 and len(out[0]) == 4
+    assert set(out[0][0]) == {"id", "score"} and isinstance(out[0][0]["id"], str) and isinstance(out[0][0]["score"], np.float32)
+    one = dr("word3 common", topk=4)
+    assert [d["id"] for d in one] == [d["id"] for d in out[0]]
+
+    class Corpus:
+        def get_document(self, pid): return {"id": pid, "title": "t", "text": "x"}
+    dr.corpus = Corpus()
+    out = dr(["word3 common"], topk=2)
+    assert isinstance(out[0][0]["score"], float) and out[0][0]["title"] == "t"
+    docs_sorted = dr.get_documents({"1003": 0.1, "1004": 0.9})
+    assert [d["id"] for d in docs_sorted] == ["1004", "1003"] and docs_sorted[0]["score"] == 0.9
+    with pytest.raises(ValueError):
+        dr.get_documents(("1003",))
+
+
+def test_corpus_embedding_shard_files_and_index_builder(tmp_path):
+    """cal_doc_embeddings' file contract (compute_corpus_embeddings.py:101-120) with a fake encoder on CPU, then the
+    faiss_index_corpus reader's ordering / id matching (faiss_index_corpus.py:23-52) up to the Indexer boundary."""
+    from kirag_amd import compute_corpus_embeddings as CC
+    from kirag_amd.collators import E5Collator
+
+    class Corpus:
+        def __init__(self, n):
+            self.index_to_passage_id = {i: str(7 * i + 1) for i in range(n)}
+        def __len__(self): return len(self.index_to_passage_id)
+        def __getitem__(self, i): return {"index": i, "passage": f"title:  t{i}, text:  word{i} tail {i % 5}"}
+
+    corpus = Corpus(53); ret = _FakeRetriever(); col = E5Collator(_WordTok(), 12, 20)
+    args = SimpleNamespace(local_rank=-1, save_dir=str(tmp_path), name="n", index_folder="f", per_gpu_batch_size=8,
+                           num_passage_per_index_file=20, encode_batch_size=16)
+    spans = [CC.cal_doc_embeddings(args, ret, corpus, col, rank=r, world=2, device=torch.device("cpu")) for r in range(2)]
+    assert spans == [(0, 27), (27, 53)] and CC.shard_range(53, 1, 2) == (27, 53) and CC.shard_range(5, 7, 8) == (5, 5)
+    folder = os.path.join(str(tmp_path), "n", "f")
+    files = sorted(os.listdir(folder))
+    assert "corpus_embeddings_0_19.pkl" in files and "corpus_embeddings_20_26.pkl" in files and "passage_id_list_47_52.pkl" in files
+    from kirag_amd.faiss_index_corpus import sort_embedding_files
+    import glob
+    embs, ids = [], []
+    for f in sort_embedding_files(glob.glob(os.path.join(folder, "corpus_embeddings_*.pkl"))):
+        e = pickle.load(open(f, "rb")); embs.append(e)
+        ids += pickle.load(open(f.replace("corpus_embeddings", "passage_id_list"), "rb"))
+        assert isinstance(e, torch.Tensor) and e.dtype == torch.float32 and len(e) <= 20
+    full = torch.cat(embs)
+    assert ids == [str(7 * i + 1) for i in range(53)]
+    ref = ret.doc(col.encode_doc([corpus[i]["passage"] for i in range(53)]))
+    torch.testing.assert_close(full, ref.detach())

@@ -1,0 +1,67 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: the sharded search's all-gather + host merge equals the unsharded
+search, and the in-batch gather helpers reproduce utils/utils.py:158-188."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import search_np as S
+        from kirag_amd.parallel import ShardedSearcher
+        from kirag_amd import utils as U
+        from kirag_amd.compute_corpus_embeddings import shard_range
+        rng = np.random.default_rng(0)
+        x = rng.standard_normal((1001, 32)).astype(np.float32); q = rng.standard_normal((9, 32)).astype(np.float32)
+        x[900] = x[3]                                            # a tie across the shard boundary
+        a, b = shard_range(len(x), rank, world)
+
+        class Shard:                                             # oracle-backed local index (CPU stand-in for FlatIPIndex)
+            ntotal = b - a
+            def search(self, qq, k): return S.search_canonical(np.asarray(qq), x[a:b], k)
+        s, i = ShardedSearcher(Shard(), row_offset=a, world=world).search(torch.from_numpy(q), 20)
+        so, io = S.search_canonical(q, x, 20)
+        assert np.array_equal(i, io) and np.array_equal(s, so)
+        # a shard smaller than k contributes what it has
+        class Small:
+            ntotal = 5 if rank == 0 else 600
+            def search(self, qq, k): return S.search_canonical(np.asarray(qq), (x[:5] if rank == 0 else x[5:605]), k)
+        s2, i2 = ShardedSearcher(Small(), row_offset=0 if rank == 0 else 5, world=world).search(torch.from_numpy(q), 8)
+        so2, io2 = S.search_canonical(q, x[:605], 8)
+        assert np.array_equal(i2, io2) and np.array_equal(s2, so2)
+        # in-batch helpers
+        emb = torch.full((2, 4), float(rank), requires_grad=True)
+        g = U.get_global_embeddings_for_inbatchtraining(rank, world, emb)
+        assert tuple(g.shape) == (4, 4) and g.requires_grad and torch.equal(g[2 * rank:2 * rank + 2].detach(), emb.detach())
+        assert torch.equal(g[:, 0].detach(), torch.tensor([0., 0., 1., 1.]))
+        lab = U.get_global_labels_for_inbatchtraining(rank, world, torch.tensor([0, 1]), local_doc_size=3)
+        assert lab.tolist() == [0, 1, 3, 4]
+        assert U.get_global_labels_for_inbatchtraining(rank, world, None, 3) is None
+        ret[rank] = "ok"
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_and_gathers_world2_gloo():
+    from oracle import search_np as S
+    S.build()                                                    # compile the C oracle once, before forking readers
+    port = _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret.get(0) == "ok" and ret.get(1) == "ok", (ret.get(0), ret.get(1))

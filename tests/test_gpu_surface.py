@@ -1,0 +1,117 @@
+"""GPU end-to-end tests of the drop-in surface: DenseRetriever / e5.py / compute_corpus_embeddings / faiss_index_corpus on the
+HIP encoder + HIP index, checked against the reference-generated goldens (G8) and the oracle."""
+import os
+import pickle
+import tempfile
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder_np as E
+from oracle import search_np as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(td, golden):
+    from transformers import BertConfig, BertTokenizerFast
+    from kirag_amd.retriever.encoders import E5Encoder
+    g = golden("g4_g8_retriever.npz")
+    H, L, heads, FF, vocab, max_pos = [int(v) for v in g["cfg"]]
+    cfg = BertConfig(vocab_size=vocab, hidden_size=H, num_hidden_layers=L, num_attention_heads=heads, intermediate_size=FF,
+                     max_position_embeddings=max_pos)
+    m = E5Encoder(cfg, add_pooling_layer=False)
+    w = E.synth_weights(H, L, FF, vocab, max_pos, seed=int(g["weight_seed"]))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    m.save_pretrained(td)
+    with open(os.path.join(td, "vocab.txt"), "w") as f:
+        f.write("\n".join(str(v) for v in g["vocab"]) + "\n")
+    tok = BertTokenizerFast(vocab_file=os.path.join(td, "vocab.txt"), do_lower_case=True)
+    return g, tok, w, heads
+
+
+def test_dense_retriever_end_to_end(golden):
+    from kirag_amd.collators import E5Collator
+    from kirag_amd.retriever import e5 as e5mod
+    from kirag_amd.retriever.index import Indexer
+    from kirag_amd.retriever.retrievers import DenseRetriever, InBatchRetriever
+    with tempfile.TemporaryDirectory() as td:
+        g, tok, w, heads = _setup(td, golden)
+        ret = InBatchRetriever("E5Retriever", td, temperature=0.01).cuda()
+        col = E5Collator(tokenizer=tok, query_maxlength=16, doc_maxlength=24)
+        queries = [str(v) for v in g["g7.queries"]]; docs = [str(v) for v in g["g7.docs"]]
+        dr = DenseRetriever(retriever=ret, collator=col, indexer=None, corpus=None, batch_size=2)
+        qe = dr.calculate_query_embeddings(queries); de = dr.calculate_document_embeddings(docs, max_length=16)
+        assert qe.device.type == "cpu" and qe.dtype == torch.float32
+        # G8: the reference encodes in batches of 2 (per-batch padding); rows are batch-invariant here
+        assert np.abs(qe.numpy() - g["g8.qemb"]).max() <= 4e-3 and np.abs(de.numpy() - g["g8.demb"]).max() <= 4e-3
+        # a 200-passage corpus through the whole surface
+        rng = np.random.default_rng(1)
+        words = [str(v) for v in g["vocab"] if str(v).isalpha() and len(str(v)) > 1]
+        corpus_docs = ["title:  " + " ".join(rng.choice(words, 2)) + ", text:  " + " ".join(rng.choice(words, int(rng.integers(3, 18)))) for _ in range(200)]
+        demb = dr.calculate_document_embeddings(corpus_docs)
+        ix = Indexer(ret.hidden_size); ix.index_data([str(5000 + i) for i in range(200)], demb.numpy())
+        dr.indexer = ix
+        qs = ["who was born in paris", "capital of france river", corpus_docs[17].split("text:  ")[1]]
+        out = dr(qs, topk=5)
+        qv = dr.calculate_query_embeddings(qs).numpy()
+        so, io = S.search_canonical(qv, demb.numpy(), 5)
+        for r in range(3):
+            assert [d["id"] for d in out[r]] == [str(5000 + j) for j in io[r]]
+            assert np.array_equal(np.array([d["score"] for d in out[r]], np.float32), so[r])
+        # encoder output vs the numpy oracle on the collator's own ids
+        a = col.encode_doc(corpus_docs[:32])
+        ref = E.e5_encode(w, a["input_ids"].numpy(), a["attention_mask"].numpy(), heads)
+        assert np.abs(demb[:32].numpy() - ref).max() <= 4e-3
+        # retriever/e5.py singleton sharing the resident encoder
+        e5mod.set_model(ret.encoder, tok)
+        eq = e5mod.get_e5_embeddings_for_query(queries, max_length=16)
+        assert eq.device.type == "cpu" and np.abs(eq.numpy() - qe.numpy()).max() <= 1e-5
+        ed = e5mod.get_e5_embeddings_for_document([d for d in docs], max_length=16)
+        assert np.abs(ed.numpy() - de.numpy()).max() <= 1e-5
+
+
+def test_corpus_encode_files_index_and_search(golden, tmp_path):
+    from kirag_amd import compute_corpus_embeddings as CC
+    from kirag_amd import faiss_index_corpus as FI
+    from kirag_amd.collators import E5Collator
+    from kirag_amd.retriever.index import Indexer
+    from kirag_amd.retriever.retrievers import InBatchRetriever
+    with tempfile.TemporaryDirectory() as td:
+        g, tok, w, heads = _setup(td, golden)
+        ret = InBatchRetriever("E5Retriever", td, temperature=0.01)
+        col = E5Collator(tokenizer=tok, query_maxlength=16, doc_maxlength=32)
+        rng = np.random.default_rng(2)
+        words = [str(v) for v in g["vocab"] if str(v).isalpha() and len(str(v)) > 1]
+
+        class Corpus:
+            def __init__(self, n):
+                self.p = ["title:  " + " ".join(rng.choice(words, 2)) + ", text:  " + " ".join(rng.choice(words, int(rng.integers(3, 25)))) for _ in range(n)]
+                self.index_to_passage_id = {i: str(3 * i + 10) for i in range(n)}
+            def __len__(self): return len(self.p)
+            def __getitem__(self, i): return {"index": i, "passage": self.p[i]}
+        corpus = Corpus(301)
+        args = SimpleNamespace(local_rank=-1, save_dir=str(tmp_path), name="e5", index_folder="c", per_gpu_batch_size=8,
+                               num_passage_per_index_file=100, encode_batch_size=64)
+        resident = Indexer(ret.hidden_size)
+        for r in range(2):      # two "ranks" run back to back on the one GPU
+            CC.cal_doc_embeddings(args, ret, corpus, col, rank=r, world=2, indexer=resident if r == 0 else None)
+        folder = os.path.join(str(tmp_path), "e5", "c")
+        assert len([f for f in os.listdir(folder) if f.startswith("corpus_embeddings_")]) == 4
+        built = FI.build_faiss_index(SimpleNamespace(index_folder=folder, embedding_size=ret.hidden_size))
+        assert built.index.ntotal == 301 and not [f for f in os.listdir(folder) if f.endswith(".pkl")]
+        assert sorted(os.listdir(folder)) == ["index.faiss", "index_meta.faiss"]
+        assert built.index_id_to_db_id.tolist() == [3 * i + 10 for i in range(301)]
+        loaded = Indexer(ret.hidden_size); loaded.deserialize_from(folder)
+        x = loaded.index.reconstruct_n(0, 301)
+        a = col.encode_doc(corpus.p[:40])
+        ref = E.e5_encode(w, a["input_ids"].numpy(), a["attention_mask"].numpy(), heads)
+        assert np.abs(x[:40] - ref).max() <= 4e-3
+        assert np.array_equal(resident.index.reconstruct_n(0, 151), x[:151])          # rank 0's resident shard == its files
+        q = x[[5, 150, 300]]
+        res = loaded.search_knn(q, 3, verbose=False)
+        so, io = S.search_canonical(q, x, 3)
+        for r in range(3):
+            assert res[r][0] == [str(3 * j + 10) for j in io[r]] and np.array_equal(res[r][1], so[r])
