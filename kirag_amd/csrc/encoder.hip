@@ -22,7 +22,9 @@
 
 namespace kr {
 
-using ShapeE = GemmShape<128, 128, 2, 2>;   // rows = output features, cols = tokens
+using ShapeE = GemmShape<256, 256, 2, 4>;   // rows = output features, cols = tokens
+constexpr int PROJ_STAGES = 2;
+constexpr int PROJ_LDS = PROJ_STAGES * ShapeE::STAGE_BYTES;
 
 struct LayerW {
     uint16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;   // bf16 [out, in]
@@ -46,6 +48,7 @@ struct Encoder {
     float *xf = nullptr, *y = nullptr, *out = nullptr;
     uint16_t *xb = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *ctx = nullptr, *h = nullptr;
     int lastB = 0, lastS = 0;
+    int num_cu = 256;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -209,65 +212,106 @@ struct ProjArgs {
     const float* resid; float* outf;                               // residual epilogue: outf[t,F] = acc + bias + resid[t,F]
 };
 
-enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2 };
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_VT = 3 };
 
-// XCD-aware map: XCD x owns feature tiles {x, x+8, ...} (its weight slice stays in that L2) and walks all token tiles
-__device__ __forceinline__ bool proj_tile_map(int bid, int tm_count, int tn_count, int& tm, int& tn) {
-    const int xcd = bid & 7, j = bid >> 3;
-    const int per = (tm_count + 7) >> 3;
-    tm = xcd + 8 * (j % per);
-    tn = j / per;
-    return tm < tm_count && tn < tn_count;
+// erf-GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of
+// the result): ~15 VALU instead of libm erff's ~45 — the epilogue of a persistent one-block-per-CU GEMM is not hidden by other work.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);                 // erf(|x|/sqrt2)
+    const float erf_s = copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_s);
 }
 
+// persistent streaming projection (gemm_nt_stream, 256x256 tiles, 8 waves of 128 features x 64 tokens, 2-stage LDS ring).
+// Tiles are walked in patches of (4 feature tiles x 8 token tiles) per XCD so that a weight slice and a token slice stay in
+// that XCD's L2 while they are reused.
 template <int EPI>
-__global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a, int tn_count) {
+__global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int tm, tn;
-    if (!proj_tile_map(blockIdx.x, a.F / ShapeE::BM, tn_count, tm, tn)) return;
     const int T = *a.Tp;
-    const int m0 = tm * ShapeE::BM, n0 = tn * ShapeE::BN;
-    if (n0 >= T) return;
-    gemm_nt_block<BF16, ShapeE>(a.W, a.K, a.F, a.X, a.K, T, a.K, m0, n0, smem, [&](AccTile<ShapeE>& acc) {
+    const int64_t tm_count = (a.F + ShapeE::BM - 1) / ShapeE::BM, tn_count = (T + ShapeE::BN - 1) / ShapeE::BN;
+    gemm_nt_stream<BF16, ShapeE, PROJ_STAGES>(
+        a.W, a.K, a.F, a.X, a.K, T, a.K, tm_count * tn_count, smem,
+        [&](int64_t nat, int64_t& m0, int64_t& n0) {
+            int64_t tm, tn;
+            patch_coord(nat, tm_count, tn_count, tm, tn);
+            m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
+        },
+        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) {
 #pragma unroll
-        for (int ni = 0; ni < ShapeE::TN; ++ni) {
-            const int t = n0 + acc.col(ni);
-            if (t >= T) continue;
+            for (int ni = 0; ni < ShapeE::TN; ++ni) {
+                const int t = (int)n0 + acc.col(ni);
+                if (t >= T) continue;
 #pragma unroll
-            for (int mi = 0; mi < ShapeE::TM; ++mi) {
+                for (int mi = 0; mi < ShapeE::TM; ++mi) {
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int f = m0 + acc.m_wave + mi * 32 + 8 * gq + 4 * (acc.lane >> 5);
-                    const float4 b = *reinterpret_cast<const float4*>(a.bias + f);
-                    float v0 = acc.v[mi][ni][4 * gq + 0] + b.x, v1 = acc.v[mi][ni][4 * gq + 1] + b.y;
-                    float v2 = acc.v[mi][ni][4 * gq + 2] + b.z, v3 = acc.v[mi][ni][4 * gq + 3] + b.w;
-                    if constexpr (EPI == EPI_QKV) {
-                        const int which = m0 / a.H;   // block-uniform: H % 128 == 0
-                        if (which < 2) {
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int f = (int)m0 + acc.m_wave + mi * 32 + 8 * gq + 4 * (acc.lane >> 5);
+                        if (f >= a.F) continue;
+                        const float4 b = *reinterpret_cast<const float4*>(a.bias + f);
+                        float v0 = acc.v[mi][ni][4 * gq + 0] + b.x, v1 = acc.v[mi][ni][4 * gq + 1] + b.y;
+                        float v2 = acc.v[mi][ni][4 * gq + 2] + b.z, v3 = acc.v[mi][ni][4 * gq + 3] + b.w;
+                        if constexpr (EPI == EPI_QKV) {
+                            const int which = f < a.H ? 0 : 1;   // a 4-feature group never straddles q|k (H % 128 == 0)
                             ushort4 o;
                             o.x = BF16::from_f32(v0); o.y = BF16::from_f32(v1); o.z = BF16::from_f32(v2); o.w = BF16::from_f32(v3);
                             uint16_t* dst = (which == 0 ? a.out0 : a.out1) + (int64_t)t * a.H + (f - which * a.H);
                             *reinterpret_cast<ushort4*>(dst) = o;
+                        } else if constexpr (EPI == EPI_RESID) {
+                            const float4 r = *reinterpret_cast<const float4*>(a.resid + (int64_t)t * a.F + f);
+                            *reinterpret_cast<float4*>(a.outf + (int64_t)t * a.F + f) = make_float4(v0 + r.x, v1 + r.y, v2 + r.z, v3 + r.w);
                         } else {
-                            uint16_t* dst = a.outT + (int64_t)(f - 2 * a.H) * a.ldT + t;
-                            dst[0] = BF16::from_f32(v0); dst[a.ldT] = BF16::from_f32(v1);
-                            dst[2 * a.ldT] = BF16::from_f32(v2); dst[3 * a.ldT] = BF16::from_f32(v3);
+                            ushort4 o;   // HF ACT2FN["gelu"]: 0.5 x (1 + erf(x / sqrt 2))
+                            o.x = BF16::from_f32(gelu_erf_fast(v0)); o.y = BF16::from_f32(gelu_erf_fast(v1));
+                            o.z = BF16::from_f32(gelu_erf_fast(v2)); o.w = BF16::from_f32(gelu_erf_fast(v3));
+                            *reinterpret_cast<ushort4*>(a.out0 + (int64_t)t * a.F + f) = o;
                         }
-                    } else if constexpr (EPI == EPI_RESID) {
-                        const float4 r = *reinterpret_cast<const float4*>(a.resid + (int64_t)t * a.F + f);
-                        *reinterpret_cast<float4*>(a.outf + (int64_t)t * a.F + f) = make_float4(v0 + r.x, v1 + r.y, v2 + r.z, v3 + r.w);
-                    } else {
-                        ushort4 o;   // HF ACT2FN["gelu"]: 0.5 x (1 + erf(x / sqrt 2))
-                        o.x = BF16::from_f32(0.5f * v0 * (1.f + erff(v0 * 0.70710678118654752f)));
-                        o.y = BF16::from_f32(0.5f * v1 * (1.f + erff(v1 * 0.70710678118654752f)));
-                        o.z = BF16::from_f32(0.5f * v2 * (1.f + erff(v2 * 0.70710678118654752f)));
-                        o.w = BF16::from_f32(0.5f * v3 * (1.f + erff(v3 * 0.70710678118654752f)));
-                        *reinterpret_cast<ushort4*>(a.out0 + (int64_t)t * a.F + f) = o;
                     }
                 }
             }
-        }
-    });
+        });
+}
+
+// V^T projection: roles swapped (rows = tokens, cols = value features) so that a lane's 4 consecutive accumulator registers
+// are 4 consecutive TOKENS of one feature -> 8-byte stores into the transposed [H, ldT] layout the attention kernel reads.
+__global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj_vt(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = *a.Tp;
+    const int64_t tm_count = (T + ShapeE::BM - 1) / ShapeE::BM, tn_count = (a.F + ShapeE::BN - 1) / ShapeE::BN;
+    gemm_nt_stream<BF16, ShapeE, PROJ_STAGES>(
+        a.X, a.K, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
+        [&](int64_t nat, int64_t& m0, int64_t& n0) {
+            const int64_t tm = nat / tn_count, tn = nat % tn_count;   // the feature tiles of one token tile are adjacent
+            m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
+        },
+        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) {
+#pragma unroll
+            for (int ni = 0; ni < ShapeE::TN; ++ni) {
+                const int f = (int)n0 + acc.col(ni);
+                if (f >= a.F) continue;
+                const float b = a.bias[f];
+                uint16_t* dst = a.outT + (int64_t)f * a.ldT;
+#pragma unroll
+                for (int mi = 0; mi < ShapeE::TM; ++mi) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int t = (int)m0 + acc.m_wave + mi * 32 + 8 * gq + 4 * (acc.lane >> 5);   // multiple of 4; ldT - T >= 64 slack
+                        if (t >= T) continue;
+                        ushort4 o;
+                        o.x = BF16::from_f32(acc.v[mi][ni][4 * gq + 0] + b); o.y = BF16::from_f32(acc.v[mi][ni][4 * gq + 1] + b);
+                        o.z = BF16::from_f32(acc.v[mi][ni][4 * gq + 2] + b); o.w = BF16::from_f32(acc.v[mi][ni][4 * gq + 3] + b);
+                        *reinterpret_cast<ushort4*>(dst + t) = o;
+                    }
+                }
+            }
+        });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -498,13 +542,20 @@ static int parse_name(const Encoder* e, const char* name, int& slot, int64_t& nu
     return fail(KR_EINVAL, "unknown tensor name '%s'", name);
 }
 
-static void launch_proj(int epi, const ProjArgs& a, int tn_count, hipStream_t st) {
-    const int tm_count = a.F / ShapeE::BM;
-    const int per = (tm_count + 7) / 8;
-    const unsigned grid = (unsigned)(8 * per * tn_count);
-    if (epi == EPI_QKV) hipLaunchKernelGGL(k_proj<EPI_QKV>, dim3(grid), dim3(ShapeE::NTHREADS), ShapeE::LDS_BYTES, st, a, tn_count);
-    else if (epi == EPI_RESID) hipLaunchKernelGGL(k_proj<EPI_RESID>, dim3(grid), dim3(ShapeE::NTHREADS), ShapeE::LDS_BYTES, st, a, tn_count);
-    else hipLaunchKernelGGL(k_proj<EPI_GELU>, dim3(grid), dim3(ShapeE::NTHREADS), ShapeE::LDS_BYTES, st, a, tn_count);
+static int launch_proj(int epi, const ProjArgs& a, int num_cu, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, PROJ_LDS));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, PROJ_LDS));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, PROJ_LDS));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_vt), hipFuncAttributeMaxDynamicSharedMemorySize, PROJ_LDS));
+        attr_set = true;
+    }
+    if (epi == EPI_VT) hipLaunchKernelGGL(k_proj_vt, dim3(num_cu), dim3(ShapeE::NTHREADS), PROJ_LDS, st, a);
+    else if (epi == EPI_QKV) hipLaunchKernelGGL(k_proj<EPI_QKV>, dim3(num_cu), dim3(ShapeE::NTHREADS), PROJ_LDS, st, a);
+    else if (epi == EPI_RESID) hipLaunchKernelGGL(k_proj<EPI_RESID>, dim3(num_cu), dim3(ShapeE::NTHREADS), PROJ_LDS, st, a);
+    else hipLaunchKernelGGL(k_proj<EPI_GELU>, dim3(num_cu), dim3(ShapeE::NTHREADS), PROJ_LDS, st, a);
+    return 0;
 }
 
 }  // namespace kr
@@ -523,6 +574,7 @@ int kr_encoder_create(const kr_bert_cfg* cfg, int device, kr_encoder** out) {
     KR_TRY(select_device(device));
     Encoder* e = new Encoder();
     e->cfg = *cfg; e->device = device;
+    { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) e->num_cu = (p.multiProcessorCount / 8) * 8; }
     e->L.resize(cfg->layers);
     e->got.assign(T_LAYER0 + (size_t)cfg->layers * L_COUNT, 0);
     const size_t H = cfg->hidden, FF = cfg->intermediate;
@@ -638,7 +690,6 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
                        e->tok_pos, e->d_err);
     const int64_t maxT = (int64_t)B * (S + 4);
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
-    const int tn_count = (int)((maxT + ShapeE::BN - 1) / ShapeE::BN);
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->xf, e->xb);
     const dim3 attn_grid((unsigned)((S + 1 + 31) / 32), (unsigned)((heads + 3) / 4), (unsigned)B);
@@ -646,19 +697,21 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         ProjArgs a{};
         a.Tp = e->d_T; a.H = H;
         // q | k | v^T
-        a.W = l.wqkv; a.X = e->xb; a.F = 3 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k; a.outT = e->vT; a.ldT = e->ldv;
-        launch_proj(EPI_QKV, a, tn_count, st);
+        a.W = l.wqkv; a.X = e->xb; a.F = 2 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k;
+        KR_TRY(launch_proj(EPI_QKV, a, e->num_cu, st));
+        a.W = l.wqkv + (size_t)2 * H * H; a.F = H; a.bias = l.bqkv + 2 * H; a.outT = e->vT; a.ldT = e->ldv;
+        KR_TRY(launch_proj(EPI_VT, a, e->num_cu, st));
         hipLaunchKernelGGL(k_attn, attn_grid, dim3(256), 0, st, e->q, e->k, e->vT, e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, e->ctx);
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo; a.resid = e->xf; a.outf = e->y;
-        launch_proj(EPI_RESID, a, tn_count, st);
+        KR_TRY(launch_proj(EPI_RESID, a, e->num_cu, st));
         hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln1g, l.ln1b, eps, H, e->xf, e->xb);
         // intermediate.dense + GELU
         a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h;
-        launch_proj(EPI_GELU, a, tn_count, st);
+        KR_TRY(launch_proj(EPI_GELU, a, e->num_cu, st));
         // output.dense + residual -> LayerNorm
         a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.resid = e->xf; a.outf = e->y;
-        launch_proj(EPI_RESID, a, tn_count, st);
+        KR_TRY(launch_proj(EPI_RESID, a, e->num_cu, st));
         hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln2g, l.ln2b, eps, H, e->xf, e->xb);
     }
     hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xf, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);

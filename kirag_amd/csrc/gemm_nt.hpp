@@ -150,4 +150,151 @@ __device__ __forceinline__ bool xcd_tile_map(int64_t bid, int64_t tm_count, int 
     return tm < tm_count;
 }
 
+
+
+// =====================================================================================================================
+// v2 main loop: PERSISTENT blocks streaming a sequence of output tiles through a 3-stage LDS ring.
+//   * the LDS-DMA of K-tile g+2 is issued while K-tile g is multiplied: two tiles stay in flight across the single
+//     raw s_barrier per K-tile, retired by a COUNTED s_waitcnt vmcnt (never 0 in steady state) — cdna_hip_programming.md
+//     "Pipelining across barriers"; the ring runs across output-tile boundaries, so a tile's first K-tiles are already
+//     landing while the previous tile's epilogue runs
+//   * iteration g:  wait own DMA(g) -> s_barrier (RAW: every wave's pieces of tile g landed; WAR: every wave is done reading
+//     buffer (g-1)%3) -> issue DMA(g+2) into buffer (g+2)%3 == (g-1)%3 -> multiply buffer g%3
+//   * MFMA fragments are double-buffered across the 16-deep k-steps so ds_read latency sits under the previous k-step's MFMAs
+// Block ids are virtual: block b takes v = b, b+G, b+2G, ... (G = gridDim.x, a multiple of 8) and xcd_chunk_map turns v into
+// a "natural" tile index such that each XCD walks a contiguous run of the natural order.
+// =====================================================================================================================
+
+// bijective: v in [0,total) -> natural index; XCD x (= v % 8) owns the contiguous natural range starting at x*q + min(x,r)
+__device__ __forceinline__ int64_t xcd_chunk_map(int64_t v, int64_t total) {
+    const int64_t q = total >> 3, r = total & 7;
+    const int64_t x = v & 7, j = v >> 3;
+    return x * q + (x < r ? x : r) + j;
+}
+
+// natural index -> (tm, tn) such that 8 consecutive tn of one tm-run are adjacent: groups of (up to) 8 tn, tm walks inside a group
+__device__ __forceinline__ void patch_coord(int64_t n, int64_t tm_count, int64_t tn_count, int64_t& tm, int64_t& tn) {
+    const int64_t g = n / (8 * tm_count);
+    const int64_t rem = n - g * 8 * tm_count;
+    const int64_t gs = (tn_count - 8 * g) < 8 ? (tn_count - 8 * g) : 8;
+    tm = rem / gs;
+    tn = 8 * g + rem % gs;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <class T, class Shape, int STAGES = 3, class Coord, class Epilogue>
+__device__ __forceinline__ void gemm_nt_stream(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb,
+                                               int64_t N, int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
+    constexpr int BM = Shape::BM, BN = Shape::BN, BK = Shape::BK;
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    constexpr int GL = Shape::A_PIECES + Shape::B_PIECES;   // LDS-DMA instructions per wave per K-tile
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / Shape::WN, wn = wave % Shape::WN;
+    const int64_t G = gridDim.x;
+    const int64_t my = (total_tiles > (int64_t)blockIdx.x) ? (total_tiles - blockIdx.x + G - 1) / G : 0;
+    if (my == 0) return;
+    const int nk = K / BK;
+    const int64_t total_g = my * nk;
+
+    // ---- prefetch cursor ---------------------------------------------------------------------------------------
+    const char* pfA; const char* pfB;
+    uint32_t a_off[Shape::A_PIECES], b_off[Shape::B_PIECES];
+    auto setup_src = [&](int64_t i) {
+        int64_t m0, n0;
+        coord(xcd_chunk_map((int64_t)blockIdx.x + i * G, total_tiles), m0, n0);
+        pfA = reinterpret_cast<const char*>(A + m0 * lda);
+        pfB = reinterpret_cast<const char*>(B + n0 * ldb);
+        const int64_t a_left = M - m0, b_left = N - n0;
+#pragma unroll
+        for (int p = 0; p < Shape::A_PIECES; ++p) {
+            int row = (wave + p * Shape::NWAVE) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            if (row >= a_left) row = (int)a_left - 1;
+            a_off[p] = (uint32_t)(row * lda * 2 + chunk * 16);
+        }
+#pragma unroll
+        for (int p = 0; p < Shape::B_PIECES; ++p) {
+            int row = (wave + p * Shape::NWAVE) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            if (row >= b_left) row = (int)b_left - 1;
+            b_off[p] = (uint32_t)(row * ldb * 2 + chunk * 16);
+        }
+    };
+    int64_t pf_g = 0, pf_tile = 0;
+    int pf_kt = 0, pf_slot = 0, cp_slot = 0, inflight = 0;   // ring slots of the next DMA / the next tile to multiply; staged-not-consumed tiles
+    setup_src(0);
+    auto stage_next = [&]() {
+        char* sa = smem + pf_slot * Shape::STAGE_BYTES;
+        char* sb = sa + Shape::A_BYTES;
+        const int64_t kbyte = (int64_t)pf_kt * BK * 2;
+#pragma unroll
+        for (int p = 0; p < Shape::A_PIECES; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(pfA + kbyte + a_off[p]), (lds_void*)(sa + (wave + p * Shape::NWAVE) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < Shape::B_PIECES; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(pfB + kbyte + b_off[p]), (lds_void*)(sb + (wave + p * Shape::NWAVE) * 1024), 16, 0, 0);
+        ++pf_g; ++inflight;
+        pf_slot = (pf_slot + 1 == STAGES) ? 0 : pf_slot + 1;
+        if (++pf_kt == nk) { pf_kt = 0; if (++pf_tile < my) setup_src(pf_tile); }
+    };
+
+    const int frow = lane & 31, fh = lane >> 5;
+    const int fswz = (frow >> 1) & 7;
+    const int a_row_byte = (wm * (BM / Shape::WM) + frow) * 128;
+    const int b_row_byte = (wn * (BN / Shape::WN) + frow) * 128;
+
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p)
+        if (pf_g < total_g) stage_next();
+
+    for (int64_t i = 0; i < my; ++i) {
+        int64_t m0, n0;
+        const int64_t nat = xcd_chunk_map((int64_t)blockIdx.x + i * G, total_tiles);
+        coord(nat, m0, n0);
+        AccTile<Shape> acc;
+        acc.m_wave = wm * (BM / Shape::WM);
+        acc.n_wave = wn * (BN / Shape::WN);
+        acc.lane = lane;
+#pragma unroll
+        for (int mi = 0; mi < Shape::TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < Shape::TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.v[mi][ni][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            // retire the oldest staged tile, leave the younger ones (at most STAGES-2) in flight
+            if (STAGES >= 4 && inflight >= 3) wait_vmcnt<2 * GL>();
+            else if (STAGES >= 3 && inflight >= 2) wait_vmcnt<GL>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            --inflight;   // the tile multiplied below is retired from the DMA queue (its buffer is re-staged only after the NEXT barrier)
+            if (pf_g < total_g) stage_next();
+            const char* sa = smem + cp_slot * Shape::STAGE_BYTES;
+            cp_slot = (cp_slot + 1 == STAGES) ? 0 : cp_slot + 1;
+            const char* sb = sa + Shape::A_BYTES;
+            uint4 af[2][Shape::TM], bf[2][Shape::TN];
+            auto load_frags = [&](int ks, int slot) {
+                const int coff = ((2 * ks + fh) ^ fswz) << 4;
+#pragma unroll
+                for (int mi = 0; mi < Shape::TM; ++mi) af[slot][mi] = *reinterpret_cast<const uint4*>(sa + a_row_byte + mi * 32 * 128 + coff);
+#pragma unroll
+                for (int ni = 0; ni < Shape::TN; ++ni) bf[slot][ni] = *reinterpret_cast<const uint4*>(sb + b_row_byte + ni * 32 * 128 + coff);
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                if (ks + 1 < BK / 16) load_frags(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                for (int mi = 0; mi < Shape::TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < Shape::TN; ++ni) acc.v[mi][ni] = T::mfma(af[ks & 1][mi], bf[ks & 1][ni], acc.v[mi][ni]);
+            }
+        }
+        epi(acc, m0, n0, nat);
+    }
+}
+
 }  // namespace kr

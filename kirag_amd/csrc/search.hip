@@ -23,12 +23,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 namespace kr {
 
-using ShapeC = GemmShape<128, 128, 2, 2>;   // coarse scan tile: 128 corpus rows x 128 queries
+using ShapeC = GemmShape<256, 256, 2, 4>;   // coarse scan tile: 256 corpus rows x 256 queries, 8 waves of 128x64, 2-stage ring (128 KiB LDS)
+constexpr int COARSE_STAGES = 2;
 constexpr int QBLK = 1024;                   // queries per search block (reference index_batch_size)
 constexpr int EXACT_RC = 1024;               // rows per block of the exact scan
 constexpr int SORT_CHUNK = 4096;             // keys per block of the merge tree
@@ -54,9 +56,11 @@ struct Index {
     int out_k = 0;
     uint64_t* ex_a = nullptr; uint64_t* ex_b = nullptr; size_t ex_bytes = 0;  // exact-scan ping/pong
     int* ex_qidx = nullptr;    // [QBLK] flagged query list
+    uint4* blk_list = nullptr; unsigned int* blk_cnt = nullptr;   // [num_cu*8, WLISTCAP] per-wave survivor lists, [num_cu*8 + 1] counts (+ overflow word)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evc[2 * 16] = {};   // begin/end pairs around each coarse round (roofline timing)
     kr_search_stats st{};
+    int num_cu = 256;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -135,108 +139,259 @@ struct CoarseArgs {
     const uint16_t* xc; int64_t n; int dpad;
     const uint16_t* qc; int nq_pad;
     const float* thr; uint32_t* cnt; uint32_t* flags; uint64_t* cand; int cand_cap;
+    int nq; int direct;
+    uint4* blk_list; unsigned int* blk_cnt; unsigned int* list_overflow;
     int64_t tile_begin, tile_count;   // this round covers permuted tile slots [tile_begin, tile_begin + tile_count)
     int64_t ntiles, perm_mul;         // slot -> tile = (slot * perm_mul) % ntiles   (perm_mul coprime to ntiles)
 };
 
-template <class T>
+// persistent streaming coarse scan (gemm_nt_stream): grid = one block per CU, so nothing else on the CU hides an epilogue
+// stall, and the whole kernel must stay inside the instruction cache: the epilogue is branch-light and touches no global
+// memory that it has to wait for.
+//   direct != 0 (round 0, thr = -inf): every score is stored at slot = (tile slot in round)*BM + row in tile, no atomics.
+//   otherwise: thresholds sit in LDS (loaded once per launch); survivors of one accumulator register are compacted with
+//   ballot/mbcnt and stored (fire-and-forget) to THIS WAVE's private list, whose cursor lives in an SGPR; k_scatter later
+//   moves the lists into the per-query buffers.
+constexpr int WLISTCAP = 8192;                      // entries per wave list (expected nq*cap/2/(8*num_blocks) ~ 1k-2k)
+constexpr int COARSE_LDS = COARSE_STAGES * ShapeC::STAGE_BYTES + QBLK * 4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// The 16-bit copy is padded with NaN rows up to a multiple of 256 (k_pad_nan): a partial last tile then needs no row test,
+// because NaN scores fail every `>=` and sort below every real key.
+template <class T, bool DIRECT>
 __global__ __launch_bounds__(ShapeC::NTHREADS, 2) void k_coarse(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int64_t tslot; int tn;
-    if (!xcd_tile_map(blockIdx.x, a.tile_count, a.nq_pad / ShapeC::BN, tslot, tn)) return;
-    // ntiles < 2^25 (2^32 rows / 128) so the product stays below 2^50
-    const int64_t tile = (int64_t)(((uint64_t)(a.tile_begin + tslot) * (uint64_t)a.perm_mul) % (uint64_t)a.ntiles);
-    const int64_t m0 = tile * ShapeC::BM;
-    const int n0 = tn * ShapeC::BN;
-    gemm_nt_block<T, ShapeC>(a.xc, a.dpad, a.n, a.qc, a.dpad, a.nq_pad, a.dpad, m0, n0, smem, [&](AccTile<ShapeC>& acc) {
+    float* thr_s = reinterpret_cast<float*>(smem + COARSE_STAGES * ShapeC::STAGE_BYTES);
+    if (!DIRECT) {
+        for (int i = threadIdx.x; i < a.nq_pad; i += ShapeC::NTHREADS) thr_s[i] = a.thr[i];
+        __syncthreads();
+    }
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // this wave's survivor list as a buffer resource: 32-bit offsets, and stores past the capacity are dropped by the hardware
+    const __amdgpu_buffer_rsrc_t wlist = __builtin_amdgcn_make_buffer_rsrc(
+        a.blk_list + ((int64_t)blockIdx.x * ShapeC::NWAVE + wave_id) * WLISTCAP, 0, WLISTCAP * 16, 0x00020000);
+    unsigned int wcnt = 0;   // wave-uniform cursor into the list
+    const int64_t tn_count = a.nq_pad / ShapeC::BN;
+    const int64_t total = a.tile_count * tn_count;
+    const int64_t n_pad = (a.n + ShapeC::BM - 1) / ShapeC::BM * ShapeC::BM;
+    gemm_nt_stream<T, ShapeC, COARSE_STAGES>(
+        a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem,
+        [&](int64_t nat, int64_t& m0, int64_t& n0) {
+            const int64_t tslot = nat / tn_count, tn = nat % tn_count;   // the query blocks of one corpus tile are adjacent
+            const int64_t tile = (int64_t)(((uint64_t)(a.tile_begin + tslot) * (uint64_t)a.perm_mul) % (uint64_t)a.ntiles);
+            m0 = tile * ShapeC::BM; n0 = tn * ShapeC::BN;
+        },
+        [&](AccTile<ShapeC>& acc, int64_t m0, int64_t n0, int64_t nat) {
+            const int lane_row0 = acc.m_wave + 4 * (acc.lane >> 5);    // register (mi, r) is tile row lane_row0 + mi*32 + (r&3) + 8*(r>>2)
+            const uint32_t row_base = (uint32_t)m0 + (uint32_t)lane_row0;
+            if constexpr (DIRECT) {
+                // round 0, thr = -inf: every score goes to slot (tile slot in round)*BM + row in tile of its query's buffer
 #pragma unroll
-        for (int ni = 0; ni < ShapeC::TN; ++ni) {
-            const int q = n0 + acc.col(ni);
-            const float t = a.thr[q];
+                for (int ni = 0; ni < ShapeC::TN; ++ni) {
+                    const int q = (int)n0 + acc.col(ni);
+                    if (q < a.nq) {
+                        uint64_t* cq = a.cand + (int64_t)q * a.cand_cap + (nat / tn_count) * ShapeC::BM + lane_row0;
 #pragma unroll
-            for (int mi = 0; mi < ShapeC::TM; ++mi) {
+                        for (int mi = 0; mi < ShapeC::TM; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float s = acc.v[mi][ni][r];
-                    if (s >= t) {
-                        const int64_t row = m0 + acc.row(mi, r);
-                        if (row < a.n) {
-                            const uint32_t slot = atomicAdd(&a.cnt[q], 1u);
-                            if (slot < (uint32_t)a.cand_cap) a.cand[(int64_t)q * a.cand_cap + slot] = make_key(s, (uint32_t)row);
+                            for (int r = 0; r < 16; ++r) {
+                                const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
+                                cq[ro] = make_key(acc.v[mi][ni][r], row_base + (uint32_t)ro);
+                            }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < ShapeC::TN; ++ni) {
+                    const uint32_t q = (uint32_t)n0 + (uint32_t)acc.col(ni);
+                    const float t = thr_s[q];
+#pragma unroll
+                    for (int mi = 0; mi < ShapeC::TM; ++mi) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
+                            const float s = acc.v[mi][ni][r];
+                            const bool p = (s >= t);
+                            const unsigned long long mask = __ballot(p);
+                            if (mask) {
+                                if (p) {
+                                    const unsigned int slot = wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                    u32x4 e = {__float_as_uint(s), row_base + (uint32_t)ro, q, 0u};
+                                    __builtin_amdgcn_raw_buffer_store_b128(e, wlist, slot * 16u, 0, 0);
+                                }
+                                wcnt += (unsigned)__popcll(mask);
+                            }
                         }
                     }
                 }
             }
+        });
+    if constexpr (!DIRECT) {
+        // ---- fused scatter: this block's 8 wave lists -> the per-query candidate buffers.  One global atomic per (block, query)
+        // reserves a range (instead of one per survivor), the position inside the range comes from an LDS counter.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's list stores have reached L2
+        unsigned int* hist = reinterpret_cast<unsigned int*>(smem);          // [QBLK]  (the LDS ring is free now)
+        unsigned int* base = hist + QBLK;                                    // [QBLK]
+        unsigned int* wc = base + QBLK;                                      // [NWAVE]
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            wc[wave_id] = wcnt < (unsigned)WLISTCAP ? wcnt : (unsigned)WLISTCAP;
+            if (wcnt > (unsigned)WLISTCAP) *a.list_overflow = 1u;
         }
-    });
+        for (int i = threadIdx.x; i < a.nq_pad; i += ShapeC::NTHREADS) hist[i] = 0u;
+        __syncthreads();
+        const uint4* lists = a.blk_list + (int64_t)blockIdx.x * ShapeC::NWAVE * WLISTCAP;
+        for (int w = 0; w < ShapeC::NWAVE; ++w)
+            for (unsigned i = threadIdx.x; i < wc[w]; i += ShapeC::NTHREADS) atomicAdd(&hist[lists[(int64_t)w * WLISTCAP + i].z], 1u);
+        __syncthreads();
+        for (int q = threadIdx.x; q < a.nq_pad; q += ShapeC::NTHREADS) {
+            const unsigned c = hist[q];
+            base[q] = c ? atomicAdd(&a.cnt[q], c) : 0u;
+            hist[q] = 0u;
+        }
+        __syncthreads();
+        for (int w = 0; w < ShapeC::NWAVE; ++w)
+            for (unsigned i = threadIdx.x; i < wc[w]; i += ShapeC::NTHREADS) {
+                const uint4 e = lists[(int64_t)w * WLISTCAP + i];
+                const unsigned pos = base[e.z] + atomicAdd(&hist[e.z], 1u);
+                if (pos < (unsigned)a.cand_cap) a.cand[(int64_t)e.z * a.cand_cap + pos] = make_key(__uint_as_float(e.x), e.y);
+            }
+    }
 }
 
-// sort a query's candidate buffer (descending); keep `keep` entries (or all when keep < 0); publish the new threshold
+// rows [n, round_up(n, 256)) of the 16-bit copy <- NaN
+__global__ void k_pad_nan(uint16_t* __restrict__ xc, int64_t n, int64_t n_pad, int dpad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (n_pad - n) * dpad) xc[n * dpad + i] = 0x7FC0;   // NaN in bf16 and in f16 (0x7FC0 = f16 NaN too: exponent 11111, mantissa != 0)
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// selection by value (no sorting of the candidate buffers): MSB-first 8-bit radix select over the ordered score bits
+// ---------------------------------------------------------------------------------------------------------
+// R-th largest (1-based) of hi32(s[0..m)), for a block of NT threads; hist: 256 + 4 words of LDS.  Requires 1 <= R <= m.
+template <int NT>
+__device__ __forceinline__ uint32_t radix_select_desc(const uint64_t* __restrict__ s, int m, int R, unsigned int* hist, int tid) {
+    uint32_t prefix = 0u, pmask = 0u;
+    int remaining = R;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = tid; i < 256; i += NT) hist[i] = 0u;
+        __syncthreads();
+        for (int i = tid; i < m; i += NT) {
+            const uint32_t hi = (uint32_t)(s[i] >> 32);
+            if ((hi & pmask) == prefix) atomicAdd(&hist[(hi >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {   // wave 0: lane l owns bins 4l .. 4l+3; suffix sums from the top bin down
+            const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const unsigned own = h0 + h1 + h2 + h3;
+            unsigned incl = own;   // inclusive suffix sum over lanes >= tid
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const unsigned t = __shfl_down(incl, d, 64); if (tid + d < 64) incl += t; }
+            const unsigned above = incl - own;                       // keys in bins of higher lanes
+            if (above < (unsigned)remaining && incl >= (unsigned)remaining) {   // the R-th key falls into this lane's bins
+                unsigned c = above; int bin = 4 * tid + 3;
+                if (c + h3 >= (unsigned)remaining) bin = 4 * tid + 3;
+                else { c += h3; if (c + h2 >= (unsigned)remaining) bin = 4 * tid + 2;
+                       else { c += h2; if (c + h1 >= (unsigned)remaining) bin = 4 * tid + 1; else { c += h1; bin = 4 * tid; } } }
+                hist[256] = (unsigned)bin; hist[257] = c;
+            }
+        }
+        __syncthreads();
+        prefix |= hist[256] << shift; pmask |= 255u << shift;
+        remaining -= (int)hist[257];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// between rounds: keep the entries with score >= (keep-th best score), publish thr[q] = thr_rank-th best score (thr_rank <= keep).
+// `preset` > 0: the buffer was filled by the direct round with `preset` slots (cnt unused).
 __global__ __launch_bounds__(256) void k_select(uint64_t* __restrict__ cand, int cand_cap, uint32_t* __restrict__ cnt,
-                                                uint32_t* __restrict__ flags, float* __restrict__ thr, int keep) {
+                                                uint32_t* __restrict__ flags, float* __restrict__ thr, int keep, int thr_rank, int preset) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* s = reinterpret_cast<uint64_t*>(smem);
+    unsigned int* hist = reinterpret_cast<unsigned int*>(smem + (size_t)cand_cap * sizeof(uint64_t));   // 256 + 4
+    unsigned int& outc = hist[259];
     const int q = blockIdx.x, tid = threadIdx.x;
-    uint32_t m = cnt[q];
+    uint32_t m = preset > 0 ? (uint32_t)preset : cnt[q];
     if (m > (uint32_t)cand_cap) {   // entries beyond the capacity were dropped: the query goes to the exact scan
         if (tid == 0) flags[q] |= 1u;
         m = (uint32_t)cand_cap;
     }
-    if (m == 0) return;
-    int P = 1; while (P < (int)m) P <<= 1;
+    if (m == 0) { if (tid == 0) cnt[q] = 0; return; }
     uint64_t* c = cand + (int64_t)q * cand_cap;
-    for (int i = tid; i < P; i += 256) s[i] = (i < (int)m) ? c[i] : 0ull;   // key 0 sorts last
-    bitonic_sort_desc(s, P, tid, 256);
-    const int out = (keep >= 0 && keep < (int)m) ? keep : (int)m;
-    for (int i = tid; i < out; i += 256) c[i] = s[i];
-    if (tid == 0) {
-        cnt[q] = (uint32_t)out;
-        if (keep >= 0 && (int)m >= keep) thr[q] = key_score(s[keep - 1]);
+    for (int i = tid; i < (int)m; i += 256) s[i] = c[i];
+    if (tid == 0) outc = 0u;
+    __syncthreads();
+    uint32_t vkeep = 0u;
+    if ((int)m >= thr_rank) {
+        const uint32_t vthr = radix_select_desc<256>(s, (int)m, thr_rank, hist, tid);
+        if (tid == 0) thr[q] = ord_f32(vthr);      // NaN (vthr == 0) compares false everywhere: nothing more is appended, the query ends up flagged
+        vkeep = vthr;
     }
+    if ((int)m > keep) vkeep = (keep == thr_rank && (int)m >= thr_rank) ? vkeep : radix_select_desc<256>(s, (int)m, keep, hist, tid);
+    else vkeep = 0u;
+    // compact: everything with score >= the keep-th best (ties kept; zero keys = padding dropped)
+    for (int i = tid; i < (int)m; i += 256) {
+        const uint64_t key = s[i];
+        if (key != 0ull && (uint32_t)(key >> 32) >= vkeep) c[atomicAdd(&outc, 1u)] = key;
+    }
+    __syncthreads();
+    if (tid == 0) cnt[q] = outc;
 }
 
-// exactness certificate + fp64 re-rank of the buffer prefix {coarse >= b_k - 2 eps}
+// exactness certificate + fp64 re-rank of the candidates with coarse score >= b_k - 2 eps   (buffer order is arbitrary)
+constexpr int RERANK_MAX = 2048;
 __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ cand, int cand_cap, const uint32_t* __restrict__ cnt,
                                                 uint32_t* __restrict__ flags, const float* __restrict__ thr, const float* __restrict__ eps,
-                                                const float* __restrict__ qf, const float* __restrict__ xf, int d, int k,
+                                                const float* __restrict__ qf, const float* __restrict__ xf, int d, int k, int preset,
                                                 float* __restrict__ out_s, int64_t* __restrict__ out_r, uint32_t* __restrict__ nrer) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* s = reinterpret_cast<uint64_t*>(smem);
-    int& r_sh = *reinterpret_cast<int*>(smem + (size_t)cand_cap * sizeof(uint64_t));   // tail word of the dynamic region (no static LDS: G17)
+    uint64_t* s = reinterpret_cast<uint64_t*>(smem);                                    // [cand_cap] copy of the buffer
+    uint64_t* sel = s + cand_cap;                                                       // [RERANK_MAX]
+    unsigned int* hist = reinterpret_cast<unsigned int*>(sel + RERANK_MAX);             // 256 + 4
+    unsigned int& rc = hist[259];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = (int)cnt[q];
-    const uint64_t* c = cand + (int64_t)q * cand_cap;
-    if (m < k) {   // fewer emittable rows than k (NaN rows, overflow truncation): exact scan decides
+    int m = preset > 0 ? preset : (int)cnt[q];
+    bool ok = (flags[q] == 0u);
+    if (m > cand_cap) { m = cand_cap; ok = false; }
+    if (m < k) {   // fewer candidates than k (NaN rows, overflow truncation): the exact scan decides
         if (tid == 0) { flags[q] |= 2u; nrer[q] = 0; }
         return;
     }
-    const float bk = key_score(c[k - 1]);
+    const uint64_t* c = cand + (int64_t)q * cand_cap;
+    for (int i = tid; i < m; i += 256) s[i] = c[i];
+    if (tid == 0) rc = 0u;
+    __syncthreads();
+    const float bk = ord_f32(radix_select_desc<256>(s, m, k, hist, tid));               // k-th best coarse score (NaN if fewer than k real scores)
     const float theta = bk - 2.f * eps[q];
-    // the buffer is complete for coarse scores strictly above thr (ties AT thr may have been compacted away)
-    const bool certified = (flags[q] == 0u) && (theta > thr[q]);
-    if (tid == 0) r_sh = 0;
+    // the buffer is complete for coarse scores >= thr (everything at or above the threshold of the last round was appended / kept)
+    const bool certified = ok && (theta > thr[q]);
+    for (int i = tid; i < m; i += 256) {
+        const uint64_t key = s[i];
+        if (key_score(key) >= theta) { const unsigned p = atomicAdd(&rc, 1u); if (p < (unsigned)RERANK_MAX) sel[p] = key; }
+    }
     __syncthreads();
-    int local = 0;
-    for (int i = tid; i < m; i += 256) local += (key_score(c[i]) >= theta) ? 1 : 0;   // sorted desc: this is a prefix
-    atomicAdd(&r_sh, local);
-    __syncthreads();
-    const int r = r_sh;
-    if (tid == 0) { nrer[q] = (uint32_t)r; if (!certified) flags[q] |= 2u; }
+    const int r_all = (int)rc;
+    const int r = r_all < RERANK_MAX ? r_all : RERANK_MAX;
+    if (tid == 0) { nrer[q] = (uint32_t)r; if (!certified || r_all > RERANK_MAX || r_all < k) flags[q] |= 2u; }
     int P = 1; while (P < r) P <<= 1;
+    if (P < 1) P = 1;
+    __syncthreads();
     const float* qv = qf + (int64_t)q * d;
     for (int i = wave; i < P; i += 4) {
         uint64_t key = 0ull;
         if (i < r) {
-            const uint32_t row = key_row(c[i]);
+            const uint32_t row = key_row(sel[i]);
             const double e = canonical_dot_wave(qv, xf + (int64_t)row * d, d, lane);
             key = make_key((float)e, row);
         }
-        if (lane == 0) s[i] = key;
+        if (lane == 0) sel[i] = key;
     }
-    bitonic_sort_desc(s, P, tid, 256);
-    for (int j = tid; j < k; j += 256) {
-        out_s[(int64_t)q * k + j] = key_score(s[j]);
-        out_r[(int64_t)q * k + j] = (int64_t)key_row(s[j]);
+    bitonic_sort_desc(sel, P, tid, 256);
+    for (int j = tid; j < k && j < P; j += 256) {
+        out_s[(int64_t)q * k + j] = key_score(sel[j]);
+        out_r[(int64_t)q * k + j] = (int64_t)key_row(sel[j]);
     }
 }
 
@@ -294,7 +449,7 @@ __global__ void k_keys_to_out(const uint64_t* __restrict__ keys, int64_t stride,
 static int grow(Index* ix, int64_t want) {
     if (want <= ix->cap_rows) return 0;
     int64_t ncap = std::max<int64_t>(want, ix->cap_rows + ix->cap_rows / 2);
-    ncap = round_up(ncap, ShapeC::BM);
+    ncap = round_up(ncap, 256);
     float* nf = nullptr; uint16_t* nc = nullptr;
     KR_HIP(hipMalloc(&nf, (size_t)ncap * ix->d * sizeof(float)));
     hipError_t e = hipMalloc(&nc, (size_t)ncap * ix->dpad * 2);
@@ -306,6 +461,11 @@ static int grow(Index* ix, int64_t want) {
     if (ix->xf) (void)hipFree(ix->xf);
     if (ix->xc) (void)hipFree(ix->xc);
     ix->xf = nf; ix->xc = nc; ix->cap_rows = ncap;
+    const int64_t n_pad = round_up(ix->n, 256);
+    if (n_pad > ix->n) {   // keep the NaN padding rows behind the last row (see k_coarse)
+        hipLaunchKernelGGL(k_pad_nan, dim3((unsigned)(((n_pad - ix->n) * ix->dpad + 255) / 256)), dim3(256), 0, 0, ix->xc, ix->n, n_pad, ix->dpad);
+        KR_HIP(hipDeviceSynchronize());
+    }
     return 0;
 }
 
@@ -319,6 +479,8 @@ static int ensure_ws(Index* ix, int k, int cand_cap) {
         KR_HIP(hipMalloc(&ix->flags, QBLK * sizeof(uint32_t)));
         KR_HIP(hipMalloc(&ix->nrer, QBLK * sizeof(uint32_t)));
         KR_HIP(hipMalloc(&ix->ex_qidx, QBLK * sizeof(int)));
+        KR_HIP(hipMalloc(&ix->blk_list, (size_t)ix->num_cu * ShapeC::NWAVE * WLISTCAP * sizeof(uint4)));
+        KR_HIP(hipMalloc(&ix->blk_cnt, ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int)));
         for (auto& e : ix->ev) KR_HIP(hipEventCreate(&e));
         for (auto& e : ix->evc) KR_HIP(hipEventCreate(&e));
     }
@@ -379,7 +541,7 @@ static int exact_scan(Index* ix, int nqf, int k, hipStream_t st) {
 
 template <class T>
 static int search_block(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int mode, hipStream_t st) {
-    const int nq_pad = (int)round_up(nq, ShapeC::BN);
+    const int nq_pad = (int)round_up(nq, ShapeC::BN);   // <= QBLK = 1024 = 4 x 256
     // over-fetch K1 and buffer capacity: K1 = max(64, pow2 >= 2.5 k); cap = 16 K1; growth 8x per round
     int K1 = std::max(64, next_pow2((5 * k + 1) / 2));
     int cap = 16 * K1;
@@ -394,38 +556,71 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         hipLaunchKernelGGL(k_prep_queries<T>, dim3(nq_pad), dim3(64), 0, st, ix->q_f, ix->q_c, nq, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr,
                            ix->cnt, ix->flags);
         CoarseArgs a;
-        a.xc = ix->xc; a.n = ix->n; a.dpad = ix->dpad; a.qc = ix->q_c; a.nq_pad = nq_pad;
+        a.xc = ix->xc; a.n = ix->n; a.dpad = ix->dpad; a.qc = ix->q_c; a.nq_pad = nq_pad; a.nq = nq;
         a.thr = ix->thr; a.cnt = ix->cnt; a.flags = ix->flags; a.cand = ix->cand; a.cand_cap = ix->cand_cap;
-        a.ntiles = (ix->n + ShapeC::BM - 1) / ShapeC::BM;
+        a.blk_list = ix->blk_list; a.blk_cnt = ix->blk_cnt; a.list_overflow = ix->blk_cnt + ix->num_cu * ShapeC::NWAVE;
+        KR_HIP(hipMemsetAsync(ix->blk_cnt, 0, ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int), st));
+        constexpr int bm = ShapeC::BM;
+        a.ntiles = (ix->n + bm - 1) / bm;
         // interleaving permutation: multiplier near ntiles / golden ratio, coprime to ntiles
         int64_t mul = std::max<int64_t>(1, (int64_t)((double)a.ntiles * 0.6180339887498949));
         while (gcd64(mul, a.ntiles) != 1) ++mul;
         a.perm_mul = mul % a.ntiles; if (a.perm_mul == 0) a.perm_mul = 1;
-        const int tn_count = nq_pad / ShapeC::BN;
+        constexpr int lds = COARSE_LDS;
+        static bool attr_set = false;
+        if (!attr_set) {
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        const size_t sel_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int);
+        const size_t rer_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + (size_t)RERANK_MAX * sizeof(uint64_t) + 264 * sizeof(unsigned int);
+        static bool sel_attr_set = false;
+        if (!sel_attr_set) {   // cap = 8192 needs 64 KiB + 16 B of dynamic LDS
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + RERANK_MAX * 8 + 264 * 4));
+            sel_attr_set = true;
+        }
+        // Round schedule (any thresholds are SAFE: the certificate in k_rerank decides exactness; the schedule only sets speed):
+        //   round 0: cap rows, every score stored (direct slots);  growth rounds: 7x the rows seen, thr = K1-th best;
+        //   as soon as rows_seen * 64 >= rows_left the rest is ONE final round whose threshold is the r-th best seen with
+        //   r = (cap/2) * seen / left  (expected cap/2 survivors), 32 <= r <= K1.
         int64_t done = 0;
-        int64_t step = std::max<int64_t>(1, cap / ShapeC::BM);   // round 0: at most `cap` rows -> cannot overflow
-        int round = 0;
+        int64_t step = std::max<int64_t>(1, cap / bm);
+        int round = 0, final_preset = 0;
+        a.direct = 1;
         while (done < a.ntiles) {
             const int64_t cnt_t = std::min<int64_t>(step, a.ntiles - done);
             a.tile_begin = done; a.tile_count = cnt_t;
-            const int64_t grid = round_up(cnt_t, 8) * tn_count;
             if (round < 16) KR_HIP(hipEventRecord(ix->evc[2 * round], st));
-            hipLaunchKernelGGL(k_coarse<T>, dim3((unsigned)grid), dim3(ShapeC::NTHREADS), ShapeC::LDS_BYTES, st, a);
+            if (a.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
+            else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
             if (round < 16) KR_HIP(hipEventRecord(ix->evc[2 * round + 1], st));
+            const int preset = a.direct ? (int)(cnt_t * bm) : 0;
             ++round;
             done += cnt_t;
-            const bool last = (done >= a.ntiles);
-            // after the last round the whole buffer is sorted and kept; thr is left untouched
-            hipLaunchKernelGGL(k_select, dim3(nq), dim3(256), (size_t)ix->cand_cap * sizeof(uint64_t), st, ix->cand, ix->cand_cap, ix->cnt,
-                               ix->flags, ix->thr, last ? -1 : K1);
-            step = done * 7;   // next round: 7x the rows seen so far (expected 7*K1 new candidates + K1 kept = cap/2)
+            a.direct = 0;
             ix->st.coarse_rounds++;
+            if (done >= a.ntiles) { final_preset = preset; break; }   // last round: k_rerank reads the buffer as it is; thr stays
+            const int64_t seen = done * bm, left = ix->n - seen;
+            int rank = K1;
+            if (seen * 64 >= left) {
+                step = a.ntiles - done;
+                rank = (int)std::min<int64_t>(K1, std::max<int64_t>(32, ((int64_t)(cap / 2) * seen + left - 1) / left));
+                rank = std::min(rank, K1);
+            } else {
+                step = done * 7;
+            }
+            hipLaunchKernelGGL(k_select, dim3(nq), dim3(256), sel_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, K1, rank, preset);
         }
-        hipLaunchKernelGGL(k_rerank, dim3(nq), dim3(256), (size_t)ix->cand_cap * sizeof(uint64_t) + 16, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags,
-                           ix->thr, ix->eps, ix->q_f, ix->xf, ix->d, k, ix->out_s, ix->out_r, ix->nrer);
+        hipLaunchKernelGGL(k_rerank, dim3(nq), dim3(256), rer_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags,
+                           ix->thr, ix->eps, ix->q_f, ix->xf, ix->d, k, final_preset, ix->out_s, ix->out_r, ix->nrer);
         KR_HIP(hipGetLastError());
         KR_HIP(hipMemcpyAsync(hflags.data(), ix->flags, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        unsigned int list_ovf = 0;
+        KR_HIP(hipMemcpyAsync(&list_ovf, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
         KR_HIP(hipStreamSynchronize(st));
+        if (list_ovf) for (auto& f : hflags) f |= 1u;   // a block list overflowed (sticky for the call): every query goes to the exact scan
         for (int r = 0; r < round && r < 16; ++r) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ix->evc[2 * r], ix->evc[2 * r + 1]) == hipSuccess) coarse_ms += ms;
@@ -470,6 +665,7 @@ int kr_index_create(int d, int metric, int coarse_dtype, int device, kr_index** 
     KR_TRY(select_device(device));
     Index* ix = new Index();
     ix->d = d; ix->dpad = (int)round_up(d, 64); ix->coarse = coarse_dtype; ix->device = device;
+    { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) ix->num_cu = (p.multiProcessorCount / 8) * 8; }
     hipError_t e = hipMalloc(&ix->bounds, 2 * sizeof(float));
     if (e != hipSuccess) { delete ix; return fail(KR_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
     (void)hipMemset(ix->bounds, 0, 2 * sizeof(float));
@@ -482,7 +678,7 @@ void kr_index_destroy(kr_index* h) {
     Index* ix = reinterpret_cast<Index*>(h);
     (void)hipSetDevice(ix->device);
     void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
-                    ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx};
+                    ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ix->evc) if (e) (void)hipEventDestroy(e);
@@ -513,6 +709,10 @@ int kr_index_add(kr_index* h, const float* x, int64_t n, void* stream) {
         hipLaunchKernelGGL(k_add_rows<BF16>, dim3(grid), dim3(256), 0, st, dst, ix->xc + ix->n * ix->dpad, n, ix->d, ix->dpad, ix->bounds);
     else
         hipLaunchKernelGGL(k_add_rows<F16>, dim3(grid), dim3(256), 0, st, dst, ix->xc + ix->n * ix->dpad, n, ix->d, ix->dpad, ix->bounds);
+    {
+        const int64_t nn = ix->n + n, n_pad = round_up(nn, 256);
+        if (n_pad > nn) hipLaunchKernelGGL(k_pad_nan, dim3((unsigned)(((n_pad - nn) * ix->dpad + 255) / 256)), dim3(256), 0, st, ix->xc, nn, n_pad, ix->dpad);
+    }
     KR_HIP(hipGetLastError());
     KR_HIP(hipStreamSynchronize(st));   // x may be a pageable host buffer the caller frees on return
     ix->n += n;

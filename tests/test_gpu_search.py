@@ -207,3 +207,16 @@ def test_full_size_config2_properties():
     ms = np.empty((64, k), np.float32); mi = np.empty((64, k), np.int64)
     _lib.check(_lib.load().kr_topk_merge(sc2.ctypes.data, ic2.ctypes.data, 2, 64, k, ms.ctypes.data, mi.ctypes.data))
     assert np.array_equal(mi, i[:64]) and np.array_equal(ms, s[:64])
+
+
+def test_k_200_uses_large_candidate_buffers():
+    """k > 102 switches to K1 = 512 / cap = 8192 (64 KiB + of dynamic LDS in k_select / k_rerank)."""
+    rng = np.random.default_rng(21)
+    x = _unit(rng, 30000, 128); q, _ = _queries_near(rng, x, 9)
+    ix = _mk(128, x)
+    s, i = ix.index.search(q, 200)
+    so, io = S.search_f64(q, x, 200)
+    assert np.array_equal(i, io) and np.array_equal(s, so)
+    s, i = ix.index.search(q, 600)            # beyond the fast path: exact scan
+    so, io = S.search_f64(q, x, 600)
+    assert np.array_equal(i, io) and np.array_equal(s, so)

@@ -1,0 +1,202 @@
+// Micro-benchmark / ablation harness for the shared MFMA main loop (kirag_amd/csrc/gemm_nt.hpp).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/gemm_bench.hip -o gpurun_out/gemm_bench && ./gpurun_out/gemm_bench
+// Random bf16 operands (cdna_hip_programming.md rule 25), C = A[M,K] . B[N,K]^T, result reduced to a checksum per tile.
+#include "../kirag_amd/csrc/gemm_nt.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <random>
+#include <vector>
+
+using namespace kr;
+
+namespace kr {
+std::string& last_error_ref() { static thread_local std::string e; return e; }
+int fail(int code, const char*, ...) { return code; }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+template <class Shape, int STAGES>
+__global__ __launch_bounds__(Shape::NTHREADS, (Shape::NTHREADS / 256)) void k_stream(const uint16_t* A, const uint16_t* B, float* out, int64_t M, int64_t N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t tm_count = M / Shape::BM, tn_count = N / Shape::BN;
+    gemm_nt_stream<BF16, Shape, STAGES>(
+        A, K, M, B, K, N, K, tm_count * tn_count, smem,
+        [&](int64_t nat, int64_t& m0, int64_t& n0) { int64_t tm, tn; patch_coord(nat, tm_count, tn_count, tm, tn); m0 = tm * Shape::BM; n0 = tn * Shape::BN; },
+        [&](AccTile<Shape>& acc, int64_t m0, int64_t n0, int64_t) {
+            float s = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < Shape::TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < Shape::TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += acc.v[mi][ni][r];
+            if (s == 12345.678f) out[0] = s;   // keeps the accumulators live, (almost) never stores
+            if (threadIdx.x == 0 && m0 == 0 && n0 == 0) out[1] = acc.v[0][0][0];
+        });
+}
+
+
+// search-like epilogue: compare against a per-column threshold held in LDS, append survivors to a block list through an LDS counter
+template <class Shape, int STAGES>
+__global__ __launch_bounds__(Shape::NTHREADS, (Shape::NTHREADS / 256)) void k_stream_filter(const uint16_t* A, const uint16_t* B, float* out, uint4* lists, int64_t M,
+                                                                                           int64_t N, int K, float thr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* thr_s = reinterpret_cast<float*>(smem + STAGES * Shape::STAGE_BYTES);
+    unsigned int* lcnt = reinterpret_cast<unsigned int*>(thr_s + 1024);
+    for (int i = threadIdx.x; i < 1024; i += Shape::NTHREADS) thr_s[i] = thr;
+    if (threadIdx.x == 0) *lcnt = 0;
+    __syncthreads();
+    uint4* list = lists + (int64_t)blockIdx.x * 65536;
+    const int64_t tm_count = M / Shape::BM, tn_count = N / Shape::BN;
+    gemm_nt_stream<BF16, Shape, STAGES>(
+        A, K, M, B, K, N, K, tm_count * tn_count, smem,
+        [&](int64_t nat, int64_t& m0, int64_t& n0) { m0 = (nat / tn_count) * Shape::BM; n0 = (nat % tn_count) * Shape::BN; },
+        [&](AccTile<Shape>& acc, int64_t m0, int64_t n0, int64_t) {
+#pragma unroll
+            for (int ni = 0; ni < Shape::TN; ++ni) {
+                const int q = (int)n0 + acc.col(ni);
+                const float t = thr_s[q & 1023];
+#pragma unroll
+                for (int mi = 0; mi < Shape::TM; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float s = acc.v[mi][ni][r];
+                        if (s >= t) {
+                            const int64_t row = m0 + acc.row(mi, r);
+                            if (row < M) {
+                                const unsigned int slot = atomicAdd(lcnt, 1u);
+                                const uint64_t key = make_key(s, (uint32_t)row);
+                                if (slot < 65536u) list[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)q, 0u);
+                            }
+                        }
+                    }
+            }
+        });
+    __syncthreads();
+    if (threadIdx.x == 0) out[2 + (blockIdx.x & 7)] = (float)*lcnt;
+}
+
+template <class Shape>
+__global__ __launch_bounds__(Shape::NTHREADS, 2) void k_block(const uint16_t* A, const uint16_t* B, float* out, int64_t M, int64_t N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int64_t tm; int tn;
+    if (!xcd_tile_map(blockIdx.x, M / Shape::BM, (int)(N / Shape::BN), tm, tn)) return;
+    gemm_nt_block<BF16, Shape>(A, K, M, B, K, N, K, tm * Shape::BM, (int64_t)tn * Shape::BN, smem, [&](AccTile<Shape>& acc) {
+        float s = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < Shape::TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < Shape::TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc.v[mi][ni][r];
+        if (s == 12345.678f) out[0] = s;
+        if (threadIdx.x == 0 && tm == 0 && tn == 0) out[1] = acc.v[0][0][0];
+    });
+}
+
+// register-only MFMA loop: what this device sustains with no memory traffic (random operands)
+__global__ __launch_bounds__(256) void k_mfma_only(const uint4* in, float* out, int iters) {
+    uint4 a = in[threadIdx.x], b = in[threadIdx.x + 256];
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    for (int i = 0; i < iters; ++i) {
+        c0 = BF16::mfma(a, b, c0); c1 = BF16::mfma(b, a, c1); c2 = BF16::mfma(a, a, c2); c3 = BF16::mfma(b, b, c3);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+    if (s == 12345.678f) out[0] = s;
+}
+
+static float time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
+
+int main(int argc, char** argv) {
+    const int64_t M = argc > 1 ? atoll(argv[1]) : 262144, N = argc > 2 ? atoll(argv[2]) : 1024;
+    const int K = argc > 3 ? atoi(argv[3]) : 1024;
+    const int reps = 5;
+    std::vector<uint16_t> hA((size_t)M * K), hB((size_t)N * K);
+    std::mt19937 rng(1);
+    std::uniform_real_distribution<float> U(-1.f, 1.f);
+    auto bf = [](float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fff + ((u >> 16) & 1)) >> 16); };
+    for (auto& v : hA) v = bf(U(rng));
+    for (auto& v : hB) v = bf(U(rng));
+    uint16_t *A, *B; float* out;
+    CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&B, hB.size() * 2)); CK(hipMalloc(&out, 64));
+    CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+    double ref = 0;
+    for (int k = 0; k < K; ++k) {
+        auto f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; __builtin_memcpy(&x, &u, 4); return x; };
+        ref += (double)f(hA[k]) * f(hB[k]);
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double flops = 2.0 * M * N * K;
+    printf("M=%lld N=%lld K=%d  (%.2f TFLOP)  C[0][0] ref = %.6f\n", (long long)M, (long long)N, K, flops / 1e12, ref);
+
+    {   // pure MFMA rate
+        const int iters = 20000;
+        hipLaunchKernelGGL(k_mfma_only, dim3(256 * 2), dim3(256), 0, 0, (const uint4*)A, out, 100);
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_mfma_only, dim3(256 * 2), dim3(256), 0, 0, (const uint4*)A, out, iters);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        const double f = 2.0 * 32 * 32 * 16 * 4.0 * iters * 4 /*waves*/ * 512;
+        printf("%-44s %8.3f ms  %7.1f TFLOP/s\n", "mfma-only (regs, 2 blocks/CU)", time_ms(e0, e1), f / time_ms(e0, e1) / 1e9);
+    }
+
+    auto run = [&](const char* name, auto launch) {
+        float best = 1e30f, c00 = 0.f;
+        for (int r = 0; r < reps + 1; ++r) {
+            CK(hipMemset(out, 0, 64));
+            CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            if (r) best = std::min(best, time_ms(e0, e1));
+        }
+        float h[2]; CK(hipMemcpy(h, out, 8, hipMemcpyDeviceToHost)); c00 = h[1];
+        printf("%-44s %8.3f ms  %7.1f TFLOP/s   C[0][0]=%.6f %s\n", name, best, flops / best / 1e9, c00, fabs(c00 - ref) < 1e-2 ? "ok" : "MISMATCH");
+    };
+
+#define STREAM(bm_, bn_, wm_, wn_, ST)                                                                                          \
+    {                                                                                                                       \
+        using S = GemmShape<bm_, bn_, wm_, wn_>;                                                                            \
+        const int lds = ST * S::STAGE_BYTES;                                                                                \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream<S, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        const int blocks_per_cu = std::max(1, std::min(160 * 1024 / lds, 2048 / S::NTHREADS));                              \
+        run("stream " #bm_ "x" #bn_ " waves " #wm_ "x" #wn_ " stages " #ST, [&] {                                               \
+            hipLaunchKernelGGL((k_stream<S, ST>), dim3(256 * blocks_per_cu), dim3(S::NTHREADS), lds, 0, A, B, out, M, N, K); \
+        });                                                                                                                 \
+    }
+#define BLOCK(bm_, bn_, wm_, wn_)                                                                                               \
+    {                                                                                                                       \
+        using S = GemmShape<bm_, bn_, wm_, wn_>;                                                                            \
+        const int64_t grid = round_up(M / S::BM, 8) * (N / S::BN);                                                          \
+        run("block  " #bm_ "x" #bn_ " waves " #wm_ "x" #wn_ " (v1, 2 bufs)", [&] {                                              \
+            hipLaunchKernelGGL((k_block<S>), dim3((unsigned)grid), dim3(S::NTHREADS), S::LDS_BYTES, 0, A, B, out, M, N, K);  \
+        });                                                                                                                 \
+    }
+    uint4* lists; CK(hipMalloc(&lists, (size_t)256 * 65536 * 16));
+#define FILTER(bm_, bn_, wm_, wn_, ST, THR)                                                                               \
+    {                                                                                                                       \
+        using S = GemmShape<bm_, bn_, wm_, wn_>;                                                                            \
+        const int lds = ST * S::STAGE_BYTES + 4096 + 16;                                                                    \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream_filter<S, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        run("filter " #bm_ "x" #bn_ " waves " #wm_ "x" #wn_ " stages " #ST " thr " #THR, [&] {                             \
+            hipLaunchKernelGGL((k_stream_filter<S, ST>), dim3(256), dim3(S::NTHREADS), lds, 0, A, B, out, lists, M, N, K, THR); \
+        });                                                                                                                 \
+    }
+    FILTER(256, 256, 2, 4, 2, 1e30f)
+    FILTER(256, 256, 2, 4, 2, 55.0f)
+    FILTER(256, 256, 2, 4, 2, 45.0f)
+    BLOCK(128, 128, 2, 2)
+    STREAM(256, 128, 4, 2, 3)
+    STREAM(256, 128, 4, 2, 2)
+    STREAM(128, 128, 2, 2, 2)
+    STREAM(128, 128, 2, 2, 3)
+    STREAM(128, 128, 2, 2, 4)
+    STREAM(256, 128, 2, 2, 3)
+    STREAM(256, 128, 2, 2, 2)
+    STREAM(256, 256, 2, 4, 2)
+    STREAM(256, 256, 4, 2, 2)
+    STREAM(256, 256, 2, 2, 2)
+    return 0;
+}
