@@ -10,7 +10,8 @@ and the per-shard top-100 are all-gathered over RCCL and merged
 
 Prints ONE JSON line on rank 0 (see the round brief for the contract) including
     "roofline"      for the dominant kernel (the MFMA coarse scan k_coarse), timed live with HIP events
-    "cpu_baseline"  the oracle's fp32 sgemm + top-k stand-in for faiss.IndexFlatIP, timed on the host cores
+    "cpu_baseline"  the reference's CPU path timed on the host cores on a bounded sample of the same step: HF BertModel fp32 query
+                    encoding (oracle/encoder_torch.py) + the oracle's fp32 sgemm + top-k stand-in for faiss.IndexFlatIP
 """
 import argparse
 import json
@@ -43,10 +44,11 @@ def parse():
     ap.add_argument("--no-encoder", action="store_true", help="search-only step (query vectors pre-computed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=64)
     return ap.parse_args()
 
 
-def cpu_baseline(args, q_host):
+def cpu_baseline(args, q_host, with_encoder):
     """faiss.IndexFlatIP stand-in (oracle.search_np.search_sgemm: fp32 BLAS sgemm + argpartition, 1024-query
     blocks as retriever/index.py:39-47) on a bounded row sample of the same synthetic corpus, scaled linearly."""
     import torch
@@ -60,10 +62,21 @@ def cpu_baseline(args, q_host):
     S.search_sgemm(q_host, xs, args.topk)
     dt = time.perf_counter() - t0
     scale = args.rows_per_gpu / rows
-    return {"value": len(q_host) / (dt * scale), "unit": "queries/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"search only: {len(q_host)} queries x {rows} of {args.rows_per_gpu} rows fp32 sgemm+argpartition top-{args.topk}, "
-                      f"{dt:.2f}s measured, time scaled x{scale:.0f} to the full shard",
-            "nproc": os.cpu_count()}
+    search_qps = len(q_host) / (dt * scale)
+    out = {"unit": "queries/s", "cores": int(torch.get_num_threads()), "kind": "port", "nproc": os.cpu_count(),
+           "search_only_qps": search_qps,
+           "sample": f"search: {len(q_host)} queries x {rows} of {args.rows_per_gpu} rows fp32 sgemm+argpartition top-{args.topk}, "
+                     f"{dt:.2f}s measured, time scaled x{scale:.0f} to the full shard"}
+    if with_encoder:
+        from oracle import encoder_torch as ET
+        enc_qps, enc_dt = ET.time_encode(args.cpu_sample_queries, args.query_tokens, batch=8)
+        out["encode_only_qps"] = enc_qps
+        out["value"] = 1.0 / (1.0 / enc_qps + 1.0 / search_qps)       # same step as the GPU side: encode the batch, then search it
+        out["sample"] += (f"; encode: {args.cpu_sample_queries} queries x {args.query_tokens} tokens through HF BertModel (BERT-large shape, fp32, "
+                          f"batches of 8), {enc_dt:.2f}s measured; value = 1/(1/encode + 1/search)")
+    else:
+        out["value"] = search_qps
+    return out
 
 
 def main():
@@ -182,7 +195,7 @@ def main():
             "search_stats": {kk: st[kk] for kk in ("queries", "certified", "fallback", "overflow", "reranked_rows", "coarse_rounds")},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, q_vec.cpu().numpy())
+            out["cpu_baseline"] = cpu_baseline(args, q_vec.cpu().numpy(), encoder is not None)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

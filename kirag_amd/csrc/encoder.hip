@@ -16,19 +16,20 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 namespace kr {
 
-using ShapeE = GemmShape<256, 256, 2, 4>;   // rows = output features, cols = tokens
+using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LDS, one block per CU: best main loop (long-K GEMMs)
+using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB LDS, two blocks per CU: one block's epilogue hides under the other's MFMAs
 constexpr int PROJ_STAGES = 2;
-constexpr int PROJ_LDS = PROJ_STAGES * ShapeE::STAGE_BYTES;
 
 struct LayerW {
     uint16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;   // bf16 [out, in]
-    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *bqkv = nullptr, *bo = nullptr, *bo_eff = nullptr, *b1 = nullptr, *b2 = nullptr;   // bo_eff = bo + Wo.bv
     float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 
@@ -61,6 +62,15 @@ __global__ void k_f32_to_bf16(const float* __restrict__ src, uint16_t* __restric
 __global__ void k_scale_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i] * scale;
+}
+
+// b_o' = b_o + W_o . b_v : softmax rows sum to 1, so P (X W_v^T + b_v) = P X W_v^T + b_v and the value bias moves into the output projection
+__global__ void k_fold_vbias(const uint16_t* __restrict__ wo, const float* __restrict__ bo, const float* __restrict__ bv, float* __restrict__ out, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H) return;
+    float s = 0.f;
+    for (int j = 0; j < H; ++j) s += BF16::to_f32(wo[(int64_t)i * H + j]) * bv[j];
+    out[i] = bo[i] + s;
 }
 
 // one wave per sequence: number of attended positions and whether position 0 is attended
@@ -186,9 +196,9 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id
     ln_row_store(v, H, lane, g, bta, eps, xf + t * H, xb + t * H);
 }
 
-// LayerNorm(y) -> xf, xb     (one wave per token; y already holds dense + bias + residual)
+// LayerNorm(y + xf) -> xf, xb     (one wave per token; y holds dense + bias, xf the residual stream, updated in place)
 __global__ __launch_bounds__(256) void k_ln(const float* __restrict__ y, const int* __restrict__ Tp, const float* __restrict__ g,
-                                            const float* __restrict__ bta, float eps, int H, float* __restrict__ xf, uint16_t* __restrict__ xb) {
+                                            const float* __restrict__ bta, float eps, int H, float* xf, uint16_t* __restrict__ xb) {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= *Tp) return;
@@ -196,7 +206,12 @@ __global__ __launch_bounds__(256) void k_ln(const float* __restrict__ y, const i
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int i = lane * 4 + j * 256;
-        v[j] = (i < H) ? *reinterpret_cast<const float4*>(y + t * H + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < H) {
+            const float4 a = *reinterpret_cast<const float4*>(y + t * H + i);
+            const float4 r = *reinterpret_cast<const float4*>(xf + t * H + i);
+            v[j] = make_float4(a.x + r.x, a.y + r.y, a.z + r.z, a.w + r.w);
+        }
     }
     ln_row_store(v, H, lane, g, bta, eps, xf + t * H, xb + t * H);
 }
@@ -216,6 +231,23 @@ enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_VT = 3 };
 
 // erf-GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of
 // the result): ~15 VALU instead of libm erff's ~45 — the epilogue of a persistent one-block-per-CU GEMM is not hidden by other work.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// two elements at once: the polynomial / products run as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32), only rcp / exp2 stay scalar
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2 z = ax * 0.70710678118654752f;
+    const f32x2 den = __builtin_elementwise_fma(z, f32x2{0.3275911f, 0.3275911f}, f32x2{1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f32x2 p = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
+    const f32x2 ez = z * z * (-1.4426950408889634f);
+    const f32x2 e = {__builtin_amdgcn_exp2f(ez.x), __builtin_amdgcn_exp2f(ez.y)};
+    const f32x2 erf_abs = __builtin_elementwise_fma(-(p * t), e, f32x2{1.0f, 1.0f});
+    const f32x2 erf_s = {copysignf(erf_abs.x, x.x), copysignf(erf_abs.y, x.y)};
+    return (x * 0.5f) * (erf_s + 1.0f);
+}
 __device__ __forceinline__ float gelu_erf_fast(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
@@ -229,87 +261,84 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     return 0.5f * x * (1.0f + erf_s);
 }
 
-// persistent streaming projection (gemm_nt_stream, 256x256 tiles, 8 waves of 128 features x 64 tokens, 2-stage LDS ring).
-// Tiles are walked in patches of (4 feature tiles x 8 token tiles) per XCD so that a weight slice and a token slice stay in
-// that XCD's L2 while they are reused.
-template <int EPI>
+// persistent streaming projections (gemm_nt_stream, 256x256 tiles, 8 waves of 128x64, 2-stage LDS ring).
+// Operand roles are chosen for COALESCED epilogue stores (a 32x32 MFMA accumulator has its column on the lane):
+//   k_proj:    rows = tokens, cols = output features -> consecutive lanes hold consecutive features of one token: every store
+//              instruction writes full contiguous 64-B (bf16) / 128-B (fp32) runs of a token row; bias is one value per lane.
+//   k_proj_vt: rows = value features, cols = tokens -> consecutive lanes are consecutive tokens of one feature row of V^T.
+// Token-indexed buffers are allocated in multiples of 256 rows, so a partial last token tile needs no bounds test (rows >= T
+// are written with values computed from clamped loads and never read).
+// Tiles are walked in patches of (4 token tiles x 8 feature tiles) per XCD so operand slices are reused from that XCD's L2.
+template <int EPI, class ShapeE>
 __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = *a.Tp;
-    const int64_t tm_count = (a.F + ShapeE::BM - 1) / ShapeE::BM, tn_count = (T + ShapeE::BN - 1) / ShapeE::BN;
-    gemm_nt_stream<BF16, ShapeE, PROJ_STAGES>(
-        a.W, a.K, a.F, a.X, a.K, T, a.K, tm_count * tn_count, smem,
-        [&](int64_t nat, int64_t& m0, int64_t& n0) {
-            int64_t tm, tn;
-            patch_coord(nat, tm_count, tn_count, tm, tn);
-            m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
-        },
-        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) {
-#pragma unroll
-            for (int ni = 0; ni < ShapeE::TN; ++ni) {
-                const int t = (int)n0 + acc.col(ni);
-                if (t >= T) continue;
-#pragma unroll
-                for (int mi = 0; mi < ShapeE::TM; ++mi) {
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int f = (int)m0 + acc.m_wave + mi * 32 + 8 * gq + 4 * (acc.lane >> 5);
-                        if (f >= a.F) continue;
-                        const float4 b = *reinterpret_cast<const float4*>(a.bias + f);
-                        float v0 = acc.v[mi][ni][4 * gq + 0] + b.x, v1 = acc.v[mi][ni][4 * gq + 1] + b.y;
-                        float v2 = acc.v[mi][ni][4 * gq + 2] + b.z, v3 = acc.v[mi][ni][4 * gq + 3] + b.w;
-                        if constexpr (EPI == EPI_QKV) {
-                            const int which = f < a.H ? 0 : 1;   // a 4-feature group never straddles q|k (H % 128 == 0)
-                            ushort4 o;
-                            o.x = BF16::from_f32(v0); o.y = BF16::from_f32(v1); o.z = BF16::from_f32(v2); o.w = BF16::from_f32(v3);
-                            uint16_t* dst = (which == 0 ? a.out0 : a.out1) + (int64_t)t * a.H + (f - which * a.H);
-                            *reinterpret_cast<ushort4*>(dst) = o;
-                        } else if constexpr (EPI == EPI_RESID) {
-                            const float4 r = *reinterpret_cast<const float4*>(a.resid + (int64_t)t * a.F + f);
-                            *reinterpret_cast<float4*>(a.outf + (int64_t)t * a.F + f) = make_float4(v0 + r.x, v1 + r.y, v2 + r.z, v3 + r.w);
-                        } else {
-                            ushort4 o;   // HF ACT2FN["gelu"]: 0.5 x (1 + erf(x / sqrt 2))
-                            o.x = BF16::from_f32(gelu_erf_fast(v0)); o.y = BF16::from_f32(gelu_erf_fast(v1));
-                            o.z = BF16::from_f32(gelu_erf_fast(v2)); o.w = BF16::from_f32(gelu_erf_fast(v3));
-                            *reinterpret_cast<ushort4*>(a.out0 + (int64_t)t * a.F + f) = o;
-                        }
-                    }
-                }
-            }
-        });
-}
-
-// V^T projection: roles swapped (rows = tokens, cols = value features) so that a lane's 4 consecutive accumulator registers
-// are 4 consecutive TOKENS of one feature -> 8-byte stores into the transposed [H, ldT] layout the attention kernel reads.
-__global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj_vt(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = *a.Tp;
     const int64_t tm_count = (T + ShapeE::BM - 1) / ShapeE::BM, tn_count = (a.F + ShapeE::BN - 1) / ShapeE::BN;
     gemm_nt_stream<BF16, ShapeE, PROJ_STAGES>(
         a.X, a.K, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
-            const int64_t tm = nat / tn_count, tn = nat % tn_count;   // the feature tiles of one token tile are adjacent
+            int64_t tm, tn;
+            patch_coord(nat, tm_count, tn_count, tm, tn);
             m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
         },
         [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) {
+            const int64_t t0 = m0 + acc.m_wave + 4 * (acc.lane >> 5);   // register (mi, r) is token t0 + mi*32 + (r&3) + 8*(r>>2)
 #pragma unroll
             for (int ni = 0; ni < ShapeE::TN; ++ni) {
                 const int f = (int)n0 + acc.col(ni);
                 if (f >= a.F) continue;
                 const float b = a.bias[f];
-                uint16_t* dst = a.outT + (int64_t)f * a.ldT;
+                if constexpr (EPI == EPI_QKV) {
+                    uint16_t* dst = (f < a.H ? a.out0 + f : a.out1 + (f - a.H)) + t0 * a.H;
 #pragma unroll
-                for (int mi = 0; mi < ShapeE::TM; ++mi) {
+                    for (int mi = 0; mi < ShapeE::TM; ++mi)
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int t = (int)m0 + acc.m_wave + mi * 32 + 8 * gq + 4 * (acc.lane >> 5);   // multiple of 4; ldT - T >= 64 slack
-                        if (t >= T) continue;
-                        ushort4 o;
-                        o.x = BF16::from_f32(acc.v[mi][ni][4 * gq + 0] + b); o.y = BF16::from_f32(acc.v[mi][ni][4 * gq + 1] + b);
-                        o.z = BF16::from_f32(acc.v[mi][ni][4 * gq + 2] + b); o.w = BF16::from_f32(acc.v[mi][ni][4 * gq + 3] + b);
-                        *reinterpret_cast<ushort4*>(dst + t) = o;
-                    }
+                        for (int r = 0; r < 16; ++r) dst[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * a.H] = BF16::from_f32(acc.v[mi][ni][r] + b);
+                } else if constexpr (EPI == EPI_RESID) {
+                    float* dst = a.outf + t0 * a.F + f;   // dense + bias in fp32; k_ln adds the residual (a load here would stall the whole CU)
+#pragma unroll
+                    for (int mi = 0; mi < ShapeE::TM; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dst[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * a.F] = acc.v[mi][ni][r] + b;
+                } else {
+                    uint16_t* dst = a.out0 + t0 * a.F + f;
+#pragma unroll
+                    for (int mi = 0; mi < ShapeE::TM; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const f32x2 gl = gelu_erf_fast2(f32x2{acc.v[mi][ni][r] + b, acc.v[mi][ni][r + 1] + b});
+                            dst[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * a.F] = BF16::from_f32(gl.x);
+                            dst[(int64_t)(mi * 32 + ((r + 1) & 3) + 8 * ((r + 1) >> 2)) * a.F] = BF16::from_f32(gl.y);
+                        }
                 }
+            }
+        });
+}
+
+template <class ShapeE>
+__global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj_vt(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = *a.Tp;
+    const int64_t tm_count = (a.F + ShapeE::BM - 1) / ShapeE::BM, tn_count = (T + ShapeE::BN - 1) / ShapeE::BN;
+    gemm_nt_stream<BF16, ShapeE, PROJ_STAGES>(
+        a.W, a.K, a.F, a.X, a.K, T, a.K, tm_count * tn_count, smem,
+        [&](int64_t nat, int64_t& m0, int64_t& n0) {
+            const int64_t tn = nat / tm_count, tm = nat % tm_count;   // the feature tiles of one token tile are adjacent
+            m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
+        },
+        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) {
+            const int f0 = (int)m0 + acc.m_wave + 4 * (acc.lane >> 5);   // register (mi, r) is feature f0 + mi*32 + (r&3) + 8*(r>>2)
+#pragma unroll
+            for (int ni = 0; ni < ShapeE::TN; ++ni) {
+                const int64_t t = n0 + acc.col(ni);                       // < round_up(T, 256) <= ldT
+                uint16_t* dst = a.outT + t;
+#pragma unroll
+                for (int mi = 0; mi < ShapeE::TM; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = f0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+                        if (f < a.F) dst[(int64_t)f * a.ldT] = BF16::from_f32(acc.v[mi][ni][r]);   // b_v is folded into the out-proj bias (k_fold_vbias)
+                    }
             }
         });
 }
@@ -481,7 +510,7 @@ static int ensure_ws(Encoder* e, int B, int S) {
     if (!e->d_T) { KR_TRY(dmalloc(&e->d_T, sizeof(int))); KR_TRY(dmalloc(&e->d_err, sizeof(int))); }
     if (maxT <= e->capT && B <= e->capB && (int64_t)B * S <= e->capBS) return 0;
     free_ws(e);
-    const int64_t capT = round_up(maxT, 128), capB = B, capBS = (int64_t)B * S;
+    const int64_t capT = round_up(maxT, 256), capB = B, capBS = (int64_t)B * S;   // multiple of the 256-token tile: see k_proj
     KR_TRY(dmalloc(&e->d_ids, capBS * 8)); KR_TRY(dmalloc(&e->d_mask, capBS * 8));
     KR_TRY(dmalloc(&e->seq_off, capB * 4)); KR_TRY(dmalloc(&e->seq_nk, capB * 4)); KR_TRY(dmalloc(&e->seq_nq, capB * 4)); KR_TRY(dmalloc(&e->seq_cls, capB * 4)); KR_TRY(dmalloc(&e->seq_has0, capB * 4));
     KR_TRY(dmalloc(&e->tok_id, capT * 4)); KR_TRY(dmalloc(&e->tok_pos, capT * 4));
@@ -542,20 +571,31 @@ static int parse_name(const Encoder* e, const char* name, int& slot, int64_t& nu
     return fail(KR_EINVAL, "unknown tensor name '%s'", name);
 }
 
-static int launch_proj(int epi, const ProjArgs& a, int num_cu, hipStream_t st) {
+template <class Shape>
+static int launch_proj_shape(int epi, const ProjArgs& a, int num_cu, hipStream_t st) {
+    constexpr int lds = PROJ_STAGES * Shape::STAGE_BYTES;
+    const int blocks = num_cu * (Shape::NTHREADS == 256 ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, PROJ_LDS));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, PROJ_LDS));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, PROJ_LDS));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_vt), hipFuncAttributeMaxDynamicSharedMemorySize, PROJ_LDS));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_QKV, Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_RESID, Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_GELU, Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_vt<Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    if (epi == EPI_VT) hipLaunchKernelGGL(k_proj_vt, dim3(num_cu), dim3(ShapeE::NTHREADS), PROJ_LDS, st, a);
-    else if (epi == EPI_QKV) hipLaunchKernelGGL(k_proj<EPI_QKV>, dim3(num_cu), dim3(ShapeE::NTHREADS), PROJ_LDS, st, a);
-    else if (epi == EPI_RESID) hipLaunchKernelGGL(k_proj<EPI_RESID>, dim3(num_cu), dim3(ShapeE::NTHREADS), PROJ_LDS, st, a);
-    else hipLaunchKernelGGL(k_proj<EPI_GELU>, dim3(num_cu), dim3(ShapeE::NTHREADS), PROJ_LDS, st, a);
+    if (epi == EPI_VT) hipLaunchKernelGGL((k_proj_vt<Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    else if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj<EPI_QKV, Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    else if (epi == EPI_RESID) hipLaunchKernelGGL((k_proj<EPI_RESID, Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    else hipLaunchKernelGGL((k_proj<EPI_GELU, Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
     return 0;
+}
+
+// shape choice per projection: env KIRAG_AMD_PROJ = 4 characters (q|k, v^T, dense->fp32, gelu), each 'b' (256x256) or 's' (128x128)
+static int launch_proj(int epi, const ProjArgs& a, int num_cu, hipStream_t st) {
+    static const std::string cfg = [] { const char* e = getenv("KIRAG_AMD_PROJ"); return std::string(e && strlen(e) == 4 ? e : "bbbb"); }();
+    const int idx = epi == EPI_QKV ? 0 : epi == EPI_VT ? 1 : epi == EPI_RESID ? 2 : 3;
+    if (cfg[idx] == 's') return launch_proj_shape<ShapeSmall>(epi, a, num_cu, st);
+    return launch_proj_shape<ShapeBig>(epi, a, num_cu, st);
 }
 
 }  // namespace kr
@@ -584,7 +624,7 @@ int kr_encoder_create(const kr_bert_cfg* cfg, int device, kr_encoder** out) {
     A(&e->elng, H * 4); A(&e->elnb, H * 4);
     for (auto& l : e->L) {
         A(&l.wqkv, 3 * H * H * 2); A(&l.wo, H * H * 2); A(&l.w1, FF * H * 2); A(&l.w2, H * FF * 2);
-        A(&l.bqkv, 3 * H * 4); A(&l.bo, H * 4); A(&l.b1, FF * 4); A(&l.b2, H * 4);
+        A(&l.bqkv, 3 * H * 4); A(&l.bo, H * 4); A(&l.bo_eff, H * 4); A(&l.b1, FF * 4); A(&l.b2, H * 4);
         A(&l.ln1g, H * 4); A(&l.ln1b, H * 4); A(&l.ln2g, H * 4); A(&l.ln2b, H * 4);
     }
     if (rc) { kr_encoder_destroy(reinterpret_cast<kr_encoder*>(e)); return rc; }
@@ -600,7 +640,7 @@ void kr_encoder_destroy(kr_encoder* h) {
     void* ptrs[] = {e->word, e->pos, e->type, e->elng, e->elnb, e->stage, e->d_T, e->d_err};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& l : e->L) {
-        void* lp[] = {l.wqkv, l.wo, l.w1, l.w2, l.bqkv, l.bo, l.b1, l.b2, l.ln1g, l.ln1b, l.ln2g, l.ln2b};
+        void* lp[] = {l.wqkv, l.wo, l.w1, l.w2, l.bqkv, l.bo, l.bo_eff, l.b1, l.b2, l.ln1g, l.ln1b, l.ln2g, l.ln2b};
         for (void* p : lp) if (p) (void)hipFree(p);
     }
     delete e;
@@ -664,6 +704,11 @@ int kr_encoder_finalize(kr_encoder* h) {
         if (!e->got[i]) return fail(KR_ESTATE, "weight slot %zu (layer %d, tensor %d) was never loaded", i,
                                     i < T_LAYER0 ? -1 : (int)((i - T_LAYER0) / L_COUNT), i < T_LAYER0 ? (int)i : (int)((i - T_LAYER0) % L_COUNT));
     if (e->stage) { (void)hipFree(e->stage); e->stage = nullptr; e->stage_elems = 0; }
+    KR_TRY(select_device(e->device));
+    const int H = e->cfg.hidden;
+    for (auto& l : e->L) hipLaunchKernelGGL(k_fold_vbias, dim3((H + 127) / 128), dim3(128), 0, 0, l.wo, l.bo, l.bqkv + 2 * H, l.bo_eff, H);
+    KR_HIP(hipGetLastError());
+    KR_HIP(hipDeviceSynchronize());
     e->ready = true;
     return 0;
 }
@@ -703,14 +748,14 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         KR_TRY(launch_proj(EPI_VT, a, e->num_cu, st));
         hipLaunchKernelGGL(k_attn, attn_grid, dim3(256), 0, st, e->q, e->k, e->vT, e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, e->ctx);
         // attention.output.dense + residual -> LayerNorm
-        a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo; a.resid = e->xf; a.outf = e->y;
+        a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.outf = e->y;
         KR_TRY(launch_proj(EPI_RESID, a, e->num_cu, st));
         hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln1g, l.ln1b, eps, H, e->xf, e->xb);
         // intermediate.dense + GELU
         a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h;
         KR_TRY(launch_proj(EPI_GELU, a, e->num_cu, st));
         // output.dense + residual -> LayerNorm
-        a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.resid = e->xf; a.outf = e->y;
+        a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.outf = e->y;
         KR_TRY(launch_proj(EPI_RESID, a, e->num_cu, st));
         hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln2g, l.ln2b, eps, H, e->xf, e->xb);
     }
