@@ -27,6 +27,14 @@ using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LD
 using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB LDS, two blocks per CU: one block's epilogue hides under the other's MFMAs
 constexpr int PROJ_STAGES = 2;
 
+// main loop per tile shape: the 256x256 tile runs the ping-pong schedule, the 128x128 tile the v2 streaming loop
+template <class ShapeE, class Coord, class Epilogue>
+__device__ __forceinline__ void gemm_main(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb, int64_t N,
+                                          int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
+    if constexpr (ShapeE::BM == 256 && ShapeE::BN == 256) gemm_nt_pingpong<BF16>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
+    else gemm_nt_stream<BF16, ShapeE, PROJ_STAGES>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
+}
+
 struct LayerW {
     uint16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;   // bf16 [out, in]
     float *bqkv = nullptr, *bo = nullptr, *bo_eff = nullptr, *b1 = nullptr, *b2 = nullptr;   // bo_eff = bo + Wo.bv
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = *a.Tp;
     const int64_t tm_count = (T + ShapeE::BM - 1) / ShapeE::BM, tn_count = (a.F + ShapeE::BN - 1) / ShapeE::BN;
-    gemm_nt_stream<BF16, ShapeE, PROJ_STAGES>(
+    gemm_main<ShapeE>(
         a.X, a.K, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             int64_t tm, tn;
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj_vt(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = *a.Tp;
     const int64_t tm_count = (a.F + ShapeE::BM - 1) / ShapeE::BM, tn_count = (T + ShapeE::BN - 1) / ShapeE::BN;
-    gemm_nt_stream<BF16, ShapeE, PROJ_STAGES>(
+    gemm_main<ShapeE>(
         a.W, a.K, a.F, a.X, a.K, T, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             const int64_t tn = nat / tm_count, tm = nat % tm_count;   // the feature tiles of one token tile are adjacent

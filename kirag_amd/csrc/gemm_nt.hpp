@@ -297,4 +297,163 @@ __device__ __forceinline__ void gemm_nt_stream(const uint16_t* __restrict__ A, i
     }
 }
 
+// =====================================================================================================================
+// v3 main loop: PING-PONG.  256x256x64 tiles, 8 waves = two groups of four (group = wave >> 2 owns tile rows
+// [128*group, +128), wave & 3 owns 64 columns; waves w and w+4 share a SIMD, so every SIMD hosts one wave of each group).
+// Time is cut into intervals separated by ONE s_barrier each; in every interval one group multiplies (16 MFMAs of
+// 32x32x16 = 512 cycles of its SIMD's matrix pipe, nothing else) while the other group does everything else: the 12
+// ds_read_b128 of its next 16 MFMAs, 4 LDS-DMA pieces of a later K-tile, and the counted waits.  The matrix pipe of every
+// SIMD therefore always has a wave whose only job is to feed it, and no LDS / DMA latency sits between two MFMAs.
+//
+//   interval        4t-1      4t        4t+1      4t+2      4t+3 ...
+//   group 0         L(t,0)    M(t,0)    L(t,1)    M(t,1)    L(t+1,0)
+//   group 1         M(t-1,1)  L(t,0)    M(t,0)    L(t,1)    M(t,1)
+//
+// L(t,h) reads the fragments of k-half h of K-tile t (ring slot t & 1) and issues DMA:  group 0: L(t,0) -> B rows 0..127 of
+// tile t+1, L(t,1) -> A rows 128..255 of tile t+1;  group 1: L(t,0) -> B rows 128..255 of tile t+1, L(t,1) -> A rows 0..127
+// of tile t+2.  Each L ends with  s_waitcnt vmcnt(4)  (everything but the 4 pieces just issued has landed: every piece gets
+// >= 2 intervals of latency budget and lands one barrier before its first reader, cdna_hip_programming.md "Read a staged
+// buffer one phase AFTER the wait that retires it") and  lgkmcnt(0)  (this wave's fragment reads are done, so the region it
+// read may be re-staged after the barrier: WAR).  Region life times (K-tile t in slot t & 1):
+//   A rows 0..127   read by group 0 in 4t-1, 4t+1     re-staged (tile t+2) by group 1 in 4t+2
+//   A rows 128..255 read by group 1 in 4t,   4t+2     re-staged by group 0 in 4t+5
+//   B               read by both in 4t-1 .. 4t+2      re-staged by group 0 in 4t+3 (rows 0..127), group 1 in 4t+4
+// The K-tile stream runs across output tiles (persistent blocks, as v2); past the end of the stream the DMA cursors stay
+// on the last K-tile (dummy re-loads into regions nobody reads any more) so that the vmcnt arithmetic never changes.
+// =====================================================================================================================
+using ShapePP = GemmShape<256, 256, 2, 4>;
+
+template <class T, class Coord, class Epilogue>
+__device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb,
+                                                 int64_t N, int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
+    using Shape = ShapePP;
+    constexpr int BK = Shape::BK, STAGE = Shape::STAGE_BYTES, ABYTES = Shape::A_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int64_t G = gridDim.x;
+    const int64_t my = (total_tiles > (int64_t)blockIdx.x) ? (total_tiles - blockIdx.x + G - 1) / G : 0;
+    if (my == 0) return;
+    const int nk = K / BK;
+    const int64_t total_g = my * nk;
+
+    // ---- DMA cursors: a position in this block's K-tile stream + per-lane source offsets of 4 pieces -------------------
+    struct Cursor {
+        int64_t tile; int kt; int slot;      // output tile index (in this block's sequence), K-tile inside it, ring slot of the stream index
+        const char* base; uint32_t off[4];
+    };
+    auto set_base = [&](Cursor& c, bool isA, int piece0) {
+        int64_t m0, n0;
+        coord(xcd_chunk_map((int64_t)blockIdx.x + c.tile * G, total_tiles), m0, n0);
+        const int64_t r0 = isA ? m0 : n0, ld = isA ? lda : ldb, left = (isA ? M : N) - r0;
+        c.base = reinterpret_cast<const char*>((isA ? A : B) + r0 * ld);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int row = (piece0 + p) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            if (row >= left) row = (int)left - 1;
+            c.off[p] = (uint32_t)(row * ld * 2 + chunk * 16);
+        }
+    };
+    auto init_cursor = [&](Cursor& c, int64_t s, bool isA, int piece0) {
+        c.slot = (int)(s & 1);
+        if (s >= total_g) s = total_g - 1;
+        c.tile = s / nk; c.kt = (int)(s - c.tile * nk);
+        set_base(c, isA, piece0);
+    };
+    auto issue4 = [&](Cursor& c, bool isA, int piece0) {
+        char* dst = smem + c.slot * STAGE + (isA ? 0 : ABYTES) + piece0 * 1024;
+        const char* src = c.base + (int64_t)c.kt * (BK * 2);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src + c.off[p]), (lds_void*)(dst + p * 1024), 16, 0, 0);
+        c.slot ^= 1;
+        if (c.kt + 1 < nk) { ++c.kt; }
+        else if (c.tile + 1 < my) { c.kt = 0; ++c.tile; set_base(c, isA, piece0); }
+        // else: end of the stream, stay on the last K-tile (dummy re-loads)
+    };
+
+    const int xpiece = grp * 16 + wq * 4;          // B pieces this wave stages in L(t,0)
+    const int ypiece = (1 - grp) * 16 + wq * 4;    // A pieces this wave stages in L(t,1)
+
+    // ---- prologue: K-tile 0 completely, A rows 0..127 of K-tile 1 ---------------------------------------------------------
+    {
+        Cursor c;
+        init_cursor(c, 0, true, wave * 4);  { Cursor d = c; issue4(d, true, wave * 4); }
+        init_cursor(c, 0, false, wave * 4); { Cursor d = c; issue4(d, false, wave * 4); }
+        // A rows 0..127 of tile 1 = 16 pieces = 2 per wave; issue4 moves 4 pieces, so waves 0..3 take them (pieces 4*wave .. +3)
+        if (wave < 4) { init_cursor(c, 1, true, wave * 4); issue4(c, true, wave * 4); }
+    }
+    Cursor cx, cy;
+    init_cursor(cx, 1, false, xpiece);
+    init_cursor(cy, grp ? 2 : 1, true, ypiece);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind group 0
+
+    const int frow = lane & 31, fh = lane >> 5;
+    const int fswz = (frow >> 1) & 7;
+    const int a_row_byte = (grp * 128 + frow) * 128;
+    const int b_row_byte = (wq * 64 + frow) * 128;
+
+    int cur = 0;   // ring slot of the K-tile being multiplied
+    for (int64_t i = 0; i < my; ++i) {
+        int64_t m0, n0;
+        const int64_t nat = xcd_chunk_map((int64_t)blockIdx.x + i * G, total_tiles);
+        coord(nat, m0, n0);
+        AccTile<Shape> acc;
+        acc.m_wave = grp * 128;
+        acc.n_wave = wq * 64;
+        acc.lane = lane;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.v[mi][ni][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sa = smem + cur * STAGE;
+            const char* sb = sa + ABYTES;
+            cur ^= 1;
+            uint4 af[2][4], bf[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // ---------------- L(t,h): fragments of k-half h, 4 DMA pieces, counted waits ----------------
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int coff = ((2 * (2 * h + k2) + fh) ^ fswz) << 4;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) bf[k2][ni] = *reinterpret_cast<const uint4*>(sb + b_row_byte + ni * 32 * 128 + coff);
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) af[k2][mi] = *reinterpret_cast<const uint4*>(sa + a_row_byte + mi * 32 * 128 + coff);
+                }
+                if (h == 0) issue4(cx, false, xpiece); else issue4(cy, true, ypiece);
+                wait_vmcnt<4>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---------------- M(t,h): 16 MFMAs, nothing else ----------------
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) acc.v[mi][ni] = T::mfma(af[k2][mi], bf[k2][ni], acc.v[mi][ni]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        epi(acc, m0, n0, nat);
+    }
+    if (!grp) __builtin_amdgcn_s_barrier();   // group 0 started one interval early: same number of barriers for every wave
+    wait_vmcnt<0>();                            // dummy tail DMAs must not land after the caller re-uses the ring
+    __builtin_amdgcn_s_barrier();
+}
+
+
 }  // namespace kr

@@ -29,7 +29,7 @@
 
 namespace kr {
 
-using ShapeC = GemmShape<256, 256, 2, 4>;   // coarse scan tile: 256 corpus rows x 256 queries, 8 waves of 128x64, 2-stage ring (128 KiB LDS)
+using ShapeC = ShapePP;                     // coarse scan tile: 256 corpus rows x 256 queries, 8 waves of 128x64, ping-pong main loop (128 KiB LDS ring)
 constexpr int COARSE_STAGES = 2;
 constexpr int QBLK = 1024;                   // queries per search block (reference index_batch_size)
 constexpr int EXACT_RC = 1024;               // rows per block of the exact scan
@@ -145,7 +145,7 @@ struct CoarseArgs {
     int64_t ntiles, perm_mul;         // slot -> tile = (slot * perm_mul) % ntiles   (perm_mul coprime to ntiles)
 };
 
-// persistent streaming coarse scan (gemm_nt_stream): grid = one block per CU, so nothing else on the CU hides an epilogue
+// persistent streaming coarse scan (gemm_nt_pingpong): grid = one block per CU, so nothing else on the CU hides an epilogue
 // stall, and the whole kernel must stay inside the instruction cache: the epilogue is branch-light and touches no global
 // memory that it has to wait for.
 //   direct != 0 (round 0, thr = -inf): every score is stored at slot = (tile slot in round)*BM + row in tile, no atomics.
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(ShapeC::NTHREADS, 2) void k_coarse(CoarseArgs a) {
     const int64_t tn_count = a.nq_pad / ShapeC::BN;
     const int64_t total = a.tile_count * tn_count;
     const int64_t n_pad = (a.n + ShapeC::BM - 1) / ShapeC::BM * ShapeC::BM;
-    gemm_nt_stream<T, ShapeC, COARSE_STAGES>(
+    gemm_nt_pingpong<T>(
         a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             const int64_t tslot = nat / tn_count, tn = nat % tn_count;   // the query blocks of one corpus tile are adjacent
