@@ -54,8 +54,8 @@ struct Encoder {
     int64_t *d_ids = nullptr, *d_mask = nullptr;
     int *seq_off = nullptr, *seq_nk = nullptr, *seq_nq = nullptr, *seq_cls = nullptr, *seq_has0 = nullptr, *d_T = nullptr, *d_err = nullptr;
     int *tok_id = nullptr, *tok_pos = nullptr;
-    float *xf = nullptr, *y = nullptr, *out = nullptr;
-    uint16_t *xb = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *ctx = nullptr, *h = nullptr;
+    float *xf = nullptr, *out = nullptr;
+    uint16_t *y = nullptr, *xb = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *ctx = nullptr, *h = nullptr;
     int lastB = 0, lastS = 0;
     int num_cu = 256;
 };
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id
     ln_row_store(v, H, lane, g, bta, eps, xf + t * H, xb + t * H);
 }
 
-// LayerNorm(y + xf) -> xf, xb     (one wave per token; y holds dense + bias, xf the residual stream, updated in place)
-__global__ __launch_bounds__(256) void k_ln(const float* __restrict__ y, const int* __restrict__ Tp, const float* __restrict__ g,
+// LayerNorm(y + xf) -> xf, xb     (one wave per token; y holds dense + bias as bf16, xf the fp32 residual stream, updated in place)
+__global__ __launch_bounds__(256) void k_ln(const uint16_t* __restrict__ y, const int* __restrict__ Tp, const float* __restrict__ g,
                                             const float* __restrict__ bta, float eps, int H, float* xf, uint16_t* __restrict__ xb) {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -216,26 +216,24 @@ __global__ __launch_bounds__(256) void k_ln(const float* __restrict__ y, const i
         const int i = lane * 4 + j * 256;
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < H) {
-            const float4 a = *reinterpret_cast<const float4*>(y + t * H + i);
+            const ushort4 a = *reinterpret_cast<const ushort4*>(y + t * H + i);
             const float4 r = *reinterpret_cast<const float4*>(xf + t * H + i);
-            v[j] = make_float4(a.x + r.x, a.y + r.y, a.z + r.z, a.w + r.w);
+            v[j] = make_float4(BF16::to_f32(a.x) + r.x, BF16::to_f32(a.y) + r.y, BF16::to_f32(a.z) + r.z, BF16::to_f32(a.w) + r.w);
         }
     }
     ln_row_store(v, H, lane, g, bta, eps, xf + t * H, xb + t * H);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// projections: C^T[feature, token] = W[feature, :] . X[token, :]   (rows = features so that a lane's 4 consecutive
-// accumulator registers are 4 consecutive features of ONE token -> 8/16-byte stores)
+// projections: C[token, feature] = X[token, :] . W[feature, :]   (rows = tokens, cols = output features)
 // ---------------------------------------------------------------------------------------------------------
 struct ProjArgs {
     const uint16_t* W; const uint16_t* X; const int* Tp; int F; int K; int H;
     const float* bias;
-    uint16_t* out0; uint16_t* out1; uint16_t* outT; int64_t ldT;   // QKV: q, k row-major [T,H]; vT [H, ldT]
-    const float* resid; float* outf;                               // residual epilogue: outf[t,F] = acc + bias + resid[t,F]
+    uint16_t* out0; uint16_t* out1; uint16_t* outT; int64_t ldT;   // QKV: q, k row-major [T,H]; vT [H, ldT].  Others: out0 [T, F]
 };
 
-enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_VT = 3 };
+enum { EPI_QKV = 0, EPI_DENSE = 1, EPI_GELU = 2 };
 
 // erf-GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of
 // the result): ~15 VALU instead of libm erff's ~45 — the epilogue of a persistent one-block-per-CU GEMM is not hidden by other work.
@@ -256,32 +254,82 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
     const f32x2 erf_s = {copysignf(erf_abs.x, x.x), copysignf(erf_abs.y, x.y)};
     return (x * 0.5f) * (erf_s + 1.0f);
 }
-__device__ __forceinline__ float gelu_erf_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = fmaf(-p * t, e, 1.0f);                 // erf(|x|/sqrt2)
-    const float erf_s = copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erf_s);
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)BF16::from_f32(lo) | ((uint32_t)BF16::from_f32(hi) << 16); }
+
+// A 32x32 MFMA accumulator has its COLUMN on the lane, so a direct store writes 2-byte elements (128 store instructions per lane per
+// 256x256 tile, the epilogue then costs as much as a third of the main loop).  Instead every wave owns a private 4-KiB LDS stage
+// behind the ring (no barrier: only this wave touches it, LDS operations of one wave complete in order):
+//   rows:  the wave's 32 x 64 block (one mi, both ni) is written as bf16 [32 rows][128 B] and read back 16 B per lane, so each global
+//          store instruction writes eight whole 128-B lines of the output;
+//   V^T:   each 32x32 tile is written TRANSPOSED ([feature][token], 4 consecutive tokens of a lane packed into 8 B, 80-B rows) and
+//          read back 16 B per lane: a store instruction writes 64-B runs of sixteen V^T rows.
+constexpr int EPI_STAGE_BYTES = 4096;
+
+template <class Shape, class F>
+__device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ out, int64_t ld, int64_t row0, int col0,
+                                                int ncols, F&& f) {
+    const int c = acc.lane & 31, h = acc.lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < Shape::TM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < Shape::TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v = f(f32x2{acc.v[mi][ni][r], acc.v[mi][ni][r + 1]}, ni);
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;     // r even: rows rl and rl + 1
+                *reinterpret_cast<uint16_t*>(stage + rl * (Shape::TN * 64) + (ni * 32 + c) * 2) = BF16::from_f32(v.x);
+                *reinterpret_cast<uint16_t*>(stage + (rl + 1) * (Shape::TN * 64) + (ni * 32 + c) * 2) = BF16::from_f32(v.y);
+            }
+        constexpr int LPR = Shape::TN * 4;           // lanes per row (16 B each)
+        constexpr int RPI = 64 / LPR;                // rows per store instruction
+#pragma unroll
+        for (int p = 0; p < 32 / RPI; ++p) {
+            const int rl = p * RPI + acc.lane / LPR, ch = acc.lane % LPR;
+            const uint4 d = *reinterpret_cast<const uint4*>(stage + rl * (Shape::TN * 64) + ch * 16);
+            if (col0 + ch * 8 < ncols) *reinterpret_cast<uint4*>(out + (row0 + mi * 32 + rl) * ld + col0 + ch * 8) = d;
+        }
+    }
 }
 
-// persistent streaming projections (gemm_nt_stream, 256x256 tiles, 8 waves of 128x64, 2-stage LDS ring).
-// Operand roles are chosen for COALESCED epilogue stores (a 32x32 MFMA accumulator has its column on the lane):
-//   k_proj:    rows = tokens, cols = output features -> consecutive lanes hold consecutive features of one token: every store
-//              instruction writes full contiguous 64-B (bf16) / 128-B (fp32) runs of a token row; bias is one value per lane.
-//   k_proj_vt: rows = value features, cols = tokens -> consecutive lanes are consecutive tokens of one feature row of V^T.
-// Token-indexed buffers are allocated in multiples of 256 rows, so a partial last token tile needs no bounds test (rows >= T
-// are written with values computed from clamped loads and never read).
-// Tiles are walked in patches of (4 token tiles x 8 feature tiles) per XCD so operand slices are reused from that XCD's L2.
+// V^T[feature, token] from the same accumulator block: features f0 .. f0+TN*32 (valid below nf), tokens t0 .. t0+TM*32
+template <class Shape>
+__device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ outT, int64_t ldT, int64_t t0, int f0, int nf) {
+    const int c = acc.lane & 31, h = acc.lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < Shape::TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < Shape::TN; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = pack_bf16x2(acc.v[mi][ni][4 * g + 0], acc.v[mi][ni][4 * g + 1]);
+                w.y = pack_bf16x2(acc.v[mi][ni][4 * g + 2], acc.v[mi][ni][4 * g + 3]);
+                *reinterpret_cast<uint2*>(stage + c * 80 + (8 * g + 4 * h) * 2) = w;    // tokens 8g+4h .. +3 of feature c
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int fl = p * 16 + (acc.lane >> 2), ch = acc.lane & 3;
+                const uint4 d = *reinterpret_cast<const uint4*>(stage + fl * 80 + ch * 16);
+                const int f = f0 + ni * 32 + fl;
+                if (f < nf) *reinterpret_cast<uint4*>(outT + (int64_t)f * ldT + t0 + mi * 32 + ch * 8) = d;
+            }
+        }
+}
+
+// persistent streaming projections (256x256 ping-pong or 128x128 streaming main loop).  rows = tokens, cols = output features; bias is
+// one value per lane and ni.  Token-indexed buffers are allocated in multiples of 256 rows, so a partial last token tile needs no bounds
+// test (rows >= T are written with values computed from clamped loads and never read).
+// Tiles are walked in patches of (token tiles x 8 feature tiles) per XCD so operand slices are reused from that XCD's L2.
+//   EPI_QKV:   F = 3H: features [0,H) -> q (bias, 1/8 folded into the weights), [H,2H) -> k, [2H,3H) -> V^T (its bias lives in bo_eff)
+//   EPI_DENSE: out0[T,F] = acc + bias as bf16 (k_ln adds the fp32 residual)
+//   EPI_GELU:  out0[T,F] = gelu(acc + bias)
 template <int EPI, class ShapeE>
 __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = *a.Tp;
     const int64_t tm_count = (T + ShapeE::BM - 1) / ShapeE::BM, tn_count = (a.F + ShapeE::BN - 1) / ShapeE::BN;
+    char* stage = smem + PROJ_STAGES * ShapeE::STAGE_BYTES + (threadIdx.x >> 6) * EPI_STAGE_BYTES;
     gemm_main<ShapeE>(
         a.X, a.K, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
@@ -290,63 +338,24 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
             m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
         },
         [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) {
-            const int64_t t0 = m0 + acc.m_wave + 4 * (acc.lane >> 5);   // register (mi, r) is token t0 + mi*32 + (r&3) + 8*(r>>2)
+            const int64_t t0 = m0 + acc.m_wave;
+            const int f0 = (int)n0 + acc.n_wave;          // first feature of this wave's 64 (TN*32) columns
+            if (f0 >= a.F) return;
+            float b[ShapeE::TN];
 #pragma unroll
-            for (int ni = 0; ni < ShapeE::TN; ++ni) {
-                const int f = (int)n0 + acc.col(ni);
-                if (f >= a.F) continue;
-                const float b = a.bias[f];
-                if constexpr (EPI == EPI_QKV) {
-                    uint16_t* dst = (f < a.H ? a.out0 + f : a.out1 + (f - a.H)) + t0 * a.H;
-#pragma unroll
-                    for (int mi = 0; mi < ShapeE::TM; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dst[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * a.H] = BF16::from_f32(acc.v[mi][ni][r] + b);
-                } else if constexpr (EPI == EPI_RESID) {
-                    float* dst = a.outf + t0 * a.F + f;   // dense + bias in fp32; k_ln adds the residual (a load here would stall the whole CU)
-#pragma unroll
-                    for (int mi = 0; mi < ShapeE::TM; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dst[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * a.F] = acc.v[mi][ni][r] + b;
+            for (int ni = 0; ni < ShapeE::TN; ++ni) { const int f = f0 + ni * 32 + (acc.lane & 31); b[ni] = (f < a.F) ? a.bias[f] : 0.f; }
+            if constexpr (EPI == EPI_QKV) {
+                const int region = f0 / a.H;              // H % 64 == 0 (TN*32 | H): a wave's columns never straddle q | k | v
+                if (region == 2) {
+                    store_transposed_bf16<ShapeE>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H, a.H);
                 } else {
-                    uint16_t* dst = a.out0 + t0 * a.F + f;
-#pragma unroll
-                    for (int mi = 0; mi < ShapeE::TM; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 16; r += 2) {
-                            const f32x2 gl = gelu_erf_fast2(f32x2{acc.v[mi][ni][r] + b, acc.v[mi][ni][r + 1] + b});
-                            dst[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * a.F] = BF16::from_f32(gl.x);
-                            dst[(int64_t)(mi * 32 + ((r + 1) & 3) + 8 * ((r + 1) >> 2)) * a.F] = BF16::from_f32(gl.y);
-                        }
+                    store_rows_bf16<ShapeE>(acc, stage, region ? a.out1 : a.out0, a.H, t0, f0 - region * a.H, a.H,
+                                            [&](f32x2 v, int ni) { return v + b[ni]; });
                 }
-            }
-        });
-}
-
-template <class ShapeE>
-__global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj_vt(ProjArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = *a.Tp;
-    const int64_t tm_count = (a.F + ShapeE::BM - 1) / ShapeE::BM, tn_count = (T + ShapeE::BN - 1) / ShapeE::BN;
-    gemm_main<ShapeE>(
-        a.W, a.K, a.F, a.X, a.K, T, a.K, tm_count * tn_count, smem,
-        [&](int64_t nat, int64_t& m0, int64_t& n0) {
-            const int64_t tn = nat / tm_count, tm = nat % tm_count;   // the feature tiles of one token tile are adjacent
-            m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
-        },
-        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) {
-            const int f0 = (int)m0 + acc.m_wave + 4 * (acc.lane >> 5);   // register (mi, r) is feature f0 + mi*32 + (r&3) + 8*(r>>2)
-#pragma unroll
-            for (int ni = 0; ni < ShapeE::TN; ++ni) {
-                const int64_t t = n0 + acc.col(ni);                       // < round_up(T, 256) <= ldT
-                uint16_t* dst = a.outT + t;
-#pragma unroll
-                for (int mi = 0; mi < ShapeE::TM; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int f = f0 + mi * 32 + (r & 3) + 8 * (r >> 2);
-                        if (f < a.F) dst[(int64_t)f * a.ldT] = BF16::from_f32(acc.v[mi][ni][r]);   // b_v is folded into the out-proj bias (k_fold_vbias)
-                    }
+            } else if constexpr (EPI == EPI_DENSE) {
+                store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, a.F, [&](f32x2 v, int ni) { return v + b[ni]; });
+            } else {
+                store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, a.F, [&](f32x2 v, int ni) { return gelu_erf_fast2(v + b[ni]); });
             }
         });
 }
@@ -354,8 +363,6 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj_vt(ProjArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // attention: one wave per (sequence, head, 32 queries); d_h = 64; softmax(Q K^T + key mask) V   (1/sqrt(d_h) is in Wq)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)BF16::from_f32(lo) | ((uint32_t)BF16::from_f32(hi) << 16); }
-
 __global__ __launch_bounds__(256) void k_attn(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vT, int64_t ldv,
                                               const int* __restrict__ seq_off, const int* __restrict__ seq_nk, const int* __restrict__ seq_nq,
                                               int H, int heads, uint16_t* __restrict__ ctx) {
@@ -508,7 +515,7 @@ static void free_ws(Encoder* e) {
                     e->xb, e->q, e->k, e->vT, e->ctx, e->h};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     e->d_ids = e->d_mask = nullptr; e->seq_off = e->seq_nk = e->seq_nq = e->seq_cls = e->seq_has0 = nullptr; e->tok_id = e->tok_pos = nullptr;
-    e->xf = e->y = e->out = nullptr; e->xb = e->q = e->k = e->vT = e->ctx = e->h = nullptr;
+    e->xf = e->out = nullptr; e->y = e->xb = e->q = e->k = e->vT = e->ctx = e->h = nullptr;
     e->capT = 0; e->capB = 0; e->capBS = 0;
 }
 
@@ -522,7 +529,7 @@ static int ensure_ws(Encoder* e, int B, int S) {
     KR_TRY(dmalloc(&e->d_ids, capBS * 8)); KR_TRY(dmalloc(&e->d_mask, capBS * 8));
     KR_TRY(dmalloc(&e->seq_off, capB * 4)); KR_TRY(dmalloc(&e->seq_nk, capB * 4)); KR_TRY(dmalloc(&e->seq_nq, capB * 4)); KR_TRY(dmalloc(&e->seq_cls, capB * 4)); KR_TRY(dmalloc(&e->seq_has0, capB * 4));
     KR_TRY(dmalloc(&e->tok_id, capT * 4)); KR_TRY(dmalloc(&e->tok_pos, capT * 4));
-    KR_TRY(dmalloc(&e->xf, capT * H * 4)); KR_TRY(dmalloc(&e->y, capT * H * 4)); KR_TRY(dmalloc(&e->out, (size_t)capB * H * 4));
+    KR_TRY(dmalloc(&e->xf, capT * H * 4)); KR_TRY(dmalloc(&e->y, capT * H * 2)); KR_TRY(dmalloc(&e->out, (size_t)capB * H * 4));
     KR_TRY(dmalloc(&e->xb, capT * H * 2)); KR_TRY(dmalloc(&e->q, capT * H * 2)); KR_TRY(dmalloc(&e->k, capT * H * 2));
     e->ldv = capT + 64;   // slack: the last key tile of the last sequence may read up to 43 columns past T
     KR_TRY(dmalloc(&e->vT, (size_t)H * e->ldv * 2));
@@ -581,27 +588,25 @@ static int parse_name(const Encoder* e, const char* name, int& slot, int64_t& nu
 
 template <class Shape>
 static int launch_proj_shape(int epi, const ProjArgs& a, int num_cu, hipStream_t st) {
-    constexpr int lds = PROJ_STAGES * Shape::STAGE_BYTES;
+    constexpr int lds = PROJ_STAGES * Shape::STAGE_BYTES + Shape::NWAVE * EPI_STAGE_BYTES;   // 160 KiB for the 256x256 tile: the whole LDS of a CU
     const int blocks = num_cu * (Shape::NTHREADS == 256 ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_QKV, Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_RESID, Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_DENSE, Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_GELU, Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_vt<Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    if (epi == EPI_VT) hipLaunchKernelGGL((k_proj_vt<Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
-    else if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj<EPI_QKV, Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
-    else if (epi == EPI_RESID) hipLaunchKernelGGL((k_proj<EPI_RESID, Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj<EPI_QKV, Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    else if (epi == EPI_DENSE) hipLaunchKernelGGL((k_proj<EPI_DENSE, Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
     else hipLaunchKernelGGL((k_proj<EPI_GELU, Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
     return 0;
 }
 
-// shape choice per projection: env KIRAG_AMD_PROJ = 4 characters (q|k, v^T, dense->fp32, gelu), each 'b' (256x256) or 's' (128x128)
+// shape choice per projection: env KIRAG_AMD_PROJ = 3 characters (q|k|v, dense, gelu), each 'b' (256x256) or 's' (128x128)
 static int launch_proj(int epi, const ProjArgs& a, int num_cu, hipStream_t st) {
-    static const std::string cfg = [] { const char* e = getenv("KIRAG_AMD_PROJ"); return std::string(e && strlen(e) == 4 ? e : "bbbb"); }();
-    const int idx = epi == EPI_QKV ? 0 : epi == EPI_VT ? 1 : epi == EPI_RESID ? 2 : 3;
+    static const std::string cfg = [] { const char* e = getenv("KIRAG_AMD_PROJ"); return std::string(e && strlen(e) == 3 ? e : "bbb"); }();
+    const int idx = epi == EPI_QKV ? 0 : epi == EPI_DENSE ? 1 : 2;
     if (cfg[idx] == 's') return launch_proj_shape<ShapeSmall>(epi, a, num_cu, st);
     return launch_proj_shape<ShapeBig>(epi, a, num_cu, st);
 }
@@ -749,22 +754,20 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
     for (const LayerW& l : e->L) {
         ProjArgs a{};
         a.Tp = e->d_T; a.H = H;
-        // q | k | v^T
-        a.W = l.wqkv; a.X = e->xb; a.F = 2 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k;
+        // q | k | v^T in one GEMM (F = 3H)
+        a.W = l.wqkv; a.X = e->xb; a.F = 3 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k; a.outT = e->vT; a.ldT = e->ldv;
         KR_TRY(launch_proj(EPI_QKV, a, e->num_cu, st));
-        a.W = l.wqkv + (size_t)2 * H * H; a.F = H; a.bias = l.bqkv + 2 * H; a.outT = e->vT; a.ldT = e->ldv;
-        KR_TRY(launch_proj(EPI_VT, a, e->num_cu, st));
         hipLaunchKernelGGL(k_attn, attn_grid, dim3(256), 0, st, e->q, e->k, e->vT, e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, e->ctx);
         // attention.output.dense + residual -> LayerNorm
-        a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.outf = e->y;
-        KR_TRY(launch_proj(EPI_RESID, a, e->num_cu, st));
+        a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y;
+        KR_TRY(launch_proj(EPI_DENSE, a, e->num_cu, st));
         hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln1g, l.ln1b, eps, H, e->xf, e->xb);
         // intermediate.dense + GELU
         a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h;
         KR_TRY(launch_proj(EPI_GELU, a, e->num_cu, st));
         // output.dense + residual -> LayerNorm
-        a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.outf = e->y;
-        KR_TRY(launch_proj(EPI_RESID, a, e->num_cu, st));
+        a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->y;
+        KR_TRY(launch_proj(EPI_DENSE, a, e->num_cu, st));
         hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln2g, l.ln2b, eps, H, e->xf, e->xb);
     }
     hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xf, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);

@@ -444,11 +444,16 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
                         for (int ni = 0; ni < 2; ++ni) acc.v[mi][ni] = T::mfma(af[k2][mi], bf[k2][ni], acc.v[mi][ni]);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
+                // The barrier that ends an output tile's last M interval: group 0 passes it and then runs its epilogue, group 1
+                // (whose M interval is the one AFTER it) runs its epilogue first and only then arrives, so the two epilogues run
+                // side by side (VALU / LDS / store work of two waves per SIMD interleaves) instead of one after the other.
+                const bool last = (h == 1) && (kt == nk - 1);
+                if (!(last && grp)) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         epi(acc, m0, n0, nat);
+        if (grp) __builtin_amdgcn_s_barrier();
     }
     if (!grp) __builtin_amdgcn_s_barrier();   // group 0 started one interval early: same number of barriers for every wave
     wait_vmcnt<0>();                            // dummy tail DMAs must not land after the caller re-uses the ring
