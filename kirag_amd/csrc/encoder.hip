@@ -464,6 +464,174 @@ __global__ __launch_bounds__(256) void k_attn(const uint16_t* __restrict__ q, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// attention, LDS-staged: one block (4 waves) per (sequence, group of HPB heads).  K [keys][64] and V^T [64][keys] of
+// the block's heads are staged ONCE in LDS (every q-tile of the head re-reads them from there instead of from L2):
+//   K image   128-B rows, 16-B chunk index XOR ((key >> 1) & 7): the ds_read_b128 of an MFMA A fragment (lane -> key l&31,
+//             d-chunk 2s + (l>>5)) is bank-conflict free (same image as the GEMM ring);
+//   V^T image row pitch 2*cap + 8 bytes (pitch / 8 odd): the two ds_read_b64 of a P.V A fragment (lane -> d = l&31) hit 32
+//             distinct 8-B bank pairs; keys >= nk are stored as zero (no 0 * NaN from rows of other sequences).
+// Each wave takes (head, 32-query tile) items: S^T = K.Q^T (keys on accumulator rows, so the softmax row reductions are in-lane +
+// one shfl_xor 32), online softmax, P^T straight from the accumulator into the V^T.P^T MFMA with the matching permuted key order.
+// The O tile is staged through a wave-private 4-KiB LDS block and stored as whole 128-B rows of ctx.
+// HPB = heads per block: 1 when a sequence has >= 3 q-tiles, 2 / 4 for short sequences so that all four waves have work.
+// ---------------------------------------------------------------------------------------------------------
+template <int HPB>
+__global__ __launch_bounds__(256) void k_attn_lds(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vT, int64_t ldv,
+                                                  const int* __restrict__ seq_off, const int* __restrict__ seq_nk, const int* __restrict__ seq_nq,
+                                                  int H, int heads, int cap, uint16_t* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hb = blockIdx.x, b = blockIdx.y;            // heads fastest: the heads of one sequence (same 2-KiB q/k rows) run together
+    const int nq = seq_nq[b];
+    if (nq == 0) return;
+    const int nk = seq_nk[b];
+    const int64_t off = seq_off[b];
+    const int nkp = (nk + 31) & ~31;                      // <= cap
+    const int vpitch = cap * 2 + 8;
+    char* Ks = smem;                                      // [HPB][cap][128 B]
+    char* Vs = smem + (size_t)HPB * cap * 128;            // [HPB][64][vpitch]
+    char* Os = Vs + (size_t)HPB * 64 * vpitch + wave * 4096;
+    // staging: every global load of a batch is issued before the first LDS store (a load -> store loop would serialise one memory
+    // round trip per iteration)
+    constexpr int NB = 8;
+    const int cpr = nkp >> 2;                             // 8-byte chunks (4 keys) per V^T row
+#pragma unroll
+    for (int hs = 0; hs < HPB; ++hs) {
+        const int head = hb * HPB + hs;
+        if (head >= heads) break;
+        char* Kh = Ks + (size_t)hs * cap * 128;
+        char* Vh = Vs + (size_t)hs * 64 * vpitch;
+        const int nkc = nkp * 8, nvc = 64 * cpr;
+        for (int base = 0; base < nkc || base < nvc; base += 256 * NB) {
+            uint4 kv[NB]; uint2 vv[NB]; int vd[NB], vk[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int i = base + j * 256 + tid;
+                const int key = i >> 3, ch = i & 7;
+                kv[j] = make_uint4(0u, 0u, 0u, 0u);
+                if (i < nkc && key < nk) kv[j] = *reinterpret_cast<const uint4*>(k + (off + key) * H + head * 64 + ch * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int i = base + j * 256 + tid;
+                const int d = i / cpr, kc = i - d * cpr;
+                vd[j] = d; vk[j] = kc;
+                vv[j] = make_uint2(0u, 0u);
+                if (i < nvc && kc * 4 < nk) vv[j] = *reinterpret_cast<const uint2*>(vT + (int64_t)(head * 64 + d) * ldv + off + kc * 4);   // off % 4 == 0: 8-B aligned
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int i = base + j * 256 + tid;
+                const int key = i >> 3, ch = i & 7;
+                if (i < nkc) *reinterpret_cast<uint4*>(Kh + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kv[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int i = base + j * 256 + tid;
+                const int key0 = vk[j] * 4;
+                uint2 v = vv[j];
+                if (key0 + 4 > nk) {      // keys >= nk (padding / the next sequence) are stored as zero
+                    v.x &= (key0 + 0 < nk ? 0xffffu : 0u) | (key0 + 1 < nk ? 0xffff0000u : 0u);
+                    v.y &= (key0 + 2 < nk ? 0xffffu : 0u) | (key0 + 3 < nk ? 0xffff0000u : 0u);
+                }
+                if (i < nvc) *reinterpret_cast<uint2*>(Vh + vd[j] * vpitch + vk[j] * 8) = v;
+            }
+        }
+    }
+    __syncthreads();
+    const int hs = wave % HPB;
+    const int head = hb * HPB + hs;
+    if (head >= heads) return;
+    const char* Kh = Ks + (size_t)hs * cap * 128;
+    const char* Vh = Vs + (size_t)hs * 64 * vpitch;
+    const int c = lane & 31, hf = lane >> 5;
+    const float LOG2E = 1.4426950408889634f;
+    for (int q0 = (wave / HPB) * 32; q0 < nq; q0 += (4 / HPB) * 32) {
+        // Q^T as the B operand: lane (c, hf) holds Q[q0 + c][16 s + 8 hf .. +7], s = 0..3
+        uint4 qf[4];
+        {
+            const int qi = (q0 + c < nq) ? (q0 + c) : (nq - 1);
+            const uint16_t* qrow = q + (off + qi) * H + head * 64;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(qrow + 16 * s + 8 * hf);
+        }
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+        float m = -INFINITY, l = 0.f;
+        for (int k0 = 0; k0 < nk; k0 += 32) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            {
+                const int key = k0 + c;
+                const char* krow = Kh + key * 128;
+                const int swz = (key >> 1) & 7;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint4 kf = *reinterpret_cast<const uint4*>(krow + (((2 * s + hf) ^ swz) << 4));
+                    st = BF16::mfma(kf, qf[s], st);
+                }
+            }
+            // register r of this lane is key k0 + (r&3) + 8 (r>>2) + 4 hf, query q0 + c
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                st[r] = (key < nk) ? st[r] : -INFINITY;
+                tmax = fmaxf(tmax, st[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mnew = fmaxf(m, tmax);
+            const float mref = (mnew == -INFINITY) ? 0.f : mnew;
+            const float alpha = exp2f((m - mref) * LOG2E);
+            float psum = 0.f;
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = exp2f((st[r] - mref) * LOG2E); psum += p[r]; }
+            psum += __shfl_xor(psum, 32, 64);
+            l = l * alpha + psum;
+            m = mnew;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            // O^T += V^T . P^T : P^T from the accumulator (k-step s2 = registers 8 s2 .. 8 s2 + 7, element j = key 16 s2 + 8 (j>>2) + 4 hf + (j&3));
+            // the V^T fragment uses the same key order: elements 0..3 = keys kb .. kb+3, 4..7 = keys kb+8 .. kb+11, kb = k0 + 16 s2 + 4 hf
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint4 pf;
+                pf.x = pack_bf16x2(p[8 * s2 + 0], p[8 * s2 + 1]); pf.y = pack_bf16x2(p[8 * s2 + 2], p[8 * s2 + 3]);
+                pf.z = pack_bf16x2(p[8 * s2 + 4], p[8 * s2 + 5]); pf.w = pack_bf16x2(p[8 * s2 + 6], p[8 * s2 + 7]);
+                const int kb = k0 + 16 * s2 + 4 * hf;
+                const char* v0 = Vh + c * vpitch + kb * 2;
+                const char* v1 = v0 + 32 * vpitch;
+                const uint2 a0 = *reinterpret_cast<const uint2*>(v0), a1 = *reinterpret_cast<const uint2*>(v0 + 16);
+                const uint2 b0 = *reinterpret_cast<const uint2*>(v1), b1 = *reinterpret_cast<const uint2*>(v1 + 16);
+                o0 = BF16::mfma(make_uint4(a0.x, a0.y, a1.x, a1.y), pf, o0);
+                o1 = BF16::mfma(make_uint4(b0.x, b0.y, b1.x, b1.y), pf, o1);
+            }
+        }
+        // a query with no attendable key (all-masked sequence) is 0/0 = NaN, as under HF's -inf masking
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            uint2 w0, w1;
+            w0.x = pack_bf16x2(o0[4 * gq + 0] * inv, o0[4 * gq + 1] * inv); w0.y = pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
+            w1.x = pack_bf16x2(o1[4 * gq + 0] * inv, o1[4 * gq + 1] * inv); w1.y = pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
+            const int j8 = 2 * gq + hf;     // 8-byte chunk (4 features) of the 128-B row of query c
+            *reinterpret_cast<uint2*>(Os + c * 128 + ((j8 ^ (c & 15)) << 3)) = w0;
+            *reinterpret_cast<uint2*>(Os + c * 128 + (((8 + j8) ^ (c & 15)) << 3)) = w1;
+        }
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {
+            const int rq = p4 * 8 + (lane >> 3), ch = lane & 7;
+            const uint2 lo = *reinterpret_cast<const uint2*>(Os + rq * 128 + (((2 * ch) ^ (rq & 15)) << 3));
+            const uint2 hi = *reinterpret_cast<const uint2*>(Os + rq * 128 + (((2 * ch + 1) ^ (rq & 15)) << 3));
+            if (q0 + rq < nq) *reinterpret_cast<uint4*>(ctx + (off + q0 + rq) * H + head * 64 + ch * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    }
+}
+
 // pooling + L2 normalisation: one block per sequence
 __global__ __launch_bounds__(256) void k_pool(const float* __restrict__ xf, const int* __restrict__ seq_off, const int* __restrict__ seq_nk,
                                               const int* __restrict__ seq_cls, int H, int pool, float* __restrict__ out) {
@@ -584,6 +752,20 @@ static int parse_name(const Encoder* e, const char* name, int& slot, int64_t& nu
         if (r == "LayerNorm.bias") { slot = T_ELNB; numel = H; return 0; }
     }
     return fail(KR_EINVAL, "unknown tensor name '%s'", name);
+}
+
+template <int HPB>
+static int launch_attn(const Encoder* e, int B, int cap, hipStream_t st) {
+    const int H = e->cfg.hidden, heads = e->cfg.heads;
+    const int lds = HPB * (cap * 128 + 64 * (cap * 2 + 8)) + 4 * 4096;
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_lds<HPB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL((k_attn_lds<HPB>), dim3((unsigned)((heads + HPB - 1) / HPB), (unsigned)B), dim3(256), lds, st, e->q, e->k, e->vT, e->ldv,
+                       e->seq_off, e->seq_nk, e->seq_nq, H, heads, cap, e->ctx);
+    return 0;
 }
 
 template <class Shape>
@@ -751,13 +933,22 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->xf, e->xb);
     const dim3 attn_grid((unsigned)((S + 1 + 31) / 32), (unsigned)((heads + 3) / 4), (unsigned)B);
+    static const bool attn_old = [] { const char* v = getenv("KIRAG_AMD_ATTN_OLD"); return v && v[0] == '1'; }();
     for (const LayerW& l : e->L) {
         ProjArgs a{};
         a.Tp = e->d_T; a.H = H;
         // q | k | v^T in one GEMM (F = 3H)
         a.W = l.wqkv; a.X = e->xb; a.F = 3 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k; a.outT = e->vT; a.ldT = e->ldv;
         KR_TRY(launch_proj(EPI_QKV, a, e->num_cu, st));
-        hipLaunchKernelGGL(k_attn, attn_grid, dim3(256), 0, st, e->q, e->k, e->vT, e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, e->ctx);
+        if (attn_old) {
+            hipLaunchKernelGGL(k_attn, attn_grid, dim3(256), 0, st, e->q, e->k, e->vT, e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, e->ctx);
+        } else {
+            const int cap = (int)round_up(S, 32);
+            const int nqt = (S + (pool == KR_POOL_CLS ? 1 : 0) + 31) / 32;      // q-tiles of the longest possible sequence
+            if (nqt >= 3) KR_TRY(launch_attn<1>(e, B, cap, st));
+            else if (nqt == 2) KR_TRY(launch_attn<2>(e, B, cap, st));
+            else KR_TRY(launch_attn<4>(e, B, cap, st));
+        }
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y;
         KR_TRY(launch_proj(EPI_DENSE, a, e->num_cu, st));
