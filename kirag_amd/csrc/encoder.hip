@@ -24,15 +24,14 @@
 namespace kr {
 
 using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LDS, one block per CU: best main loop (long-K GEMMs)
-using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB LDS, two blocks per CU: one block's epilogue hides under the other's MFMAs
 constexpr int PROJ_STAGES = 2;
 
-// main loop per tile shape: the 256x256 tile runs the ping-pong schedule, the 128x128 tile the v2 streaming loop
+// the projections run the ping-pong main loop with exchanged MFMA operands (accumulators hold 4 consecutive features per lane)
 template <class ShapeE, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_main(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb, int64_t N,
                                           int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
-    if constexpr (ShapeE::BM == 256 && ShapeE::BN == 256) gemm_nt_pingpong<BF16>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
-    else gemm_nt_stream<BF16, ShapeE, PROJ_STAGES>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
+    static_assert(ShapeE::BM == 256 && ShapeE::BN == 256, "projections use the 256x256 ping-pong tile");
+    gemm_nt_pingpong<BF16, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
 }
 
 struct LayerW {
@@ -266,53 +265,53 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return (ui
 //          read back 16 B per lane: a store instruction writes 64-B runs of sixteen V^T rows.
 constexpr int EPI_STAGE_BYTES = 4096;
 
+// Both helpers take the SWAPPED accumulator layout of gemm_nt_pingpong<.., true> / gemm_nt_stream_swapped: tile (mi, ni), register r,
+// lane (c = l & 31, h = l >> 5) is token mi*32 + c, feature ni*32 + (r & 3) + 8 (r >> 2) + 4 h of the wave's (TM*32 tokens) x (TN*32 features).
+//
+// rows: for one mi the wave's 32 tokens x 64 features are staged as bf16 [32 tokens][128 B]; registers 4g .. 4g+3 of a lane are 4
+// consecutive features -> one packed ds_write_b64 (16-B chunk index XOR (token & 7): 2-way instead of 16-way conflicts), read back 16 B
+// per lane: every global store instruction writes eight whole 128-B rows.  f(v, ni, g) maps 4 features (bias / GELU) before packing.
 template <class Shape, class F>
-__device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ out, int64_t ld, int64_t row0, int col0,
-                                                int ncols, F&& f) {
+__device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ out, int64_t ld, int64_t row0, int col0, F&& f) {
+    static_assert(Shape::TN == 2, "stage geometry assumes 64 features per wave");
     const int c = acc.lane & 31, h = acc.lane >> 5;
 #pragma unroll
     for (int mi = 0; mi < Shape::TM; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < Shape::TN; ++ni)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 v = f(f32x2{acc.v[mi][ni][r], acc.v[mi][ni][r + 1]}, ni);
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;     // r even: rows rl and rl + 1
-                *reinterpret_cast<uint16_t*>(stage + rl * (Shape::TN * 64) + (ni * 32 + c) * 2) = BF16::from_f32(v.x);
-                *reinterpret_cast<uint16_t*>(stage + (rl + 1) * (Shape::TN * 64) + (ni * 32 + c) * 2) = BF16::from_f32(v.y);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = f(f32x4{acc.v[mi][ni][4 * g], acc.v[mi][ni][4 * g + 1], acc.v[mi][ni][4 * g + 2], acc.v[mi][ni][4 * g + 3]}, ni, g);
+                uint2 w;
+                w.x = pack_bf16x2(v.x, v.y); w.y = pack_bf16x2(v.z, v.w);
+                *reinterpret_cast<uint2*>(stage + c * 128 + (((ni * 4 + g) ^ (c & 7)) << 4) + h * 8) = w;
             }
-        constexpr int LPR = Shape::TN * 4;           // lanes per row (16 B each)
-        constexpr int RPI = 64 / LPR;                // rows per store instruction
 #pragma unroll
-        for (int p = 0; p < 32 / RPI; ++p) {
-            const int rl = p * RPI + acc.lane / LPR, ch = acc.lane % LPR;
-            const uint4 d = *reinterpret_cast<const uint4*>(stage + rl * (Shape::TN * 64) + ch * 16);
-            if (col0 + ch * 8 < ncols) *reinterpret_cast<uint4*>(out + (row0 + mi * 32 + rl) * ld + col0 + ch * 8) = d;
+        for (int p = 0; p < 4; ++p) {
+            const int rl = p * 8 + (acc.lane >> 3), ch = acc.lane & 7;
+            const uint4 d = *reinterpret_cast<const uint4*>(stage + rl * 128 + ((ch ^ (rl & 7)) << 4));
+            *reinterpret_cast<uint4*>(out + (row0 + mi * 32 + rl) * ld + col0 + ch * 8) = d;
         }
     }
 }
 
-// V^T[feature, token] from the same accumulator block: features f0 .. f0+TN*32 (valid below nf), tokens t0 .. t0+TM*32
+// V^T[feature, token]: each 32x32 tile is staged as [32 features][32 tokens] (80-B rows), lanes = consecutive tokens of a feature row,
+// read back 16 B per lane: a store instruction writes 64-B runs of sixteen V^T rows.
 template <class Shape>
-__device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ outT, int64_t ldT, int64_t t0, int f0, int nf) {
+__device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ outT, int64_t ldT, int64_t t0, int f0) {
     const int c = acc.lane & 31, h = acc.lane >> 5;
 #pragma unroll
     for (int mi = 0; mi < Shape::TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < Shape::TN; ++ni) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 w;
-                w.x = pack_bf16x2(acc.v[mi][ni][4 * g + 0], acc.v[mi][ni][4 * g + 1]);
-                w.y = pack_bf16x2(acc.v[mi][ni][4 * g + 2], acc.v[mi][ni][4 * g + 3]);
-                *reinterpret_cast<uint2*>(stage + c * 80 + (8 * g + 4 * h) * 2) = w;    // tokens 8g+4h .. +3 of feature c
-            }
+            for (int r = 0; r < 16; ++r)
+                *reinterpret_cast<uint16_t*>(stage + ((r & 3) + 8 * (r >> 2) + 4 * h) * 80 + c * 2) = BF16::from_f32(acc.v[mi][ni][r]);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int fl = p * 16 + (acc.lane >> 2), ch = acc.lane & 3;
                 const uint4 d = *reinterpret_cast<const uint4*>(stage + fl * 80 + ch * 16);
-                const int f = f0 + ni * 32 + fl;
-                if (f < nf) *reinterpret_cast<uint4*>(outT + (int64_t)f * ldT + t0 + mi * 32 + ch * 8) = d;
+                *reinterpret_cast<uint4*>(outT + (int64_t)(f0 + ni * 32 + fl) * ldT + t0 + mi * 32 + ch * 8) = d;
             }
         }
 }
@@ -339,23 +338,30 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
         },
         [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) {
             const int64_t t0 = m0 + acc.m_wave;
-            const int f0 = (int)n0 + acc.n_wave;          // first feature of this wave's 64 (TN*32) columns
+            const int f0 = (int)n0 + acc.n_wave;          // first feature of this wave's 64 columns; F % 64 == 0, so a wave is never partial
             if (f0 >= a.F) return;
-            float b[ShapeE::TN];
+            const int h = acc.lane >> 5;
+            f32x4 b[2][4];                                // bias of the lane's 32 features: (ni, g) -> features ni*32 + 8g + 4h .. +3
 #pragma unroll
-            for (int ni = 0; ni < ShapeE::TN; ++ni) { const int f = f0 + ni * 32 + (acc.lane & 31); b[ni] = (f < a.F) ? a.bias[f] : 0.f; }
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b[ni][g] = *reinterpret_cast<const f32x4*>(a.bias + f0 + ni * 32 + 8 * g + 4 * h);
             if constexpr (EPI == EPI_QKV) {
-                const int region = f0 / a.H;              // H % 64 == 0 (TN*32 | H): a wave's columns never straddle q | k | v
+                const int region = f0 / a.H;              // H % 64 == 0: a wave's columns never straddle q | k | v
                 if (region == 2) {
-                    store_transposed_bf16<ShapeE>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H, a.H);
+                    store_transposed_bf16<ShapeE>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H);   // value bias lives in bo_eff
                 } else {
-                    store_rows_bf16<ShapeE>(acc, stage, region ? a.out1 : a.out0, a.H, t0, f0 - region * a.H, a.H,
-                                            [&](f32x2 v, int ni) { return v + b[ni]; });
+                    store_rows_bf16<ShapeE>(acc, stage, region ? a.out1 : a.out0, a.H, t0, f0 - region * a.H,
+                                            [&](f32x4 v, int ni, int g) { return v + b[ni][g]; });
                 }
             } else if constexpr (EPI == EPI_DENSE) {
-                store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, a.F, [&](f32x2 v, int ni) { return v + b[ni]; });
+                store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int ni, int g) { return v + b[ni][g]; });
             } else {
-                store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, a.F, [&](f32x2 v, int ni) { return gelu_erf_fast2(v + b[ni]); });
+                store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int ni, int g) {
+                    const f32x4 x = v + b[ni][g];
+                    const f32x2 lo = gelu_erf_fast2(f32x2{x.x, x.y}), hi = gelu_erf_fast2(f32x2{x.z, x.w});
+                    return f32x4{lo.x, lo.y, hi.x, hi.y};
+                });
             }
         });
 }
@@ -785,13 +791,7 @@ static int launch_proj_shape(int epi, const ProjArgs& a, int num_cu, hipStream_t
     return 0;
 }
 
-// shape choice per projection: env KIRAG_AMD_PROJ = 3 characters (q|k|v, dense, gelu), each 'b' (256x256) or 's' (128x128)
-static int launch_proj(int epi, const ProjArgs& a, int num_cu, hipStream_t st) {
-    static const std::string cfg = [] { const char* e = getenv("KIRAG_AMD_PROJ"); return std::string(e && strlen(e) == 3 ? e : "bbb"); }();
-    const int idx = epi == EPI_QKV ? 0 : epi == EPI_DENSE ? 1 : 2;
-    if (cfg[idx] == 's') return launch_proj_shape<ShapeSmall>(epi, a, num_cu, st);
-    return launch_proj_shape<ShapeBig>(epi, a, num_cu, st);
-}
+static int launch_proj(int epi, const ProjArgs& a, int num_cu, hipStream_t st) { return launch_proj_shape<ShapeBig>(epi, a, num_cu, st); }
 
 }  // namespace kr
 

@@ -318,12 +318,15 @@ __device__ __forceinline__ void gemm_nt_stream(const uint16_t* __restrict__ A, i
 //   A rows 0..127   read by group 0 in 4t-1, 4t+1     re-staged (tile t+2) by group 1 in 4t+2
 //   A rows 128..255 read by group 1 in 4t,   4t+2     re-staged by group 0 in 4t+5
 //   B               read by both in 4t-1 .. 4t+2      re-staged by group 0 in 4t+3 (rows 0..127), group 1 in 4t+4
+// SWAP = true multiplies B.A^T instead (operands exchanged in the MFMA): accumulator tile (mi, ni) then holds the TRANSPOSED 32x32 block,
+// element (register r, lane l) = C[m_wave + mi*32 + (l & 31)][n_wave + ni*32 + (r & 3) + 8 (r >> 2) + 4 (l >> 5)]: a lane owns 4 consecutive
+// columns of one row, which is what a row-major 16-bit epilogue wants (packed 8-byte LDS-stage writes).
 // The K-tile stream runs across output tiles (persistent blocks, as v2); past the end of the stream the DMA cursors stay
 // on the last K-tile (dummy re-loads into regions nobody reads any more) so that the vmcnt arithmetic never changes.
 // =====================================================================================================================
 using ShapePP = GemmShape<256, 256, 2, 4>;
 
-template <class T, class Coord, class Epilogue>
+template <class T, bool SWAP = false, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb,
                                                  int64_t N, int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
     using Shape = ShapePP;
@@ -441,7 +444,8 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) acc.v[mi][ni] = T::mfma(af[k2][mi], bf[k2][ni], acc.v[mi][ni]);
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc.v[mi][ni] = SWAP ? T::mfma(bf[k2][ni], af[k2][mi], acc.v[mi][ni]) : T::mfma(af[k2][mi], bf[k2][ni], acc.v[mi][ni]);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 // The barrier that ends an output tile's last M interval: group 0 passes it and then runs its epilogue, group 1

@@ -103,6 +103,66 @@ __global__ __launch_bounds__(Shape::NTHREADS, (Shape::NTHREADS / 256)) void k_st
     if (threadIdx.x == 0) out[2 + (blockIdx.x & 7)] = (float)*lcnt;
 }
 
+
+// ---- epilogue cost ablation on the ping-pong loop: MODE 0 = nothing, 1 = bias + bf16 through the wave-private LDS stage + 16-B global stores
+// (what k_proj<EPI_DENSE> does), 2 = the same without the global stores, 3 = direct 2-byte global stores (no stage)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_pp_epi(const uint16_t* A, const uint16_t* B, float* out, uint16_t* C, const float* bias, int64_t M, int64_t N, int K, int do_store) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Shape = ShapePP;
+    const int64_t tm_count = M / Shape::BM, tn_count = N / Shape::BN;
+    char* stage = smem + 2 * Shape::STAGE_BYTES + (threadIdx.x >> 6) * 4096;
+    gemm_nt_pingpong<BF16>(
+        A, K, M, B, K, N, K, tm_count * tn_count, smem,
+        [&](int64_t nat, int64_t& m0, int64_t& n0) { int64_t tm, tn; patch_coord(nat, tm_count, tn_count, tm, tn); m0 = tm * Shape::BM; n0 = tn * Shape::BN; },
+        [&](AccTile<Shape>& acc, int64_t m0, int64_t n0, int64_t) {
+            if constexpr (MODE == 0) {
+                float s = 0.f;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s += acc.v[mi][ni][r];
+                if (s == 12345.678f) out[0] = s;
+            } else if constexpr (MODE == 3) {
+                const int64_t t0 = m0 + acc.m_wave + 4 * (acc.lane >> 5);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int f = (int)n0 + acc.col(ni);
+                    const float b = bias[f];
+                    uint16_t* dst = C + t0 * N + f;
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dst[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * N] = BF16::from_f32(acc.v[mi][ni][r] + b);
+                }
+            } else {
+                const int c = acc.lane & 31, h = acc.lane >> 5;
+                const int64_t row0 = m0 + acc.m_wave; const int col0 = (int)n0 + acc.n_wave;
+                float b[2] = {bias[col0 + c], bias[col0 + 32 + c]};
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+                            *reinterpret_cast<uint16_t*>(stage + rl * 128 + (ni * 32 + c) * 2) = BF16::from_f32(acc.v[mi][ni][r] + b[ni]);
+                        }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int rl = p * 8 + (acc.lane >> 3), ch = acc.lane & 7;
+                        const uint4 d = *reinterpret_cast<const uint4*>(stage + rl * 128 + ch * 16);
+                        if (MODE == 1 || do_store) *reinterpret_cast<uint4*>(C + (row0 + mi * 32 + rl) * N + col0 + ch * 8) = d;
+                        else if (d.x == 0x12345678u) out[3] = 1.f;
+                    }
+                }
+            }
+        });
+}
+
 template <class Shape>
 __global__ __launch_bounds__(Shape::NTHREADS, 2) void k_block(const uint16_t* A, const uint16_t* B, float* out, int64_t M, int64_t N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -231,6 +291,21 @@ int main(int argc, char** argv) {
         }
         run("pingpong 256x256 grid 256 (no sums)", [&] { hipLaunchKernelGGL(k_pp, dim3(256), dim3(512), lds, 0, A, B, out, (float*)nullptr, M, N, K); });
         run("stream 256x256 stages 2 (no sums)", [&] { hipLaunchKernelGGL((k_stream<S, 2>), dim3(256), dim3(512), lds, 0, A, B, out, (float*)nullptr, M, N, K); });
+        {
+            uint16_t* C; float* bias; CK(hipMalloc(&C, (size_t)M * N * 2)); CK(hipMalloc(&bias, N * 4)); CK(hipMemset(bias, 0, N * 4));
+            const int lds2 = lds + 8 * 4096;
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pp_epi<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pp_epi<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pp_epi<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pp_epi<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+            for (int rep = 0; rep < 2; ++rep) {
+                run("pp epilogue: none", [&] { hipLaunchKernelGGL(k_pp_epi<0>, dim3(256), dim3(512), lds2, 0, A, B, out, C, bias, M, N, K, 0); });
+                run("pp epilogue: LDS stage, no global store", [&] { hipLaunchKernelGGL(k_pp_epi<2>, dim3(256), dim3(512), lds2, 0, A, B, out, C, bias, M, N, K, 0); });
+                run("pp epilogue: LDS stage + 16-B stores", [&] { hipLaunchKernelGGL(k_pp_epi<1>, dim3(256), dim3(512), lds2, 0, A, B, out, C, bias, M, N, K, 1); });
+                run("pp epilogue: direct 2-B stores", [&] { hipLaunchKernelGGL(k_pp_epi<3>, dim3(256), dim3(512), lds2, 0, A, B, out, C, bias, M, N, K, 1); });
+            }
+            CK(hipFree(C)); CK(hipFree(bias));
+        }
         if (getenv("PP_ONLY")) return 0;
     }
     FILTER(256, 256, 2, 4, 2, 1e30f)
