@@ -172,6 +172,17 @@ def main():
 
     if rank == 0:
         st = index.stats()
+        # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the figure comes from the
+        # committed rocprofv3 --pmc passes of this same workload (tools/profile_round.sh -> profiles/rNN/traffic.json), newest round.
+        traffic, traffic_src = None, None
+        if (n, d, nq, k) == (1_000_000, 1024, 1000, 100) and args.coarse_dtype == "bf16":
+            import glob
+            cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "traffic.json")))
+            if cands:
+                with open(cands[-1]) as f:
+                    tj = json.load(f)
+                traffic = tj["hbm_bytes_per_scan"] / 1e9
+                traffic_src = os.path.relpath(cands[-1], REPO)
         ms_step = dt / args.steps * 1e3
         coarse = float(np.mean(coarse_ms)) * 1e-3           # seconds per coarse scan (sum of its round launches)
         flops = 2.0 * nq * n * d                             # algorithmic: every query against every row of the shard
@@ -187,10 +198,12 @@ def main():
                        "encoder_in_step": encoder is not None,
                        "parallelism": f"row-sharded x{world}, all-gather top-k + host merge"},
             "roofline": {"bound": "mfma", "achieved": flops / coarse / 1e12, "peak": PEAK_MFMA_DENSE_16BIT / 1e12, "unit": "TFLOP/s",
-                         "frac": flops / coarse / PEAK_MFMA_DENSE_16BIT, "traffic": None, "kernel": "k_coarse",
+                         "frac": flops / coarse / PEAK_MFMA_DENSE_16BIT, "traffic": traffic, "traffic_unit": "GB per scan (FETCH_SIZE x2 + WRITE_SIZE)",
+                         "traffic_source": traffic_src, "algorithmic_gb": n * d * 2 / 1e9, "kernel": "k_coarse",
                          "launch_ms": coarse * 1e3,
-                         "note": "one 'launch' = one coarse scan of the shard = the sum of its 3-5 k_coarse round launches; "
-                                 "algorithmic FLOPs = 2*nq*rows*dim"},
+                         "note": "one 'launch' = one coarse scan of the shard = the sum of its k_coarse round launches (3 at 1M rows), HIP events "
+                                 "around each launch on its stream; algorithmic FLOPs = 2*nq*rows*dim; the bf16 MFMA-only loop measured on this "
+                                 "device sustains ~1.6-1.7 PFLOP/s on random data (tools/gemm_bench.hip)"},
             "encode": enc_info,
             "search_stats": {kk: st[kk] for kk in ("queries", "certified", "fallback", "overflow", "reranked_rows", "coarse_rounds")},
         }
