@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Headline benchmark of the dense-retrieval hot path on MI355X (BASELINE.json metric).
+"""Headline benchmark of the dense-retrieval hot path on MI355X (BASELINE.json metric: queries/sec + passages-encoded/sec,
+e5-large-v2 shape, 5M-doc corpus, top-100).
 
 One "step" = one pass of the hot path over one batch of synthetic input:
-    encode a 1k-query batch (32 tokens each) with the BERT-large-shape encoder  +  exact top-100 search of
-    those 1k query vectors over the GPU-resident corpus shard (BASELINE config 2: 1M x 1024 per GPU).
+    encode a 1k-query batch (32 tokens each) with the BERT-large-shape encoder  +  exact top-100 search of those 1k query
+    vectors over the GPU-resident 5M x 1024 corpus (bf16 scan copy + fp32 master rows).
 Inputs (token ids, corpus embeddings, weights) are resident in HBM before the timed region.
-With --gpus N every rank owns a 1M-row shard (weak scaling: 1M rows per GPU), searches the same query batch,
-and the per-shard top-100 are all-gathered over RCCL and merged.
+With --gpus N the SAME job is split over the ranks (strong scaling, SURVEY.md 8e / BASELINE.md 4): the corpus is row-sharded
+(5M / N rows per GPU), every rank encodes its 1/N slice of the query batch, the query embeddings are all-gathered (RCCL, nq*4 KiB),
+every rank searches all queries on its shard, and the per-shard top-100 are all-gathered and merged on the host.
 
 Prints ONE JSON line on rank 0 (see the round brief for the contract) including
     "roofline"      for the dominant kernel (the MFMA coarse scan k_coarse), timed live with HIP events
@@ -33,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--total-rows", type=int, default=5_000_000, help="corpus rows of the whole job (sharded over the ranks)")
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--dim", type=int, default=1024)
@@ -53,7 +55,7 @@ def cpu_baseline(args, q_host, with_encoder):
     blocks as retriever/index.py:39-47) on a bounded row sample of the same synthetic corpus, scaled linearly."""
     import torch
     from oracle import search_np as S
-    rows = min(args.cpu_sample_rows, args.rows_per_gpu)
+    rows = min(args.cpu_sample_rows, args.total_rows)
     rng = np.random.Generator(np.random.PCG64(3))
     xs = rng.standard_normal((rows, args.dim), dtype=np.float32)
     xs /= np.linalg.norm(xs, axis=1, keepdims=True)
@@ -61,12 +63,12 @@ def cpu_baseline(args, q_host, with_encoder):
     t0 = time.perf_counter()
     S.search_sgemm(q_host, xs, args.topk)
     dt = time.perf_counter() - t0
-    scale = args.rows_per_gpu / rows
+    scale = args.total_rows / rows
     search_qps = len(q_host) / (dt * scale)
     out = {"unit": "queries/s", "cores": int(torch.get_num_threads()), "kind": "port", "nproc": os.cpu_count(),
            "search_only_qps": search_qps,
-           "sample": f"search: {len(q_host)} queries x {rows} of {args.rows_per_gpu} rows fp32 sgemm+argpartition top-{args.topk}, "
-                     f"{dt:.2f}s measured, time scaled x{scale:.0f} to the full shard"}
+           "sample": f"search: {len(q_host)} queries x {rows} of {args.total_rows} rows fp32 sgemm+argpartition top-{args.topk}, "
+                     f"{dt:.2f}s measured, time scaled x{scale:.0f} to the full corpus"}
     if with_encoder:
         from oracle import encoder_torch as ET
         enc_qps, enc_dt = ET.time_encode(args.cpu_sample_queries, args.query_tokens, batch=8)
@@ -99,11 +101,15 @@ def main():
     from kirag_amd.retriever.index import FlatIPIndex
     from kirag_amd.parallel import ShardedSearcher
 
-    n, d, nq, k = args.rows_per_gpu, args.dim, args.queries, args.topk
+    total, d, nq, k = args.total_rows, args.dim, args.queries, args.topk
+    per = (total + world - 1) // world                      # contiguous row shards
+    row0 = min(rank * per, total)
+    n = min(per, total - row0)                              # rows resident on this rank
     g = torch.Generator(device=dev); g.manual_seed(3 + rank)
     index = FlatIPIndex(d, device=local_rank, coarse_dtype=args.coarse_dtype)
     index.reserve(n)
     chunk = 250_000
+    head = None
     for s0 in range(0, n, chunk):            # synthetic unit-norm corpus rows, generated on the device
         m = min(chunk, n - s0)
         x = torch.nn.functional.normalize(torch.randn(m, d, generator=g, device=dev), dim=1)
@@ -118,15 +124,28 @@ def main():
         dist.broadcast(q_vec, src=0)
 
     encoder = None
+    q_lo, q_hi = (rank * nq) // world, ((rank + 1) * nq) // world      # this rank's slice of the query batch
     if not args.no_encoder:
         from kirag_amd import bench_support as BS
         encoder = BS.make_hip_encoder(dev)
         tok_ids, tok_mask = BS.synthetic_tokens(dev, nq, args.query_tokens, seed=2)
         pas_ids, pas_mask = BS.synthetic_tokens(dev, args.passages, args.passage_tokens, seed=1)
-    searcher = ShardedSearcher(index, row_offset=rank * n, world=world)
+    searcher = ShardedSearcher(index, row_offset=row0, world=world)
+    q_all = torch.empty((nq, d), dtype=torch.float32, device=dev)
+    counts = [((r + 1) * nq) // world - (r * nq) // world for r in range(world)]
 
     def step():
-        qv = encoder.forward(tok_ids, tok_mask, 0) if encoder is not None else q_vec   # [nq, d] fp32 on the device
+        if encoder is None:
+            qv = q_vec
+        elif world == 1:
+            qv = encoder.forward(tok_ids, tok_mask, 0)                  # [nq, d] fp32 on the device
+        else:
+            mine = encoder.forward(tok_ids[q_lo:q_hi], tok_mask[q_lo:q_hi], 0)
+            if len(set(counts)) == 1:
+                dist.all_gather_into_tensor(q_all, mine)
+            else:
+                dist.all_gather(list(q_all.split(counts)), mine)
+            qv = q_all
         return searcher.search(qv, k)
 
     for _ in range(args.warmup):
@@ -175,33 +194,34 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the figure comes from the
         # committed rocprofv3 --pmc passes of this same workload (tools/profile_round.sh -> profiles/rNN/traffic.json), newest round.
         traffic, traffic_src = None, None
-        if (n, d, nq, k) == (1_000_000, 1024, 1000, 100) and args.coarse_dtype == "bf16":
-            import glob
-            cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "traffic.json")))
-            if cands:
-                with open(cands[-1]) as f:
-                    tj = json.load(f)
+        import glob
+        for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "traffic*.json")), reverse=True):
+            with open(cand) as f:
+                tj = json.load(f)
+            if (tj.get("rows"), tj.get("dim"), tj.get("queries"), tj.get("topk"), tj.get("coarse_dtype")) == (n, d, nq, k, args.coarse_dtype):
                 traffic = tj["hbm_bytes_per_scan"] / 1e9
-                traffic_src = os.path.relpath(cands[-1], REPO)
+                traffic_src = os.path.relpath(cand, REPO)
+                break
         ms_step = dt / args.steps * 1e3
         coarse = float(np.mean(coarse_ms)) * 1e-3           # seconds per coarse scan (sum of its round launches)
         flops = 2.0 * nq * n * d                             # algorithmic: every query against every row of the shard
         out = {
-            "metric": "queries/sec (encode + exact top-100 search), e5-large-v2 shape, 1M x 1024 corpus rows per GPU",
+            "metric": f"queries/sec (encode + exact top-{k} search), e5-large-v2 shape, {total / 1e6:g}M x {d} corpus",
             "value": nq * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": args.coarse_dtype + " MFMA coarse scan / fp64 exact re-rank",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: {n}x{d} {args.coarse_dtype}+fp32 corpus per GPU in HBM, {nq}-query batch "
-                                   f"({args.query_tokens} tokens), brute-force top-{k}",
-                       "rows_per_gpu": n, "dim": d, "queries": nq, "topk": k, "total_rows": n * world,
+            "config": {"workload": f"BASELINE metric config: {total}x{d} {args.coarse_dtype}+fp32 corpus resident in HBM (row-sharded over "
+                                   f"{world} GPU(s)), {nq}-query batch ({args.query_tokens} tokens) encoded then searched, brute-force top-{k}",
+                       "rows_per_gpu": n, "dim": d, "queries": nq, "topk": k, "total_rows": total,
                        "encoder_in_step": encoder is not None,
-                       "parallelism": f"row-sharded x{world}, all-gather top-k + host merge"},
+                       "parallelism": f"corpus row-sharded x{world}, query batch split x{world} for encoding, all-gather of query vectors and of "
+                                      f"per-shard top-k, host merge"},
             "roofline": {"bound": "mfma", "achieved": flops / coarse / 1e12, "peak": PEAK_MFMA_DENSE_16BIT / 1e12, "unit": "TFLOP/s",
                          "frac": flops / coarse / PEAK_MFMA_DENSE_16BIT, "traffic": traffic, "traffic_unit": "GB per scan (FETCH_SIZE x2 + WRITE_SIZE)",
-                         "traffic_source": traffic_src, "algorithmic_gb": n * d * 2 / 1e9, "kernel": "k_coarse",
+                         "traffic_source": traffic_src, "algorithmic_gb": n * d * 2 / 1e9, "kernel": "k_coarse", "rows_scanned": n,
                          "launch_ms": coarse * 1e3,
-                         "note": "one 'launch' = one coarse scan of the shard = the sum of its k_coarse round launches (3 at 1M rows), HIP events "
+                         "note": "one 'launch' = one coarse scan of the shard = the sum of its k_coarse round launches (4 at 5M rows), HIP events "
                                  "around each launch on its stream; algorithmic FLOPs = 2*nq*rows*dim; the bf16 MFMA-only loop measured on this "
                                  "device sustains ~1.6-1.7 PFLOP/s on random data (tools/gemm_bench.hip)"},
             "encode": enc_info,

@@ -12,4 +12,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-encoder --no-cpu-baseline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-encoder --no-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 python3 $R/tools/pmc_summary.py $OUT > $OUT/search_pmc_fetch_write.json
+python3 $R/tools/pmc_summary.py $OUT --traffic 4 > $OUT/traffic.json
 echo "profile_round done: $OUT"
