@@ -26,12 +26,15 @@ namespace kr {
 using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LDS, one block per CU: best main loop (long-K GEMMs)
 constexpr int PROJ_STAGES = 2;
 
-// the projections run the ping-pong main loop with exchanged MFMA operands (accumulators hold 4 consecutive features per lane)
+using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB ring, two blocks per CU: for launches with too few 256x256 tiles to fill the chip
+
+// both main loops run with exchanged MFMA operands (accumulators hold 4 consecutive features per lane):
+// 256x256 tiles -> ping-pong loop; 128x128 tiles (small token counts: 4x the tiles, a quarter of the latency each) -> streaming loop
 template <class ShapeE, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_main(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb, int64_t N,
                                           int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
-    static_assert(ShapeE::BM == 256 && ShapeE::BN == 256, "projections use the 256x256 ping-pong tile");
-    gemm_nt_pingpong<BF16, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
+    if constexpr (ShapeE::BM == 256 && ShapeE::BN == 256) gemm_nt_pingpong<BF16, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
+    else gemm_nt_stream<BF16, ShapeE, PROJ_STAGES, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
 }
 
 struct LayerW {
@@ -791,7 +794,15 @@ static int launch_proj_shape(int epi, const ProjArgs& a, int num_cu, hipStream_t
     return 0;
 }
 
-static int launch_proj(int epi, const ProjArgs& a, int num_cu, hipStream_t st) { return launch_proj_shape<ShapeBig>(epi, a, num_cu, st); }
+// tile shape per launch: when the 256x256 tiling has fewer tiles than CUs (small batches: the reference's per_gpu_batch_size 4-8, the KiRAG
+// loop's triple batches, a 1/8 slice of a query batch) the 128x128 tiling gives 4x the parallelism at a quarter of the per-tile latency
+static int launch_proj(int epi, const ProjArgs& a, int64_t max_tokens, int num_cu, hipStream_t st) {
+    const int64_t big_tiles = ((max_tokens + 255) / 256) * ((a.F + 255) / 256);
+    static const int force = [] { const char* e = getenv("KIRAG_AMD_PROJ_TILE"); return e ? atoi(e) : 0; }();   // 128 / 256 for A/B tests
+    const bool small = force == 128 || (force != 256 && big_tiles < num_cu);
+    if (small) return launch_proj_shape<ShapeSmall>(epi, a, num_cu, st);
+    return launch_proj_shape<ShapeBig>(epi, a, num_cu, st);
+}
 
 }  // namespace kr
 
@@ -939,7 +950,7 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         a.Tp = e->d_T; a.H = H;
         // q | k | v^T in one GEMM (F = 3H)
         a.W = l.wqkv; a.X = e->xb; a.F = 3 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k; a.outT = e->vT; a.ldT = e->ldv;
-        KR_TRY(launch_proj(EPI_QKV, a, e->num_cu, st));
+        KR_TRY(launch_proj(EPI_QKV, a, maxT, e->num_cu, st));
         if (attn_old) {
             hipLaunchKernelGGL(k_attn, attn_grid, dim3(256), 0, st, e->q, e->k, e->vT, e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, e->ctx);
         } else {
@@ -951,14 +962,14 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         }
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y;
-        KR_TRY(launch_proj(EPI_DENSE, a, e->num_cu, st));
+        KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, st));
         hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln1g, l.ln1b, eps, H, e->xf, e->xb);
         // intermediate.dense + GELU
         a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h;
-        KR_TRY(launch_proj(EPI_GELU, a, e->num_cu, st));
+        KR_TRY(launch_proj(EPI_GELU, a, maxT, e->num_cu, st));
         // output.dense + residual -> LayerNorm
         a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->y;
-        KR_TRY(launch_proj(EPI_DENSE, a, e->num_cu, st));
+        KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, st));
         hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln2g, l.ln2b, eps, H, e->xf, e->xb);
     }
     hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xf, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);

@@ -183,7 +183,7 @@ __device__ __forceinline__ void patch_coord(int64_t n, int64_t tm_count, int64_t
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <class T, class Shape, int STAGES = 3, class Coord, class Epilogue>
+template <class T, class Shape, int STAGES = 3, bool SWAP = false, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_nt_stream(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb,
                                                int64_t N, int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
     constexpr int BM = Shape::BM, BN = Shape::BN, BK = Shape::BK;
@@ -290,7 +290,8 @@ __device__ __forceinline__ void gemm_nt_stream(const uint16_t* __restrict__ A, i
 #pragma unroll
                 for (int mi = 0; mi < Shape::TM; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < Shape::TN; ++ni) acc.v[mi][ni] = T::mfma(af[ks & 1][mi], bf[ks & 1][ni], acc.v[mi][ni]);
+                    for (int ni = 0; ni < Shape::TN; ++ni)
+                        acc.v[mi][ni] = SWAP ? T::mfma(bf[ks & 1][ni], af[ks & 1][mi], acc.v[mi][ni]) : T::mfma(af[ks & 1][mi], bf[ks & 1][ni], acc.v[mi][ni]);
             }
         }
         epi(acc, m0, n0, nat);
