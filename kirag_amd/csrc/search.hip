@@ -53,6 +53,7 @@ struct Index {
     float* out_s = nullptr;    // [QBLK, kmax]
     int64_t* out_r = nullptr;  // [QBLK, kmax]
     uint32_t* nrer = nullptr;  // [QBLK] re-ranked rows (stats)
+    uint32_t* h_status = nullptr;   // pinned host: [QBLK] flags | [QBLK] nrer | [1] list overflow
     int out_k = 0;
     uint64_t* ex_a = nullptr; uint64_t* ex_b = nullptr; size_t ex_bytes = 0;  // exact-scan ping/pong
     int* ex_qidx = nullptr;    // [QBLK] flagged query list
@@ -478,6 +479,7 @@ static int ensure_ws(Index* ix, int k, int cand_cap) {
         KR_HIP(hipMalloc(&ix->cnt, QBLK * sizeof(uint32_t)));
         KR_HIP(hipMalloc(&ix->flags, QBLK * sizeof(uint32_t)));
         KR_HIP(hipMalloc(&ix->nrer, QBLK * sizeof(uint32_t)));
+        KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->h_status), (2 * QBLK + 1) * sizeof(uint32_t), hipHostMallocDefault));
         KR_HIP(hipMalloc(&ix->ex_qidx, QBLK * sizeof(int)));
         KR_HIP(hipMalloc(&ix->blk_list, (size_t)ix->num_cu * ShapeC::NWAVE * WLISTCAP * sizeof(uint4)));
         KR_HIP(hipMalloc(&ix->blk_cnt, ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int)));
@@ -616,31 +618,34 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         hipLaunchKernelGGL(k_rerank, dim3(nq), dim3(256), rer_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags,
                            ix->thr, ix->eps, ix->q_f, ix->xf, ix->d, k, final_preset, ix->out_s, ix->out_r, ix->nrer);
         KR_HIP(hipGetLastError());
-        KR_HIP(hipMemcpyAsync(hflags.data(), ix->flags, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        unsigned int list_ovf = 0;
-        KR_HIP(hipMemcpyAsync(&list_ovf, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        // one round trip: status words into pinned memory and (optimistically) the results into the caller's buffers, ONE stream sync;
+        // only if a query was flagged does the exact scan run and overwrite its rows
+        KR_HIP(hipMemcpyAsync(ix->h_status, ix->flags, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        KR_HIP(hipMemcpyAsync(ix->h_status + QBLK, ix->nrer, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        KR_HIP(hipMemcpyAsync(ix->h_status + 2 * QBLK, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        KR_HIP(hipMemcpyAsync(scores, ix->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
+        KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
+        KR_HIP(hipEventRecord(ix->ev[3], st));
         KR_HIP(hipStreamSynchronize(st));
-        if (list_ovf) for (auto& f : hflags) f |= 1u;   // a block list overflowed (sticky for the call): every query goes to the exact scan
+        const bool list_ovf = ix->h_status[2 * QBLK] != 0u;   // a block list overflowed (sticky for the call): every query goes to the exact scan
+        for (int i = 0; i < nq; ++i) { hflags[i] = ix->h_status[i] | (list_ovf ? 1u : 0u); ix->st.reranked_rows += ix->h_status[QBLK + i]; }
         for (int r = 0; r < round && r < 16; ++r) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ix->evc[2 * r], ix->evc[2 * r + 1]) == hipSuccess) coarse_ms += ms;
         }
-        std::vector<uint32_t> hn(nq);
-        KR_HIP(hipMemcpy(hn.data(), ix->nrer, nq * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (int i = 0; i < nq; ++i) ix->st.reranked_rows += hn[i];
     }
     std::vector<int> fl;
     for (int i = 0; i < nq; ++i) {
         if (hflags[i]) { fl.push_back(i); if (hflags[i] & 1u) ix->st.overflow++; }
     }
-    if (!fl.empty()) {
+    if (!fl.empty() || !fast_ok) {
         KR_HIP(hipMemcpyAsync(ix->ex_qidx, fl.data(), fl.size() * sizeof(int), hipMemcpyHostToDevice, st));
         KR_TRY(exact_scan(ix, (int)fl.size(), k, st));
+        KR_HIP(hipMemcpyAsync(scores, ix->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
+        KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
+        KR_HIP(hipEventRecord(ix->ev[3], st));
+        KR_HIP(hipStreamSynchronize(st));
     }
-    KR_HIP(hipMemcpyAsync(scores, ix->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
-    KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
-    KR_HIP(hipEventRecord(ix->ev[3], st));
-    KR_HIP(hipStreamSynchronize(st));
     float tot = 0.f;
     if (hipEventElapsedTime(&tot, ix->ev[0], ix->ev[3]) == hipSuccess) ix->st.last_total_ms += tot;
     ix->st.last_coarse_ms += coarse_ms;
@@ -680,6 +685,7 @@ void kr_index_destroy(kr_index* h) {
     void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
                     ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (ix->h_status) (void)hipHostFree(ix->h_status);
     for (auto& e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ix->evc) if (e) (void)hipEventDestroy(e);
     delete ix;
