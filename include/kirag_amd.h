@@ -81,6 +81,13 @@ typedef struct {
 } kr_search_stats;
 int kr_index_stats(kr_index* ix, kr_search_stats* out, int reset);
 
+/* Exact top-k of q . x^T for a small transient candidate set — replaces the torch.matmul + torch.topk of the KiRAG loop's aligner step
+ * (knowledge_graph/models.py:1532-1538: [1-2 queries] x [T triples], top-20) and the matmul + argsort of the exemplar / dev-MRR ranking
+ * (models.py:1315-1316, kg_generator.py:119-120, trainer/aligner_trainer.py:112-113).
+ *   q [nq,d], x [n,d] fp32 (host or device pointers), scores [nq,k] fp32 descending, rows [nq,k] int64 row numbers of x.
+ * Same result definition as kr_index_search (canonical score, ties by row asc); 0 < k <= min(n, 1024), nq <= 65535. */
+int kr_score_topk(const float* q, int nq, const float* x, int64_t n, int d, int k, float* scores, int64_t* rows, int device, void* stream);
+
 /* Host-side final merge of per-shard results (north_star: "host-side final merge" after the RCCL all-gather).
  *   scores [nshards,nq,k], ids [nshards,nq,k] (GLOBAL ids) -> out_scores/out_ids [nq,k] by (score desc, id asc).
  *   Host pointers only. */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "kr_index_get_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "kr_index_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kr_index_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
+    "kr_score_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kr_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "kr_encoder_create": (C.c_int, [C.POINTER(BertCfg), C.c_int, C.POINTER(C.c_void_p)]),
     "kr_encoder_destroy": (None, [C.c_void_p]),

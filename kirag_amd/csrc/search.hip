@@ -762,6 +762,48 @@ int kr_index_search(kr_index* h, const float* q, int nq, int k, float* scores, i
     return 0;
 }
 
+// exact top-k of q x^T for a small, transient candidate set (the KiRAG loop's aligner step): canonical scores of every (query, row)
+// pair by k_exact_scan + the sort tree, on a per-device scratch Index (no 16-bit copy, no certificate needed: this IS the exact scan)
+int kr_score_topk(const float* q, int nq, const float* x, int64_t n, int d, int k, float* scores, int64_t* rows, int device, void* stream) {
+    if (!q || !x || !scores || !rows) return fail(KR_EINVAL, "NULL argument");
+    if (d < 4 || d > 4096 || (d % 4) != 0) return fail(KR_EINVAL, "vector size %d unsupported (need 4 <= d <= 4096, d %% 4 == 0)", d);
+    if (nq <= 0 || nq > 65535) return fail(KR_EINVAL, "nq=%d must satisfy 0 < nq <= 65535", nq);
+    if (n <= 0 || n > 0xFFFFFFF0ll) return fail(KR_EINVAL, "bad row count");
+    if (k <= 0 || (int64_t)k > n || k > EXACT_RC) return fail(KR_EINVAL, "k=%d must satisfy 0 < k <= min(n=%lld, %d)", k, (long long)n, EXACT_RC);
+    KR_TRY(select_device(device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static thread_local Index* scratch[64] = {};
+    if (device < 0 || device >= 64) return fail(KR_EINVAL, "device %d out of range", device);
+    Index*& w = scratch[device];
+    if (!w) { w = new Index(); w->device = device; }
+    auto regrow = [](auto*& p, size_t& have, size_t need) -> int {
+        if (need <= have) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; have = 0;
+        KR_HIP(hipMalloc(reinterpret_cast<void**>(&p), need));
+        have = need;
+        return 0;
+    };
+    static thread_local size_t cap_x[64] = {}, cap_q[64] = {}, cap_i[64] = {}, cap_s[64] = {}, cap_r[64] = {};
+    KR_TRY(regrow(w->xf, cap_x[device], (size_t)n * d * sizeof(float)));
+    KR_TRY(regrow(w->q_f, cap_q[device], (size_t)nq * d * sizeof(float)));
+    KR_TRY(regrow(w->ex_qidx, cap_i[device], (size_t)nq * sizeof(int)));
+    KR_TRY(regrow(w->out_s, cap_s[device], (size_t)nq * k * sizeof(float)));
+    KR_TRY(regrow(w->out_r, cap_r[device], (size_t)nq * k * sizeof(int64_t)));
+    w->d = d; w->n = n;
+    KR_HIP(hipMemcpyAsync(w->xf, x, (size_t)n * d * sizeof(float), hipMemcpyDefault, st));
+    KR_HIP(hipMemcpyAsync(w->q_f, q, (size_t)nq * d * sizeof(float), hipMemcpyDefault, st));
+    std::vector<int> iota(nq);
+    for (int i = 0; i < nq; ++i) iota[i] = i;
+    KR_HIP(hipMemcpyAsync(w->ex_qidx, iota.data(), (size_t)nq * sizeof(int), hipMemcpyHostToDevice, st));
+    KR_HIP(hipStreamSynchronize(st));   // iota is a stack/heap host buffer
+    KR_TRY(exact_scan(w, nq, k, st));
+    KR_HIP(hipMemcpyAsync(scores, w->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
+    KR_HIP(hipMemcpyAsync(rows, w->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
+    KR_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 int kr_index_stats(kr_index* h, kr_search_stats* out, int reset) {
     if (!h || !out) return fail(KR_EINVAL, "NULL argument");
     Index* ix = reinterpret_cast<Index*>(h);

@@ -1,0 +1,73 @@
+"""CPU-side checks of the KiRAG-loop aligner helpers (kirag_amd/retriever/aligner.py): the embedding cache and the text contract of
+filter_candidate_triples (reference knowledge_graph/models.py:1514-1542).  The ranking itself needs the GPU (tests/test_gpu_aligner.py)."""
+import numpy as np
+import pytest
+import torch
+
+from kirag_amd import _lib
+from kirag_amd.retriever.aligner import EmbeddingCache, filter_candidate_triples
+
+
+def _fake_encode(calls):
+    def encode(texts):
+        calls.append(list(texts))
+        return torch.tensor([[float(len(t)), float(sum(map(ord, t)) % 97), 1.0, 0.0] for t in texts])
+    return encode
+
+
+def test_embedding_cache_encodes_each_text_once_and_keeps_order():
+    calls = []
+    c = EmbeddingCache()
+    a = c.embed(["bb", "a", "bb", "ccc"], "doc", 128, _fake_encode(calls))
+    assert calls == [["bb", "a", "ccc"]]                      # duplicates inside one request are encoded once
+    assert a.shape == (4, 4) and torch.equal(a[0], a[2]) and a[1, 0] == 1.0 and a[3, 0] == 3.0
+    b = c.embed(["ccc", "dddd", "a"], "doc", 128, _fake_encode(calls))
+    assert calls[-1] == ["dddd"]                              # only the miss
+    assert torch.equal(b[0], a[3]) and torch.equal(b[2], a[1])
+    c.embed(["a"], "doc", 64, _fake_encode(calls))            # another max_length is another key (truncation differs)
+    c.embed(["a"], "query", 128, _fake_encode(calls))         # and so is the other prefix kind
+    assert calls[-2:] == [["a"], ["a"]]
+    assert c.hits == 2 and c.misses == 6 and len(c) == 6
+
+
+def test_embedding_cache_lru_bound():
+    calls = []
+    c = EmbeddingCache(max_bytes=3 * 16)                      # three float32[4] rows
+    for t in ["t1", "t2", "t3", "t4"]:
+        c.embed([t], "doc", 8, _fake_encode(calls))
+    assert len(c) == 3
+    c.embed(["t1"], "doc", 8, _fake_encode(calls))            # evicted -> encoded again
+    assert calls[-1] == ["t1"]
+    c.embed(["t4"], "doc", 8, _fake_encode(calls))            # still resident
+    assert calls[-1] == ["t1"]
+
+
+def test_filter_candidate_triples_builds_the_reference_query_strings(monkeypatch):
+    seen = {}
+
+    class FakeAligner:
+        def calculate_query_embeddings(self, queries, max_length=None, **kw):
+            seen["queries"] = list(queries); seen["qlen"] = max_length
+            return torch.eye(4)[: len(queries)]
+
+        def calculate_document_embeddings(self, documents, max_length=None, **kw):
+            seen["docs"] = list(documents); seen["dlen"] = max_length
+            return torch.eye(4)[: len(documents)]
+
+    import kirag_amd.retriever.aligner as A
+    monkeypatch.setattr(A, "rank_by_similarity", lambda q, x, k, device=None: ("idx", (tuple(q.shape), tuple(x.shape), k)))
+    out = filter_candidate_triples(FakeAligner(), "who?", [["<a; r; b>", "<b; r; c>"], []], ["<x; y; z>", "<p; q; r>", "<s; t; u>"], 20)
+    # models.py:1526  "{}\nknowledge triples: {}.".format(question, ". ".join(texts))
+    assert seen["queries"] == ["who?\nknowledge triples: <a; r; b>. <b; r; c>.", "who?\nknowledge triples: ."]
+    assert seen["qlen"] == 256 and seen["dlen"] == 128 and seen["docs"] == ["<x; y; z>", "<p; q; r>", "<s; t; u>"]
+    assert out == ("idx", ((2, 4), (3, 4), 3))                # k = min(num_candidate_triples, num_triples)  (models.py:1536)
+
+
+def test_score_topk_argument_validation_needs_no_device():
+    lib = _lib.load()
+    q = np.zeros((2, 8), np.float32); x = np.zeros((5, 8), np.float32)
+    s = np.zeros((2, 3), np.float32); r = np.zeros((2, 3), np.int64)
+    assert lib.kr_score_topk(q.ctypes.data, 2, x.ctypes.data, 5, 6, 3, s.ctypes.data, r.ctypes.data, 0, None) == -22    # d % 4 != 0
+    assert lib.kr_score_topk(q.ctypes.data, 2, x.ctypes.data, 5, 8, 6, s.ctypes.data, r.ctypes.data, 0, None) == -22    # k > n
+    assert lib.kr_score_topk(q.ctypes.data, 0, x.ctypes.data, 5, 8, 3, s.ctypes.data, r.ctypes.data, 0, None) == -22    # nq = 0
+    assert lib.kr_score_topk(None, 2, x.ctypes.data, 5, 8, 3, s.ctypes.data, r.ctypes.data, 0, None) == -22
