@@ -24,17 +24,19 @@
 namespace kr {
 
 using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LDS, one block per CU: best main loop (long-K GEMMs)
-constexpr int PROJ_STAGES = 2;
+// LDS ring depth (template parameter STAGES of k_proj): the 256x256 ping-pong ring is fixed at 2 K-tiles; the 128x128 streaming loop runs with
+// 2 slots and two blocks per CU, or, for launches with at most one tile per CU (latency-bound: a tile's time is its K-tiles x the memory round trip),
+// with 4 slots = 3 K-tiles in flight (4 x 32 KiB + 4 x 4 KiB of epilogue stage = 144 KiB: one block per CU)
 
 using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB ring, two blocks per CU: for launches with too few 256x256 tiles to fill the chip
 
 // both main loops run with exchanged MFMA operands (accumulators hold 4 consecutive features per lane):
 // 256x256 tiles -> ping-pong loop; 128x128 tiles (small token counts: 4x the tiles, a quarter of the latency each) -> streaming loop
-template <class ShapeE, class Coord, class Epilogue>
+template <class ShapeE, int STAGES, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_main(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb, int64_t N,
                                           int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
     if constexpr (ShapeE::BM == 256 && ShapeE::BN == 256) gemm_nt_pingpong<BF16, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
-    else gemm_nt_stream<BF16, ShapeE, PROJ_STAGES, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
+    else gemm_nt_stream<BF16, ShapeE, STAGES, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
 }
 
 struct LayerW {
@@ -326,13 +328,13 @@ __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char*
 //   EPI_QKV:   F = 3H: features [0,H) -> q (bias, 1/8 folded into the weights), [H,2H) -> k, [2H,3H) -> V^T (its bias lives in bo_eff)
 //   EPI_DENSE: out0[T,F] = acc + bias as bf16 (k_ln adds the fp32 residual)
 //   EPI_GELU:  out0[T,F] = gelu(acc + bias)
-template <int EPI, class ShapeE>
+template <int EPI, class ShapeE, int STAGES>
 __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = *a.Tp;
     const int64_t tm_count = (T + ShapeE::BM - 1) / ShapeE::BM, tn_count = (a.F + ShapeE::BN - 1) / ShapeE::BN;
-    char* stage = smem + PROJ_STAGES * ShapeE::STAGE_BYTES + (threadIdx.x >> 6) * EPI_STAGE_BYTES;
-    gemm_main<ShapeE>(
+    char* stage = smem + STAGES * ShapeE::STAGE_BYTES + (threadIdx.x >> 6) * EPI_STAGE_BYTES;
+    gemm_main<ShapeE, STAGES>(
         a.X, a.K, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             int64_t tm, tn;
@@ -777,20 +779,19 @@ static int launch_attn(const Encoder* e, int B, int cap, hipStream_t st) {
     return 0;
 }
 
-template <class Shape>
-static int launch_proj_shape(int epi, const ProjArgs& a, int num_cu, hipStream_t st) {
-    constexpr int lds = PROJ_STAGES * Shape::STAGE_BYTES + Shape::NWAVE * EPI_STAGE_BYTES;   // 160 KiB for the 256x256 tile: the whole LDS of a CU
-    const int blocks = num_cu * (Shape::NTHREADS == 256 ? 2 : 1);
+template <class Shape, int STAGES>
+static int launch_proj_shape(int epi, const ProjArgs& a, int blocks, hipStream_t st) {
+    constexpr int lds = STAGES * Shape::STAGE_BYTES + Shape::NWAVE * EPI_STAGE_BYTES;   // 160 KiB for the 256x256 tile: the whole LDS of a CU
     static bool attr_set = false;
     if (!attr_set) {
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_QKV, Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_DENSE, Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_GELU, Shape>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_QKV, Shape, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_DENSE, Shape, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_GELU, Shape, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj<EPI_QKV, Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
-    else if (epi == EPI_DENSE) hipLaunchKernelGGL((k_proj<EPI_DENSE, Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
-    else hipLaunchKernelGGL((k_proj<EPI_GELU, Shape>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj<EPI_QKV, Shape, STAGES>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    else if (epi == EPI_DENSE) hipLaunchKernelGGL((k_proj<EPI_DENSE, Shape, STAGES>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    else hipLaunchKernelGGL((k_proj<EPI_GELU, Shape, STAGES>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
     return 0;
 }
 
@@ -798,10 +799,12 @@ static int launch_proj_shape(int epi, const ProjArgs& a, int num_cu, hipStream_t
 // loop's triple batches, a 1/8 slice of a query batch) the 128x128 tiling gives 4x the parallelism at a quarter of the per-tile latency
 static int launch_proj(int epi, const ProjArgs& a, int64_t max_tokens, int num_cu, hipStream_t st) {
     const int64_t big_tiles = ((max_tokens + 255) / 256) * ((a.F + 255) / 256);
+    const int64_t small_tiles = ((max_tokens + 127) / 128) * ((a.F + 127) / 128);
     static const int force = [] { const char* e = getenv("KIRAG_AMD_PROJ_TILE"); return e ? atoi(e) : 0; }();   // 128 / 256 for A/B tests
     const bool small = force == 128 || (force != 256 && big_tiles < num_cu);
-    if (small) return launch_proj_shape<ShapeSmall>(epi, a, num_cu, st);
-    return launch_proj_shape<ShapeBig>(epi, a, num_cu, st);
+    if (!small) return launch_proj_shape<ShapeBig, 2>(epi, a, num_cu, st);
+    if (small_tiles <= num_cu) return launch_proj_shape<ShapeSmall, 4>(epi, a, num_cu, st);
+    return launch_proj_shape<ShapeSmall, 2>(epi, a, 2 * num_cu, st);
 }
 
 }  // namespace kr
