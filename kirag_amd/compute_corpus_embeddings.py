@@ -21,7 +21,7 @@ import torch
 
 from .collators import COLLATOR_MAP
 from .retriever.retrievers import InBatchRetriever
-from .utils import to_device
+from .utils import prefetch_map, to_device
 
 logger = logging.getLogger(__file__)
 
@@ -42,6 +42,7 @@ def setup_parser(argv=None):
     parser.add_argument("--num_passage_per_index_file", type=int, default=1000000)
     # MI355X path: passages per encoder launch (rows are batch-invariant, so this changes speed only)
     parser.add_argument("--encode_batch_size", type=int, default=512)
+    parser.add_argument("--prefetch_batches", type=int, default=2, help="batches tokenised ahead of the GPU on a background thread")
     return parser.parse_args(argv)
 
 
@@ -77,12 +78,13 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
             pickle.dump(buf_ids, f)
         buf, buf_ids, file_start = [], [], upto
 
-    for s in range(start, end, bs):
-        e = min(s + bs, end)
-        items = [corpus_dataset[i] for i in range(s, e)]
-        inputs = to_device(collator.encode_doc([it["passage"] for it in items]), device)
+    def collate(s):                                          # runs on the prefetch thread: dataset access + tokenisation of batch i+1, i+2
+        items = [corpus_dataset[i] for i in range(s, min(s + bs, end))]
+        return collator.encode_doc([it["passage"] for it in items]), [corpus_dataset.index_to_passage_id[it["index"]] for it in items]
+
+    for cpu_inputs, ids in prefetch_map(collate, range(start, end, bs), depth=int(getattr(args, "prefetch_batches", 2))):
+        inputs = to_device(cpu_inputs, device)
         emb = model.doc(inputs).detach()                     # HIP path (eval mode), stays on the GPU
-        ids = [corpus_dataset.index_to_passage_id[it["index"]] for it in items]
         if indexer is not None:
             indexer.index_data(ids, emb)                     # device-to-device append into the resident shard
         emb = emb.cpu()

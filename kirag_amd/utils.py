@@ -3,7 +3,9 @@ device placement of collated batches (:190-209) and the in-batch-negative all-ga
 Everything else in that file (JSON/TSV IO, logging, seeding) is out of scope and stays in the reference."""
 from __future__ import annotations
 
-from typing import List
+import queue
+import threading
+from typing import Callable, Iterable, Iterator, List, TypeVar
 
 import torch
 import torch.distributed as dist
@@ -46,3 +48,49 @@ def get_global_labels_for_inbatchtraining(local_rank: int, world_size: int, loca
         return None
     gathered = get_global_tensor_list(local_rank, world_size, local_labels)
     return torch.cat([lab + i * local_doc_size for i, lab in enumerate(gathered)], dim=0).to(local_labels.device)
+
+
+_T = TypeVar("_T")
+_R = TypeVar("_R")
+
+
+def prefetch_map(fn: Callable[[_T], _R], items: Iterable[_T], depth: int = 2) -> Iterator[_R]:
+    """``map(fn, items)`` with ``fn`` running on a background thread, at most ``depth`` results ahead of the consumer, order kept,
+    exceptions re-raised at the consumer.  Used to tokenise batch i+1 (HF fast tokenizers release the GIL) while the GPU encodes
+    batch i — the reference tokenises inside its single-threaded loop (``compute_corpus_embeddings.py:77-81``, DataLoader
+    ``num_workers=0``, ``utils/utils.py:122``), which cannot keep a >10k passages/s encoder fed.
+    Length bucketing is not needed on this path: the encoder packs attended tokens on the device, so padding costs no FLOPs."""
+    q: "queue.Queue" = queue.Queue(maxsize=max(1, int(depth)))
+    stop = threading.Event()
+    _END, _ERR = object(), object()
+
+    def put(x) -> bool:
+        while not stop.is_set():
+            try:
+                q.put(x, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def work():
+        try:
+            for it in items:
+                if not put(fn(it)):
+                    return
+            put(_END)
+        except BaseException as e:   # noqa: BLE001 - forwarded to the consumer
+            put((_ERR, e))
+
+    t = threading.Thread(target=work, daemon=True, name="kirag-amd-prefetch")
+    t.start()
+    try:
+        while True:
+            x = q.get()
+            if x is _END:
+                return
+            if isinstance(x, tuple) and len(x) == 2 and x[0] is _ERR:
+                raise x[1]
+            yield x
+    finally:
+        stop.set()

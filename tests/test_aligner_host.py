@@ -71,3 +71,36 @@ def test_score_topk_argument_validation_needs_no_device():
     assert lib.kr_score_topk(q.ctypes.data, 2, x.ctypes.data, 5, 8, 6, s.ctypes.data, r.ctypes.data, 0, None) == -22    # k > n
     assert lib.kr_score_topk(q.ctypes.data, 0, x.ctypes.data, 5, 8, 3, s.ctypes.data, r.ctypes.data, 0, None) == -22    # nq = 0
     assert lib.kr_score_topk(None, 2, x.ctypes.data, 5, 8, 3, s.ctypes.data, r.ctypes.data, 0, None) == -22
+
+
+def test_prefetch_map_order_bound_and_errors():
+    import threading
+    import time
+    from kirag_amd.utils import prefetch_map
+    started = []
+
+    def fn(i):
+        started.append(i)
+        time.sleep(0.01)
+        return i * i
+
+    it = prefetch_map(fn, range(10), depth=2)
+    first = next(it)
+    time.sleep(0.1)
+    assert first == 0 and len(started) <= 4          # the worker runs at most depth (+1 in flight) ahead of the consumer
+    assert [first] + list(it) == [i * i for i in range(10)]
+
+    def bad(i):
+        if i == 3:
+            raise ValueError("boom")
+        return i
+
+    got = []
+    with pytest.raises(ValueError, match="boom"):
+        for x in prefetch_map(bad, range(6)):
+            got.append(x)
+    assert got == [0, 1, 2]
+    n0 = threading.active_count()
+    g = prefetch_map(fn, range(1000), depth=1); next(g); g.close()      # abandoning the generator stops the worker
+    time.sleep(0.5)
+    assert threading.active_count() <= n0 + 1
