@@ -800,10 +800,11 @@ static int launch_proj_shape(int epi, const ProjArgs& a, int blocks, hipStream_t
 static int launch_proj(int epi, const ProjArgs& a, int64_t max_tokens, int num_cu, hipStream_t st) {
     const int64_t big_tiles = ((max_tokens + 255) / 256) * ((a.F + 255) / 256);
     const int64_t small_tiles = ((max_tokens + 127) / 128) * ((a.F + 127) / 128);
-    static const int force = [] { const char* e = getenv("KIRAG_AMD_PROJ_TILE"); return e ? atoi(e) : 0; }();   // 128 / 256 for A/B tests
+    const char* fe = getenv("KIRAG_AMD_PROJ_TILE");   // 128 / 256 force a path (tests run every parity case through both); read per call
+    const int force = fe ? atoi(fe) : 0;
     const bool small = force == 128 || (force != 256 && big_tiles < num_cu);
     if (!small) return launch_proj_shape<ShapeBig, 2>(epi, a, num_cu, st);
-    if (small_tiles <= num_cu) return launch_proj_shape<ShapeSmall, 4>(epi, a, num_cu, st);
+    if (small_tiles <= num_cu && force != 128) return launch_proj_shape<ShapeSmall, 4>(epi, a, num_cu, st);
     return launch_proj_shape<ShapeSmall, 2>(epi, a, 2 * num_cu, st);
 }
 

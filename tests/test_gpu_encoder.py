@@ -147,3 +147,50 @@ def test_module_surface_eval_hip_train_torch():
         m.train(); ref2 = m(ids.cuda(), mask.cuda()).detach(); m.eval()
         assert (out2 - ref2).abs().max().item() <= 4e-3
         assert m.config.hidden_size == 128 and len(list(m.named_parameters())) > 0
+
+
+@pytest.mark.parametrize("B,S", [(3, 512), (5, 300), (9, 96), (70, 64), (300, 33)])
+def test_long_and_many_sequences_vs_oracle(B, S):
+    """Sequence lengths up to max_position_embeddings (the reference's doc_maxlength default, compute_corpus_embeddings.py:32-33) and
+    batches that span several attention blocks / token tiles, ragged with right and left padding, against the numpy oracle (which is
+    pinned to the reference by the goldens).  Covers every heads-per-block variant of the attention kernel (S = 33 / 64 / >= 96) and
+    the large-tile, small-tile and 4-slot projection paths."""
+    cfg = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
+                          max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    w = E.synth_weights(128, 2, 512, 1000, 512, seed=11)
+    h = _hip(cfg, w)
+    rng = np.random.default_rng(B * 1000 + S)
+    ids = rng.integers(5, 1000, (B, S)); mask = np.zeros((B, S), np.int64)
+    lens = rng.integers(max(1, S // 3), S + 1, B); lens[0] = S
+    for b in range(B):
+        if b % 3 == 2:
+            mask[b, S - lens[b]:] = 1           # left padded
+        else:
+            mask[b, :lens[b]] = 1
+    for pool, fn in ((0, E.e5_encode), (1, E.bge_encode)):
+        out = h.forward_np(ids, mask, pool)
+        ref = fn(w, ids, mask, 2)
+        _check(out, ref, 4e-3, f"B{B} S{S} pool{pool}")
+
+
+@pytest.mark.parametrize("tile", ["256", "128"])
+def test_every_projection_path_on_every_shape(golden, tile, monkeypatch):
+    """The launcher picks the 256x256 ping-pong loop, the 128x128 2-slot loop or the 128x128 4-slot loop from the token count; force the
+    256x256 path and the 128x128 2-slot path on the full-size golden batch and on a ragged tiny-config batch (the default choice, covered by
+    the other tests, is the 4-slot path for these sizes)."""
+    monkeypatch.setenv("KIRAG_AMD_PROJ_TILE", tile)
+    g = golden("g2_encoder_large.npz")
+    cfg = _cfg(g["cfg"])
+    w = E.synth_weights(cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
+                        seed=int(g["weight_seed"]))
+    h = _hip(cfg, w)
+    for key, pool in (("e5.c0", 0), ("e5.c1", 0), ("e5.c2", 0), ("bge.c0", 1)):
+        out = h.forward_np(g[key + ".ids"], g[key + ".mask"], pool)
+        _check(out, g[key + ".out"], 3e-3, f"tile{tile} {key}")
+    del h
+    cfg2 = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
+                           max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    w2 = E.synth_weights(128, 2, 512, 1000, 512, seed=11)
+    h2 = _hip(cfg2, w2)
+    ids, mask = E.synth_tokens(700, 48, seed=3, ragged=True, vocab_lo=5, vocab_hi=1000, min_len=3)
+    _check(h2.forward_np(ids, mask, 0), E.e5_encode(w2, ids, mask, 2), 4e-3, f"tile{tile} tiny ragged")
