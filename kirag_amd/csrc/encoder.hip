@@ -795,14 +795,14 @@ static int launch_proj_shape(int epi, const ProjArgs& a, int blocks, hipStream_t
     return 0;
 }
 
-// tile shape per launch: when the 256x256 tiling has fewer tiles than CUs (small batches: the reference's per_gpu_batch_size 4-8, the KiRAG
+// tile shape per launch: when the 256x256 tiling has fewer tiles than ~5/8 of the CUs (small batches: the reference's per_gpu_batch_size 4-8, the KiRAG
 // loop's triple batches, a 1/8 slice of a query batch) the 128x128 tiling gives 4x the parallelism at a quarter of the per-tile latency
 static int launch_proj(int epi, const ProjArgs& a, int64_t max_tokens, int num_cu, hipStream_t st) {
     const int64_t big_tiles = ((max_tokens + 255) / 256) * ((a.F + 255) / 256);
     const int64_t small_tiles = ((max_tokens + 127) / 128) * ((a.F + 127) / 128);
     const char* fe = getenv("KIRAG_AMD_PROJ_TILE");   // 128 / 256 force a path (tests run every parity case through both); read per call
     const int force = fe ? atoi(fe) : 0;
-    const bool small = force == 128 || (force != 256 && big_tiles < num_cu);
+    const bool small = force == 128 || (force != 256 && big_tiles * 8 < (int64_t)num_cu * 5);   // measured crossover: ~5/8 of the CUs busy with 256x256 tiles
     if (!small) return launch_proj_shape<ShapeBig, 2>(epi, a, num_cu, st);
     if (small_tiles <= num_cu && force != 128) return launch_proj_shape<ShapeSmall, 4>(epi, a, num_cu, st);
     return launch_proj_shape<ShapeSmall, 2>(epi, a, 2 * num_cu, st);
@@ -943,7 +943,7 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
     hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(64), 0, st, e->seq_nk, e->seq_has0, B, pool, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->d_err);
     hipLaunchKernelGGL(k_fill_tokens, dim3(B), dim3(64), 0, st, e->d_ids, e->d_mask, S, e->cfg.vocab, e->seq_off, e->seq_nk, e->seq_nq, e->tok_id,
                        e->tok_pos, e->d_err);
-    const int64_t maxT = (int64_t)B * (S + 4);
+    const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + 3) & ~3);   // upper bound of the packed token count (each sequence is padded to 4)
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->xf, e->xb);
