@@ -327,7 +327,7 @@ __device__ __forceinline__ void gemm_nt_stream(const uint16_t* __restrict__ A, i
 // =====================================================================================================================
 using ShapePP = GemmShape<256, 256, 2, 4>;
 
-template <class T, bool SWAP = false, class Coord, class Epilogue>
+template <class T, bool SWAP = false, bool A_NT = false, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb,
                                                  int64_t N, int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
     using Shape = ShapePP;
@@ -370,8 +370,12 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
         char* dst = smem + c.slot * STAGE + (isA ? 0 : ABYTES) + piece0 * 1024;
         const char* src = c.base + (int64_t)c.kt * (BK * 2);
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(src + c.off[p]), (lds_void*)(dst + p * 1024), 16, 0, 0);
+        for (int p = 0; p < 4; ++p) {
+            // A_NT: the A operand is a once-through stream (the corpus of the coarse scan): non-temporal, so that it does not push the small,
+            // re-used B operand (the query block) out of L2
+            if (A_NT && isA) __builtin_amdgcn_global_load_lds((gbl_void*)(src + c.off[p]), (lds_void*)(dst + p * 1024), 16, 0, 2);
+            else __builtin_amdgcn_global_load_lds((gbl_void*)(src + c.off[p]), (lds_void*)(dst + p * 1024), 16, 0, 0);
+        }
         c.slot ^= 1;
         if (c.kt + 1 < nk) { ++c.kt; }
         else if (c.tile + 1 < my) { c.kt = 0; ++c.tile; set_base(c, isA, piece0); }

@@ -175,7 +175,10 @@ __global__ __launch_bounds__(ShapeC::NTHREADS, 2) void k_coarse(CoarseArgs a) {
     const int64_t tn_count = a.nq_pad / ShapeC::BN;
     const int64_t total = a.tile_count * tn_count;
     const int64_t n_pad = (a.n + ShapeC::BM - 1) / ShapeC::BM * ShapeC::BM;
-    gemm_nt_pingpong<T>(
+    // corpus loads are non-temporal: the corpus is a once-through stream (shared by the 4 CUs of an XCD that hold the other query tiles of the
+    // same rows at about the same time), while the 2-MiB query block is re-read by every job; with default-policy corpus loads the stream
+    // pushed the queries out of the 4-MiB L2 once per job (FETCH_SIZE 1.54x the corpus bytes; 1.18x with nt, profiles/)
+    gemm_nt_pingpong<T, false, true>(
         a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             const int64_t tslot = nat / tn_count, tn = nat % tn_count;   // the query blocks of one corpus tile are adjacent
