@@ -7,9 +7,9 @@
 // beyond the device-side total exit.  Residual stream fp32 (xf), MFMA operands bf16 (xb, q, k, vT, ctx, h),
 // fp32 accumulation everywhere.
 //
-// Per layer (post-LN BERT):  [Wq/8|Wk|Wv] x -> q, k (row-major) and v TRANSPOSED [H, T] (so that attention reads
-// V^T fragments contiguously); attention = one wave per (sequence, head, 32 queries), swapped QK^T so the softmax
-// reductions are in-lane, P^T fed from the accumulator straight into the V^T.P^T MFMA (no LDS);  Wo ctx + b +
+// Per layer (post-LN BERT):  ONE GEMM [Wq/8|Wk|Wv] x -> q, k (row-major) and v TRANSPOSED [H, T] (so that attention reads
+// V^T fragments contiguously); attention = one block per (sequence, head group) with K and V^T staged once in LDS, swapped QK^T so
+// the softmax reductions are in-lane, P^T fed from the accumulator straight into the V^T.P^T MFMA;  Wo ctx + b +
 // residual -> LayerNorm;  W1 x + b -> erf-GELU;  W2 h + b + residual -> LayerNorm.  Pooling (masked mean or CLS)
 // + L2 normalisation produce out[B,H] fp32.
 #include "gemm_nt.hpp"
@@ -369,110 +369,6 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
                 });
             }
         });
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// attention: one wave per (sequence, head, 32 queries); d_h = 64; softmax(Q K^T + key mask) V   (1/sqrt(d_h) is in Wq)
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_attn(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vT, int64_t ldv,
-                                              const int* __restrict__ seq_off, const int* __restrict__ seq_nk, const int* __restrict__ seq_nq,
-                                              int H, int heads, uint16_t* __restrict__ ctx) {
-    const int lane = threadIdx.x & 63;
-    const int head = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int b = blockIdx.z;
-    const int q0 = blockIdx.x * 32;
-    const int nq = seq_nq[b];
-    if (head >= heads || q0 >= nq) return;
-    const int nk = seq_nk[b];
-    const int64_t off = seq_off[b];
-    const int c = lane & 31, hf = lane >> 5;
-    // Q^T as the B operand: lane (c, hf) holds Q[q0 + c][16 s + 8 hf .. +7], s = 0..3
-    uint4 qf[4];
-    {
-        const int qi = (q0 + c < nq) ? (q0 + c) : (nq - 1);
-        const uint16_t* qrow = q + (off + qi) * H + head * 64;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(qrow + 16 * s + 8 * hf);
-    }
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m = -INFINITY, l = 0.f;
-    const float LOG2E = 1.4426950408889634f;
-    const uint16_t* vrow0 = vT + (int64_t)(head * 64 + c) * ldv + off;        // V^T rows d = c and d = 32 + c of this head
-    const uint16_t* vrow1 = vrow0 + 32 * ldv;
-    for (int k0 = 0; k0 < nk; k0 += 32) {
-        // S^T tile [32 keys x 32 queries] = K_tile . Q^T
-        f32x16 st;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = 0.f;
-        {
-            const int ki = (k0 + c < nk) ? (k0 + c) : (nk - 1);
-            const uint16_t* krow = k + (off + ki) * H + head * 64;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(krow + 16 * s + 8 * hf);
-                st = BF16::mfma(kf, qf[s], st);
-            }
-        }
-        // register r of this lane is key k0 + (r&3) + 8 (r>>2) + 4 hf, query q0 + c
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            st[r] = (key < nk) ? st[r] : -INFINITY;
-            tmax = fmaxf(tmax, st[r]);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(m, tmax);
-        const float mref = (mnew == -INFINITY) ? 0.f : mnew;
-        const float alpha = exp2f((m - mref) * LOG2E);
-        float psum = 0.f;
-        float p[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = exp2f((st[r] - mref) * LOG2E); psum += p[r]; }
-        psum += __shfl_xor(psum, 32, 64);
-        l = l * alpha + psum;
-        m = mnew;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        // O^T += V^T . P^T : P^T comes from the accumulator (B operand, k-step s2 = registers 8 s2 .. 8 s2 + 7, whose
-        // element j is key 16 s2 + 8 (j>>2) + 4 hf + (j&3)); the V^T fragment must use the same key order:
-        // elements 0..3 = keys kb .. kb+3, elements 4..7 = keys kb+8 .. kb+11 with kb = k0 + 16 s2 + 4 hf
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            uint4 pf;
-            pf.x = pack_bf16x2(p[8 * s2 + 0], p[8 * s2 + 1]); pf.y = pack_bf16x2(p[8 * s2 + 2], p[8 * s2 + 3]);
-            pf.z = pack_bf16x2(p[8 * s2 + 4], p[8 * s2 + 5]); pf.w = pack_bf16x2(p[8 * s2 + 6], p[8 * s2 + 7]);
-            const int kb = k0 + 16 * s2 + 4 * hf;
-            uint2 a0 = *reinterpret_cast<const uint2*>(vrow0 + kb), a1 = *reinterpret_cast<const uint2*>(vrow0 + kb + 8);
-            uint2 b0 = *reinterpret_cast<const uint2*>(vrow1 + kb), b1 = *reinterpret_cast<const uint2*>(vrow1 + kb + 8);
-            if (k0 + 32 > nk) {   // last tile: rows past nk belong to padding / the next sequence -> zero them (0 * NaN guard)
-                const uint32_t m00 = (kb + 0 < nk ? 0xffffu : 0u) | (kb + 1 < nk ? 0xffff0000u : 0u);
-                const uint32_t m01 = (kb + 2 < nk ? 0xffffu : 0u) | (kb + 3 < nk ? 0xffff0000u : 0u);
-                const uint32_t m10 = (kb + 8 < nk ? 0xffffu : 0u) | (kb + 9 < nk ? 0xffff0000u : 0u);
-                const uint32_t m11 = (kb + 10 < nk ? 0xffffu : 0u) | (kb + 11 < nk ? 0xffff0000u : 0u);
-                a0.x &= m00; a0.y &= m01; a1.x &= m10; a1.y &= m11;
-                b0.x &= m00; b0.y &= m01; b1.x &= m10; b1.y &= m11;
-            }
-            o0 = BF16::mfma(make_uint4(a0.x, a0.y, a1.x, a1.y), pf, o0);
-            o1 = BF16::mfma(make_uint4(b0.x, b0.y, b1.x, b1.y), pf, o1);
-        }
-    }
-    if (q0 + c < nq) {
-        // a query with no attendable key (all-masked sequence) is 0/0 = NaN, as under HF's -inf masking
-        const float inv = 1.0f / l;
-        uint16_t* dst = ctx + (off + q0 + c) * H + head * 64;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int d = 8 * gq + 4 * hf;
-            uint2 w0, w1;
-            w0.x = pack_bf16x2(o0[4 * gq + 0] * inv, o0[4 * gq + 1] * inv); w0.y = pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
-            w1.x = pack_bf16x2(o1[4 * gq + 0] * inv, o1[4 * gq + 1] * inv); w1.y = pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
-            *reinterpret_cast<uint2*>(dst + d) = w0;
-            *reinterpret_cast<uint2*>(dst + 32 + d) = w1;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -935,7 +831,7 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
     KR_TRY(select_device(e->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     KR_TRY(ensure_ws(e, B, S));
-    const int H = e->cfg.hidden, FF = e->cfg.intermediate, heads = e->cfg.heads;
+    const int H = e->cfg.hidden, FF = e->cfg.intermediate;
     const float eps = e->cfg.ln_eps;
     KR_HIP(hipMemcpyAsync(e->d_ids, input_ids, (size_t)B * S * 8, hipMemcpyDefault, st));
     KR_HIP(hipMemcpyAsync(e->d_mask, attention_mask, (size_t)B * S * 8, hipMemcpyDefault, st));
@@ -947,17 +843,13 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->xf, e->xb);
-    const dim3 attn_grid((unsigned)((S + 1 + 31) / 32), (unsigned)((heads + 3) / 4), (unsigned)B);
-    static const bool attn_old = [] { const char* v = getenv("KIRAG_AMD_ATTN_OLD"); return v && v[0] == '1'; }();
     for (const LayerW& l : e->L) {
         ProjArgs a{};
         a.Tp = e->d_T; a.H = H;
         // q | k | v^T in one GEMM (F = 3H)
         a.W = l.wqkv; a.X = e->xb; a.F = 3 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k; a.outT = e->vT; a.ldT = e->ldv;
         KR_TRY(launch_proj(EPI_QKV, a, maxT, e->num_cu, st));
-        if (attn_old) {
-            hipLaunchKernelGGL(k_attn, attn_grid, dim3(256), 0, st, e->q, e->k, e->vT, e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, e->ctx);
-        } else {
+        {
             const int cap = (int)round_up(S, 32);
             const int nqt = (S + (pool == KR_POOL_CLS ? 1 : 0) + 31) / 32;      // q-tiles of the longest possible sequence
             if (nqt >= 3) KR_TRY(launch_attn<1>(e, B, cap, st));

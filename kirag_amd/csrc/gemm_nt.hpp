@@ -3,10 +3,10 @@
 // B = queries, epilogue = threshold filter) and every encoder projection (A = tokens, B = weight [out,in],
 // epilogue = bias / GELU / residual).  The result tile stays in registers and is handed to an epilogue functor.
 //
-// Structure (cdna_hip_programming.md §5): BM x BN block tile, BK = 64, waves WM x WN each owning a
-// (BM/WM) x (BN/WN) sub-tile of 32x32x16 MFMAs; both operands staged HBM -> LDS by LDS-DMA
-// (global_load_lds_dwordx4, 1 KiB per wave-instruction = 8 rows x 128 B), two LDS buffers, one barrier per
-// K-tile with the next tile's DMA in flight under the MFMAs.  The LDS image of a tile is [rows][8 x 16 B]
+// Two main loops share the staging scheme: gemm_nt_pingpong (256x256 tiles, the product path of the coarse scan and of the large
+// projections) and gemm_nt_stream (any tile shape, used for 128x128 tiles when a launch has few tiles).
+// Staging (cdna_hip_programming.md §5): BK = 64; both operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+// wave-instruction = 8 rows x 128 B) into a ring of K-tiles.  The LDS image of a tile is [rows][8 x 16 B]
 // with the 16-B chunk index XOR-swizzled by ((row >> 1) & 7): the DMA destination is lane-linear, so the
 // swizzle is applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads (rule 21).
 // ds_read_b128 of a fragment (lane -> row l&31, chunk 2*ks + (l>>5)) is then bank-conflict free.
@@ -46,114 +46,8 @@ struct AccTile {
     __device__ __forceinline__ int col(int ni) const { return n_wave + ni * 32 + (lane & 31); }
 };
 
-// A: [M, lda] elements, rows m0 .. m0+BM (rows >= M are clamped to M-1 on load: mask them in the epilogue)
-// B: [N, ldb] elements, rows n0 .. n0+BN (same clamping).  K % 64 == 0.  smem: Shape::LDS_BYTES, 16-B aligned.
-template <class T, class Shape, class Epilogue>
-__device__ __forceinline__ void gemm_nt_block(const uint16_t* __restrict__ A, int64_t lda, int64_t M,
-                                              const uint16_t* __restrict__ B, int64_t ldb, int64_t N, int K,
-                                              int64_t m0, int64_t n0, char* smem, Epilogue&& epi) {
-    constexpr int BM = Shape::BM, BN = Shape::BN, BK = Shape::BK;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / Shape::WN, wn = wave % Shape::WN;
-
-    // ---- per-lane DMA source offsets (bytes, relative to the block's first row), constant over the K loop
-    const char* Ablk = reinterpret_cast<const char*>(A + m0 * lda);
-    const char* Bblk = reinterpret_cast<const char*>(B + n0 * ldb);
-    const int64_t a_rows_left = M - m0, b_rows_left = N - n0;
-    uint32_t a_off[Shape::A_PIECES], b_off[Shape::B_PIECES];
-#pragma unroll
-    for (int p = 0; p < Shape::A_PIECES; ++p) {
-        const int piece = wave + p * Shape::NWAVE;
-        int row = piece * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        if (row >= a_rows_left) row = (int)a_rows_left - 1;
-        a_off[p] = (uint32_t)(row * lda * 2 + chunk * 16);
-    }
-#pragma unroll
-    for (int p = 0; p < Shape::B_PIECES; ++p) {
-        const int piece = wave + p * Shape::NWAVE;
-        int row = piece * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        if (row >= b_rows_left) row = (int)b_rows_left - 1;
-        b_off[p] = (uint32_t)(row * ldb * 2 + chunk * 16);
-    }
-
-    auto stage = [&](int buf, int kt) {
-        char* sa = smem + buf * Shape::STAGE_BYTES;
-        char* sb = sa + Shape::A_BYTES;
-        const int64_t kbyte = (int64_t)kt * BK * 2;
-#pragma unroll
-        for (int p = 0; p < Shape::A_PIECES; ++p) {
-            const int piece = wave + p * Shape::NWAVE;
-            __builtin_amdgcn_global_load_lds((gbl_void*)(Ablk + kbyte + a_off[p]), (lds_void*)(sa + piece * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int p = 0; p < Shape::B_PIECES; ++p) {
-            const int piece = wave + p * Shape::NWAVE;
-            __builtin_amdgcn_global_load_lds((gbl_void*)(Bblk + kbyte + b_off[p]), (lds_void*)(sb + piece * 1024), 16, 0, 0);
-        }
-    };
-
-    AccTile<Shape> acc;
-    acc.m_wave = wm * (BM / Shape::WM);
-    acc.n_wave = wn * (BN / Shape::WN);
-    acc.lane = lane;
-#pragma unroll
-    for (int mi = 0; mi < Shape::TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < Shape::TN; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc.v[mi][ni][r] = 0.f;
-
-    // fragment read offsets: row (l&31) of the wave's sub-tile, chunk (2*ks + (l>>5)) ^ swz(row)
-    const int frow = lane & 31, fh = lane >> 5;
-    const int fswz = (frow >> 1) & 7;  // wave sub-tile bases are multiples of 32, so swz depends on frow only
-    const int a_row_byte = (acc.m_wave + frow) * 128;
-    const int b_row_byte = (acc.n_wave + frow) * 128;
-
-    const int nk = K / BK;
-    stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* sa = smem + cur * Shape::STAGE_BYTES;
-        const char* sb = sa + Shape::A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const int coff = ((2 * ks + fh) ^ fswz) << 4;
-            uint4 af[Shape::TM], bf[Shape::TN];
-#pragma unroll
-            for (int mi = 0; mi < Shape::TM; ++mi) af[mi] = *reinterpret_cast<const uint4*>(sa + a_row_byte + mi * 32 * 128 + coff);
-#pragma unroll
-            for (int ni = 0; ni < Shape::TN; ++ni) bf[ni] = *reinterpret_cast<const uint4*>(sb + b_row_byte + ni * 32 * 128 + coff);
-#pragma unroll
-            for (int mi = 0; mi < Shape::TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < Shape::TN; ++ni) acc.v[mi][ni] = T::mfma(af[mi], bf[ni], acc.v[mi][ni]);
-        }
-        __syncthreads();  // next tile landed (hipcc drains the LDS-DMA with vmcnt(0) here) and this one is free
-    }
-    epi(acc);
-}
-
-// XCD-aware 1-D block id -> (tile_m, tile_n): the tn_count blocks that share one A row-tile get block ids that
-// are equal mod 8 (same XCD under round-robin dispatch -> the A tile is fetched into ONE L2) and adjacent in
-// dispatch order.  Returns false for padding blocks.  Grid size = round_up(tm_count, 8) * tn_count.
-__device__ __forceinline__ bool xcd_tile_map(int64_t bid, int64_t tm_count, int tn_count, int64_t& tm, int& tn) {
-    const int64_t group = bid / (8 * (int64_t)tn_count);
-    const int w = (int)(bid % (8 * (int64_t)tn_count));
-    tm = group * 8 + (w & 7);
-    tn = w >> 3;
-    return tm < tm_count;
-}
-
-
-
 // =====================================================================================================================
-// v2 main loop: PERSISTENT blocks streaming a sequence of output tiles through a 3-stage LDS ring.
+// streaming main loop: PERSISTENT blocks streaming a sequence of output tiles through a 2..4-stage LDS ring.
 //   * the LDS-DMA of K-tile g+2 is issued while K-tile g is multiplied: two tiles stay in flight across the single
 //     raw s_barrier per K-tile, retired by a COUNTED s_waitcnt vmcnt (never 0 in steady state) — cdna_hip_programming.md
 //     "Pipelining across barriers"; the ring runs across output-tile boundaries, so a tile's first K-tiles are already

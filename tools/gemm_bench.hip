@@ -163,24 +163,6 @@ __global__ __launch_bounds__(512, 2) void k_pp_epi(const uint16_t* A, const uint
         });
 }
 
-template <class Shape>
-__global__ __launch_bounds__(Shape::NTHREADS, 2) void k_block(const uint16_t* A, const uint16_t* B, float* out, int64_t M, int64_t N, int K) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int64_t tm; int tn;
-    if (!xcd_tile_map(blockIdx.x, M / Shape::BM, (int)(N / Shape::BN), tm, tn)) return;
-    gemm_nt_block<BF16, Shape>(A, K, M, B, K, N, K, tm * Shape::BM, (int64_t)tn * Shape::BN, smem, [&](AccTile<Shape>& acc) {
-        float s = 0.f;
-#pragma unroll
-        for (int mi = 0; mi < Shape::TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < Shape::TN; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc.v[mi][ni][r];
-        if (s == 12345.678f) out[0] = s;
-        if (threadIdx.x == 0 && tm == 0 && tn == 0) out[1] = acc.v[0][0][0];
-    });
-}
-
 // register-only MFMA loop: what this device sustains with no memory traffic (random operands)
 __global__ __launch_bounds__(256) void k_mfma_only(const uint4* in, float* out, int iters) {
     uint4 a = in[threadIdx.x], b = in[threadIdx.x + 256];
@@ -250,14 +232,6 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL((k_stream<S, ST>), dim3(256 * blocks_per_cu), dim3(S::NTHREADS), lds, 0, A, B, out, sums_ptr, M, N, K); \
         });                                                                                                                 \
     }
-#define BLOCK(bm_, bn_, wm_, wn_)                                                                                               \
-    {                                                                                                                       \
-        using S = GemmShape<bm_, bn_, wm_, wn_>;                                                                            \
-        const int64_t grid = round_up(M / S::BM, 8) * (N / S::BN);                                                          \
-        run("block  " #bm_ "x" #bn_ " waves " #wm_ "x" #wn_ " (v1, 2 bufs)", [&] {                                              \
-            hipLaunchKernelGGL((k_block<S>), dim3((unsigned)grid), dim3(S::NTHREADS), S::LDS_BYTES, 0, A, B, out, M, N, K);  \
-        });                                                                                                                 \
-    }
     uint4* lists; CK(hipMalloc(&lists, (size_t)256 * 65536 * 16));
 #define FILTER(bm_, bn_, wm_, wn_, ST, THR)                                                                               \
     {                                                                                                                       \
@@ -311,7 +285,6 @@ int main(int argc, char** argv) {
     FILTER(256, 256, 2, 4, 2, 1e30f)
     FILTER(256, 256, 2, 4, 2, 55.0f)
     FILTER(256, 256, 2, 4, 2, 45.0f)
-    BLOCK(128, 128, 2, 2)
     STREAM(256, 128, 4, 2, 3)
     STREAM(256, 128, 4, 2, 2)
     STREAM(128, 128, 2, 2, 2)
