@@ -259,7 +259,11 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
     return (x * 0.5f) * (erf_s + 1.0f);
 }
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)BF16::from_f32(lo) | ((uint32_t)BF16::from_f32(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two floats -> packed bf16 pair (lo in bits 0..15): ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
+}
 
 // A 32x32 MFMA accumulator has its COLUMN on the lane, so a direct store writes 2-byte elements (128 store instructions per lane per
 // 256x256 tile, the epilogue then costs as much as a third of the main loop).  Instead every wave owns a private 4-KiB LDS stage
@@ -403,6 +407,7 @@ __global__ __launch_bounds__(256) void k_attn_lds(const uint16_t* __restrict__ q
     // round trip per iteration)
     constexpr int NB = 8;
     const int cpr = nkp >> 2;                             // 8-byte chunks (4 keys) per V^T row
+    const unsigned cpr_magic = cpr ? 0xFFFFFFFFu / (unsigned)cpr + 1u : 0u;
 #pragma unroll
     for (int hs = 0; hs < HPB; ++hs) {
         const int head = hb * HPB + hs;
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(256) void k_attn_lds(const uint16_t* __restrict__ q
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int i = base + j * 256 + tid;
-                const int d = i / cpr, kc = i - d * cpr;
+                const int d = (int)__umulhi((unsigned)i, cpr_magic), kc = i - d * cpr;   // i / cpr (exact: i < 2^16, cpr <= 128)
                 vd[j] = d; vk[j] = kc;
                 vv[j] = make_uint2(0u, 0u);
                 if (i < nvc && kc * 4 < nk) vv[j] = *reinterpret_cast<const uint2*>(vT + (int64_t)(head * 64 + d) * ldv + off + kc * 4);   // off % 4 == 0: 8-B aligned
@@ -482,26 +487,26 @@ __global__ __launch_bounds__(256) void k_attn_lds(const uint16_t* __restrict__ q
                 }
             }
             // register r of this lane is key k0 + (r&3) + 8 (r>>2) + 4 hf, query q0 + c
-            float tmax = -INFINITY;
+            if (k0 + 32 > nk) {   // only the last key tile can hold keys >= nk
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                st[r] = (key < nk) ? st[r] : -INFINITY;
-                tmax = fmaxf(tmax, st[r]);
+                for (int r = 0; r < 16; ++r) st[r] = (k0 + (r & 3) + 8 * (r >> 2) + 4 * hf < nk) ? st[r] : -INFINITY;
             }
+            float tmax = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, st[r]), st[r + 1]);   // v_max3_f32
+            tmax = fmaxf(tmax, st[15]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float mnew = fmaxf(m, tmax);
-            const float mref = (mnew == -INFINITY) ? 0.f : mnew;
-            const float alpha = exp2f((m - mref) * LOG2E);
+            const float mL = ((mnew == -INFINITY) ? 0.f : mnew) * LOG2E;
+            const float alpha = __builtin_amdgcn_exp2f(fmaf(m, LOG2E, -mL));        // arguments <= 0: no overflow; exp2(-inf) = 0
             float psum = 0.f;
             float p[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = exp2f((st[r] - mref) * LOG2E); psum += p[r]; }
+            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(st[r], LOG2E, -mL)); psum += p[r]; }
             psum += __shfl_xor(psum, 32, 64);
             l = l * alpha + psum;
             m = mnew;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            o0 *= alpha; o1 *= alpha;
             // O^T += V^T . P^T : P^T from the accumulator (k-step s2 = registers 8 s2 .. 8 s2 + 7, element j = key 16 s2 + 8 (j>>2) + 4 hf + (j&3));
             // the V^T fragment uses the same key order: elements 0..3 = keys kb .. kb+3, 4..7 = keys kb+8 .. kb+11, kb = k0 + 16 s2 + 4 hf
 #pragma unroll
