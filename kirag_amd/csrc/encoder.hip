@@ -4,7 +4,8 @@
 // Layout.  The [B,S] batch is PACKED on the device: only positions with attention_mask != 0 become token rows
 // (sequence b owns rows [off_b, off_b + nq_b), off_b % 4 == 0; absolute position ids are kept per token), so the
 // projections run on sum(len) rows instead of B*S.  No host round trip: grids are sized for B*(S+4) rows and blocks
-// beyond the device-side total exit.  Residual stream fp32 (xf), MFMA operands bf16 (xb, q, k, vT, ctx, h),
+// beyond the device-side total exit.  Residual stream = bf16 pair xb (hi, also the MFMA operand) + xlo (bf16 of the remainder: 16
+// mantissa bits together, 4 B per element like fp32 but only the hi half is re-read by the GEMMs), MFMA operands bf16 (xb, q, k, vT, ctx, h),
 // fp32 accumulation everywhere.
 //
 // Per layer (post-LN BERT):  ONE GEMM [Wq/8|Wk|Wv] x -> q, k (row-major) and v TRANSPOSED [H, T] (so that attention reads
@@ -58,7 +59,8 @@ struct Encoder {
     int64_t *d_ids = nullptr, *d_mask = nullptr;
     int *seq_off = nullptr, *seq_nk = nullptr, *seq_nq = nullptr, *seq_cls = nullptr, *seq_has0 = nullptr, *d_T = nullptr, *d_err = nullptr;
     int *tok_id = nullptr, *tok_pos = nullptr;
-    float *xf = nullptr, *out = nullptr;
+    float *out = nullptr;
+    uint16_t *xlo = nullptr;   // low half of the residual stream (see file header)
     uint16_t *y = nullptr, *xb = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *ctx = nullptr, *h = nullptr;
     int lastB = 0, lastS = 0;
     int num_cu = 256;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ 
 
 // LayerNorm of one row held as up to 8 float4 per lane (H <= 2048); writes fp32 and bf16 copies
 __device__ __forceinline__ void ln_row_store(float4 (&v)[8], int H, int lane, const float* __restrict__ g, const float* __restrict__ bta, float eps,
-                                             float* __restrict__ xf_row, uint16_t* __restrict__ xb_row) {
+                                             uint16_t* __restrict__ xlo_row, uint16_t* __restrict__ xb_row) {
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) if (lane * 4 + j * 256 < H) s += v[j].x + v[j].y + v[j].z + v[j].w;
@@ -175,10 +177,13 @@ __device__ __forceinline__ void ln_row_store(float4 (&v)[8], int H, int lane, co
             float4 o;
             o.x = (v[j].x - mu) * rstd * gg.x + bb.x; o.y = (v[j].y - mu) * rstd * gg.y + bb.y;
             o.z = (v[j].z - mu) * rstd * gg.z + bb.z; o.w = (v[j].w - mu) * rstd * gg.w + bb.w;
-            *reinterpret_cast<float4*>(xf_row + i) = o;
-            ushort4 ob;
+            // o = hi + lo with hi = bf16(o), lo = bf16(o - hi): |o - (hi + lo)| <= 2^-18 |o|
+            ushort4 ob, ol;
             ob.x = BF16::from_f32(o.x); ob.y = BF16::from_f32(o.y); ob.z = BF16::from_f32(o.z); ob.w = BF16::from_f32(o.w);
+            ol.x = BF16::from_f32(o.x - BF16::to_f32(ob.x)); ol.y = BF16::from_f32(o.y - BF16::to_f32(ob.y));
+            ol.z = BF16::from_f32(o.z - BF16::to_f32(ob.z)); ol.w = BF16::from_f32(o.w - BF16::to_f32(ob.w));
             *reinterpret_cast<ushort4*>(xb_row + i) = ob;
+            *reinterpret_cast<ushort4*>(xlo_row + i) = ol;
         }
     }
 }
@@ -187,7 +192,7 @@ __device__ __forceinline__ void ln_row_store(float4 (&v)[8], int H, int lane, co
 __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id, const int* __restrict__ tok_pos, const int* __restrict__ Tp,
                                                   const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
                                                   const float* __restrict__ g, const float* __restrict__ bta, float eps, int H,
-                                                  float* __restrict__ xf, uint16_t* __restrict__ xb) {
+                                                  uint16_t* __restrict__ xlo, uint16_t* __restrict__ xb) {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= *Tp) return;
@@ -205,12 +210,12 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id
             v[j] = make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
         }
     }
-    ln_row_store(v, H, lane, g, bta, eps, xf + t * H, xb + t * H);
+    ln_row_store(v, H, lane, g, bta, eps, xlo + t * H, xb + t * H);
 }
 
-// LayerNorm(y + xf) -> xf, xb     (one wave per token; y holds dense + bias as bf16, xf the fp32 residual stream, updated in place)
+// LayerNorm(y + (xb + xlo)) -> xb, xlo     (one wave per token; y holds dense + bias as bf16, xb + xlo the residual stream, updated in place)
 __global__ __launch_bounds__(256) void k_ln(const uint16_t* __restrict__ y, const int* __restrict__ Tp, const float* __restrict__ g,
-                                            const float* __restrict__ bta, float eps, int H, float* xf, uint16_t* __restrict__ xb) {
+                                            const float* __restrict__ bta, float eps, int H, uint16_t* xlo, uint16_t* xb) {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= *Tp) return;
@@ -221,11 +226,13 @@ __global__ __launch_bounds__(256) void k_ln(const uint16_t* __restrict__ y, cons
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < H) {
             const ushort4 a = *reinterpret_cast<const ushort4*>(y + t * H + i);
-            const float4 r = *reinterpret_cast<const float4*>(xf + t * H + i);
-            v[j] = make_float4(BF16::to_f32(a.x) + r.x, BF16::to_f32(a.y) + r.y, BF16::to_f32(a.z) + r.z, BF16::to_f32(a.w) + r.w);
+            const ushort4 rh = *reinterpret_cast<const ushort4*>(xb + t * H + i);
+            const ushort4 rl = *reinterpret_cast<const ushort4*>(xlo + t * H + i);
+            v[j] = make_float4(BF16::to_f32(a.x) + (BF16::to_f32(rh.x) + BF16::to_f32(rl.x)), BF16::to_f32(a.y) + (BF16::to_f32(rh.y) + BF16::to_f32(rl.y)),
+                               BF16::to_f32(a.z) + (BF16::to_f32(rh.z) + BF16::to_f32(rl.z)), BF16::to_f32(a.w) + (BF16::to_f32(rh.w) + BF16::to_f32(rl.w)));
         }
     }
-    ln_row_store(v, H, lane, g, bta, eps, xf + t * H, xb + t * H);
+    ln_row_store(v, H, lane, g, bta, eps, xlo + t * H, xb + t * H);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(256) void k_attn_lds(const uint16_t* __restrict__ q
 }
 
 // pooling + L2 normalisation: one block per sequence
-__global__ __launch_bounds__(256) void k_pool(const float* __restrict__ xf, const int* __restrict__ seq_off, const int* __restrict__ seq_nk,
+__global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, const uint16_t* __restrict__ xlo, const int* __restrict__ seq_off, const int* __restrict__ seq_nk,
                                               const int* __restrict__ seq_cls, int H, int pool, float* __restrict__ out) {
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -559,10 +566,10 @@ __global__ __launch_bounds__(256) void k_pool(const float* __restrict__ xf, cons
         v[j] = 0.f;
         if (i < H) {
             if (pool == KR_POOL_CLS) {
-                v[j] = xf[(off + seq_cls[b]) * H + i];
+                v[j] = BF16::to_f32(xb[(off + seq_cls[b]) * H + i]) + BF16::to_f32(xlo[(off + seq_cls[b]) * H + i]);
             } else {
                 float s = 0.f;
-                for (int t = 0; t < nk; ++t) s += xf[(off + t) * H + i];
+                for (int t = 0; t < nk; ++t) s += BF16::to_f32(xb[(off + t) * H + i]) + BF16::to_f32(xlo[(off + t) * H + i]);
                 v[j] = s / (float)nk;   // nk == 0 -> 0/0 = NaN like average_pool (encoders.py:56-58)
             }
             ss += v[j] * v[j];
@@ -591,11 +598,11 @@ static int dmalloc(P** p, size_t bytes) {
 }
 
 static void free_ws(Encoder* e) {
-    void* ptrs[] = {e->d_ids, e->d_mask, e->seq_off, e->seq_nk, e->seq_nq, e->seq_cls, e->seq_has0, e->tok_id, e->tok_pos, e->xf, e->y, e->out,
+    void* ptrs[] = {e->d_ids, e->d_mask, e->seq_off, e->seq_nk, e->seq_nq, e->seq_cls, e->seq_has0, e->tok_id, e->tok_pos, e->xlo, e->y, e->out,
                     e->xb, e->q, e->k, e->vT, e->ctx, e->h};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     e->d_ids = e->d_mask = nullptr; e->seq_off = e->seq_nk = e->seq_nq = e->seq_cls = e->seq_has0 = nullptr; e->tok_id = e->tok_pos = nullptr;
-    e->xf = e->out = nullptr; e->y = e->xb = e->q = e->k = e->vT = e->ctx = e->h = nullptr;
+    e->out = nullptr; e->xlo = e->y = e->xb = e->q = e->k = e->vT = e->ctx = e->h = nullptr;
     e->capT = 0; e->capB = 0; e->capBS = 0;
 }
 
@@ -609,7 +616,7 @@ static int ensure_ws(Encoder* e, int B, int S) {
     KR_TRY(dmalloc(&e->d_ids, capBS * 8)); KR_TRY(dmalloc(&e->d_mask, capBS * 8));
     KR_TRY(dmalloc(&e->seq_off, capB * 4)); KR_TRY(dmalloc(&e->seq_nk, capB * 4)); KR_TRY(dmalloc(&e->seq_nq, capB * 4)); KR_TRY(dmalloc(&e->seq_cls, capB * 4)); KR_TRY(dmalloc(&e->seq_has0, capB * 4));
     KR_TRY(dmalloc(&e->tok_id, capT * 4)); KR_TRY(dmalloc(&e->tok_pos, capT * 4));
-    KR_TRY(dmalloc(&e->xf, capT * H * 4)); KR_TRY(dmalloc(&e->y, capT * H * 2)); KR_TRY(dmalloc(&e->out, (size_t)capB * H * 4));
+    KR_TRY(dmalloc(&e->xlo, capT * H * 2)); KR_TRY(dmalloc(&e->y, capT * H * 2)); KR_TRY(dmalloc(&e->out, (size_t)capB * H * 4));
     KR_TRY(dmalloc(&e->xb, capT * H * 2)); KR_TRY(dmalloc(&e->q, capT * H * 2)); KR_TRY(dmalloc(&e->k, capT * H * 2));
     e->ldv = capT + 64;   // slack: the last key tile of the last sequence may read up to 43 columns past T
     KR_TRY(dmalloc(&e->vT, (size_t)H * e->ldv * 2));
@@ -847,7 +854,7 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
     const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + 3) & ~3);   // upper bound of the packed token count (each sequence is padded to 4)
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
-                       e->xf, e->xb);
+                       e->xlo, e->xb);
     for (const LayerW& l : e->L) {
         ProjArgs a{};
         a.Tp = e->d_T; a.H = H;
@@ -864,16 +871,16 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, st));
-        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln1g, l.ln1b, eps, H, e->xf, e->xb);
+        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln1g, l.ln1b, eps, H, e->xlo, e->xb);
         // intermediate.dense + GELU
         a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h;
         KR_TRY(launch_proj(EPI_GELU, a, maxT, e->num_cu, st));
         // output.dense + residual -> LayerNorm
         a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->y;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, st));
-        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln2g, l.ln2b, eps, H, e->xf, e->xb);
+        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln2g, l.ln2b, eps, H, e->xlo, e->xb);
     }
-    hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xf, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);
+    hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);
     KR_HIP(hipGetLastError());
     KR_HIP(hipMemcpyAsync(out, e->out, (size_t)B * H * 4, hipMemcpyDefault, st));
     int err = 0;
@@ -899,7 +906,13 @@ int kr_encoder_last_hidden(kr_encoder* h, float* out, int B, int S) {
     std::vector<int> pos(T);
     std::vector<float> x((size_t)T * H);
     KR_HIP(hipMemcpy(pos.data(), e->tok_pos, (size_t)T * 4, hipMemcpyDeviceToHost));
-    KR_HIP(hipMemcpy(x.data(), e->xf, (size_t)T * H * 4, hipMemcpyDeviceToHost));
+    {   // the residual stream is stored as a bf16 (hi, lo) pair
+        std::vector<uint16_t> hi((size_t)T * H), lo((size_t)T * H);
+        KR_HIP(hipMemcpy(hi.data(), e->xb, hi.size() * 2, hipMemcpyDeviceToHost));
+        KR_HIP(hipMemcpy(lo.data(), e->xlo, lo.size() * 2, hipMemcpyDeviceToHost));
+        auto f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float v; std::memcpy(&v, &u, 4); return v; };
+        for (size_t i = 0; i < x.size(); ++i) x[i] = f(hi[i]) + f(lo[i]);
+    }
     std::vector<float> full((size_t)B * S * H, 0.f);
     for (int b = 0; b < B; ++b)
         for (int i = 0; i < nq[b]; ++i)
