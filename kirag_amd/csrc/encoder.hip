@@ -280,6 +280,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 //   V^T:   each 32x32 tile is written TRANSPOSED ([feature][token], 4 consecutive tokens of a lane packed into 8 B, 80-B rows) and
 //          read back 16 B per lane: a store instruction writes 64-B runs of sixteen V^T rows.
 constexpr int EPI_STAGE_BYTES = 4096;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // Both helpers take the SWAPPED accumulator layout of gemm_nt_pingpong<.., true> / gemm_nt_stream_swapped: tile (mi, ni), register r,
 // lane (c = l & 31, h = l >> 5) is token mi*32 + c, feature ni*32 + (r & 3) + 8 (r >> 2) + 4 h of the wave's (TM*32 tokens) x (TN*32 features).
@@ -306,7 +307,7 @@ __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage
         for (int p = 0; p < 4; ++p) {
             const int rl = p * 8 + (acc.lane >> 3), ch = acc.lane & 7;
             const uint4 d = *reinterpret_cast<const uint4*>(stage + rl * 128 + ((ch ^ (rl & 7)) << 4));
-            *reinterpret_cast<uint4*>(out + (row0 + mi * 32 + rl) * ld + col0 + ch * 8) = d;
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d), reinterpret_cast<u32x4_t*>(out + (row0 + mi * 32 + rl) * ld + col0 + ch * 8));
         }
     }
 }
@@ -327,7 +328,7 @@ __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char*
             for (int p = 0; p < 2; ++p) {
                 const int fl = p * 16 + (acc.lane >> 2), ch = acc.lane & 3;
                 const uint4 d = *reinterpret_cast<const uint4*>(stage + fl * 80 + ch * 16);
-                *reinterpret_cast<uint4*>(outT + (int64_t)(f0 + ni * 32 + fl) * ldT + t0 + mi * 32 + ch * 8) = d;
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d), reinterpret_cast<u32x4_t*>(outT + (int64_t)(f0 + ni * 32 + fl) * ldT + t0 + mi * 32 + ch * 8));
             }
         }
 }
