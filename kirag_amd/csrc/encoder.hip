@@ -678,7 +678,8 @@ template <int HPB>
 static int launch_attn(const Encoder* e, int B, int cap, hipStream_t st) {
     const int H = e->cfg.hidden, heads = e->cfg.heads;
     const int lds = HPB * (cap * 128 + 64 * (cap * 2 + 8)) + 4 * 4096;
-    static int attr_lds = 0;
+    static int attr_lds_dev[64] = {};   // per device: function attributes belong to the device's code object instance
+    int& attr_lds = attr_lds_dev[e->device & 63];
     if (lds > attr_lds) {
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_lds<HPB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_lds = lds;
@@ -689,9 +690,10 @@ static int launch_attn(const Encoder* e, int B, int cap, hipStream_t st) {
 }
 
 template <class Shape, int STAGES>
-static int launch_proj_shape(int epi, const ProjArgs& a, int blocks, hipStream_t st) {
+static int launch_proj_shape(int epi, const ProjArgs& a, int blocks, int device, hipStream_t st) {
     constexpr int lds = STAGES * Shape::STAGE_BYTES + Shape::NWAVE * EPI_STAGE_BYTES;   // 160 KiB for the 256x256 tile: the whole LDS of a CU
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};
+    bool& attr_set = attr_set_dev[device & 63];
     if (!attr_set) {
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_QKV, Shape, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_DENSE, Shape, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -706,15 +708,15 @@ static int launch_proj_shape(int epi, const ProjArgs& a, int blocks, hipStream_t
 
 // tile shape per launch: when the 256x256 tiling has fewer tiles than ~5/8 of the CUs (small batches: the reference's per_gpu_batch_size 4-8, the KiRAG
 // loop's triple batches, a 1/8 slice of a query batch) the 128x128 tiling gives 4x the parallelism at a quarter of the per-tile latency
-static int launch_proj(int epi, const ProjArgs& a, int64_t max_tokens, int num_cu, hipStream_t st) {
+static int launch_proj(int epi, const ProjArgs& a, int64_t max_tokens, int num_cu, int device, hipStream_t st) {
     const int64_t big_tiles = ((max_tokens + 255) / 256) * ((a.F + 255) / 256);
     const int64_t small_tiles = ((max_tokens + 127) / 128) * ((a.F + 127) / 128);
     const char* fe = getenv("KIRAG_AMD_PROJ_TILE");   // 128 / 256 force a path (tests run every parity case through both); read per call
     const int force = fe ? atoi(fe) : 0;
     const bool small = force == 128 || (force != 256 && big_tiles * 8 < (int64_t)num_cu * 5);   // measured crossover: ~5/8 of the CUs busy with 256x256 tiles
-    if (!small) return launch_proj_shape<ShapeBig, 2>(epi, a, num_cu, st);
-    if (small_tiles <= num_cu && force != 128) return launch_proj_shape<ShapeSmall, 4>(epi, a, num_cu, st);
-    return launch_proj_shape<ShapeSmall, 2>(epi, a, 2 * num_cu, st);
+    if (!small) return launch_proj_shape<ShapeBig, 2>(epi, a, num_cu, device, st);
+    if (small_tiles <= num_cu && force != 128) return launch_proj_shape<ShapeSmall, 4>(epi, a, num_cu, device, st);
+    return launch_proj_shape<ShapeSmall, 2>(epi, a, 2 * num_cu, device, st);
 }
 
 }  // namespace kr
@@ -861,7 +863,7 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         a.Tp = e->d_T; a.H = H;
         // q | k | v^T in one GEMM (F = 3H)
         a.W = l.wqkv; a.X = e->xb; a.F = 3 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k; a.outT = e->vT; a.ldT = e->ldv;
-        KR_TRY(launch_proj(EPI_QKV, a, maxT, e->num_cu, st));
+        KR_TRY(launch_proj(EPI_QKV, a, maxT, e->num_cu, e->device, st));
         {
             const int cap = (int)round_up(S, 32);
             const int nqt = (S + (pool == KR_POOL_CLS ? 1 : 0) + 31) / 32;      // q-tiles of the longest possible sequence
@@ -871,14 +873,14 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         }
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y;
-        KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, st));
+        KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
         hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln1g, l.ln1b, eps, H, e->xlo, e->xb);
         // intermediate.dense + GELU
         a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h;
-        KR_TRY(launch_proj(EPI_GELU, a, maxT, e->num_cu, st));
+        KR_TRY(launch_proj(EPI_GELU, a, maxT, e->num_cu, e->device, st));
         // output.dense + residual -> LayerNorm
         a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->y;
-        KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, st));
+        KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
         hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln2g, l.ln2b, eps, H, e->xlo, e->xb);
     }
     hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);

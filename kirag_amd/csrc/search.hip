@@ -572,7 +572,8 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         while (gcd64(mul, a.ntiles) != 1) ++mul;
         a.perm_mul = mul % a.ntiles; if (a.perm_mul == 0) a.perm_mul = 1;
         constexpr int lds = COARSE_LDS;
-        static bool attr_set = false;
+        static bool attr_set_dev[64] = {};   // per device: function attributes belong to the device's code object instance
+        bool& attr_set = attr_set_dev[ix->device & 63];
         if (!attr_set) {
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -580,7 +581,8 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         }
         const size_t sel_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int);
         const size_t rer_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + (size_t)RERANK_MAX * sizeof(uint64_t) + 264 * sizeof(unsigned int);
-        static bool sel_attr_set = false;
+        static bool sel_attr_set_dev[64] = {};
+        bool& sel_attr_set = sel_attr_set_dev[ix->device & 63];
         if (!sel_attr_set) {   // cap = 8192 needs 64 KiB + 16 B of dynamic LDS
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + RERANK_MAX * 8 + 264 * 4));
