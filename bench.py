@@ -188,6 +188,18 @@ def main():
         enc_info = {"passages_per_s": args.passages * world * args.steps / te, "batch": args.passages, "tokens": args.passage_tokens,
                     "tflops_per_gpu": fl * args.steps / te / 1e12, "frac_of_mfma_peak": fl * args.steps / te / PEAK_MFMA_DENSE_16BIT,
                     "algorithmic_gflop_per_passage": fl / args.passages / 1e9}
+        # same batch with ragged lengths (clip(N(0.86 S, 0.2 S), 16, S)): the encoder packs attended tokens, padding costs no FLOPs
+        rag_ids, rag_mask = BS.synthetic_tokens(dev, args.passages, args.passage_tokens, seed=1, ragged=True)
+        encoder.forward(rag_ids, rag_mask, 0)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            encoder.forward(rag_ids, rag_mask, 0)
+        torch.cuda.synchronize()
+        tr = time.perf_counter() - t2
+        flr = BS.encoder_flops(encoder.cfg, rag_mask.sum(1))
+        enc_info["ragged"] = {"passages_per_s_per_gpu": args.passages * args.steps / tr, "mean_tokens": float(rag_mask.sum(1).float().mean().item()),
+                              "tflops_per_gpu": flr * args.steps / tr / 1e12}
 
     if rank == 0:
         st = index.stats()
