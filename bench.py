@@ -239,7 +239,7 @@ def main():
             "encode": enc_info,
             "search_stats": {kk: st[kk] for kk in ("queries", "certified", "fallback", "overflow", "reranked_rows", "coarse_rounds")},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(args, q_vec.cpu().numpy(), encoder is not None)
         print(json.dumps(out))
     if world > 1:
