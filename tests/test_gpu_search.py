@@ -220,3 +220,24 @@ def test_k_200_uses_large_candidate_buffers():
     s, i = ix.index.search(q, 600)            # beyond the fast path: exact scan
     so, io = S.search_f64(q, x, 600)
     assert np.array_equal(i, io) and np.array_equal(s, so)
+
+
+def test_seeded_random_shape_sweep_vs_canonical():
+    """30 seeded random (n, d, nq, k) combinations — d any multiple of 4 (dpad padding), nq across the 256-query tile and the 1024-query block
+    boundary, k up to the fast path's limit and beyond (exact-scan path), clustered data (dense near-ties) — all bit-exact vs the oracle."""
+    rng = np.random.default_rng(2026)
+    for case in range(30):
+        d = int(rng.choice([4, 20, 64, 100, 256, 384, 768, 1024, 1500]))
+        n = int(rng.integers(1, 9000))
+        nq = int(rng.choice([1, 2, 3, 31, 255, 256, 257, 700, 1025, 1100])) if case % 3 == 0 else int(rng.integers(1, 300))
+        k = int(min(n, rng.choice([1, 5, 10, 20, 100, 204, 205, 400])))
+        x = _unit(rng, n, d)
+        if case % 4 == 1 and n > 50:                       # a tight cluster: many scores within the 16-bit resolution
+            x[: n // 2] = x[0] + 1e-3 * rng.standard_normal((n // 2, d)).astype(np.float32)
+            x /= np.linalg.norm(x, axis=1, keepdims=True)
+        q, _ = _queries_near(rng, x, nq)
+        ix = _mk(d, x)
+        s, i = ix.index.search(q, k)
+        so, io = S.search_canonical(q, x, k)
+        assert np.array_equal(i, io), (case, n, d, nq, k)
+        assert np.array_equal(s.view(np.uint32), so.view(np.uint32)), (case, n, d, nq, k)
