@@ -66,13 +66,34 @@ __device__ __forceinline__ int64_t xcd_chunk_map(int64_t v, int64_t total) {
     return x * q + (x < r ? x : r) + j;
 }
 
-// natural index -> (tm, tn) such that 8 consecutive tn of one tm-run are adjacent: groups of (up to) 8 tn, tm walks inside a group
+// exact n / d and n % d for n < 2^24, 0 < d (fp32 reciprocal + one correction step): ~10 VALU.  The tile coordinates are recomputed at
+// every output-tile boundary by every wave (three times: two DMA cursors + the epilogue); a 64-bit integer division costs ~150 VALU
+// instructions each and sat in the boundary's critical path (PMC: 900 VALU per tile per wave, of which the epilogue itself is 211).
+__device__ __forceinline__ void fast_divmod(uint32_t n, uint32_t d, uint32_t& q, uint32_t& r) {
+    q = (uint32_t)((float)n * __builtin_amdgcn_rcpf((float)d));
+    r = n - q * d;
+    if ((int32_t)r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
+// exact n / d and n % d for n < 2^53 (fp64 reciprocal + one correction step)
+__device__ __forceinline__ void fast_divmod64(uint64_t n, uint32_t d, uint64_t& q, uint32_t& r) {
+    q = (uint64_t)((double)n * (1.0 / (double)d));
+    int64_t rr = (int64_t)(n - q * (uint64_t)d);
+    if (rr < 0) { --q; rr += d; }
+    else if (rr >= (int64_t)d) { ++q; rr -= d; }
+    r = (uint32_t)rr;
+}
+
+// natural index -> (tm, tn) such that 8 consecutive tn of one tm-run are adjacent: groups of (up to) 8 tn, tm walks inside a group.
+// Tile counts are far below 2^24 (a 2^32-row shard has 2^24 256-row tiles only together with 1 column tile).
 __device__ __forceinline__ void patch_coord(int64_t n, int64_t tm_count, int64_t tn_count, int64_t& tm, int64_t& tn) {
-    const int64_t g = n / (8 * tm_count);
-    const int64_t rem = n - g * 8 * tm_count;
-    const int64_t gs = (tn_count - 8 * g) < 8 ? (tn_count - 8 * g) : 8;
-    tm = rem / gs;
-    tn = 8 * g + rem % gs;
+    uint32_t g, rem, q, r;
+    fast_divmod((uint32_t)n, 8u * (uint32_t)tm_count, g, rem);
+    const uint32_t left = (uint32_t)tn_count - 8u * g;
+    const uint32_t gs = left < 8u ? left : 8u;
+    fast_divmod(rem, gs, q, r);
+    tm = q;
+    tn = 8u * g + r;
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
