@@ -85,7 +85,7 @@ __device__ __forceinline__ void fast_divmod64(uint64_t n, uint32_t d, uint64_t& 
 }
 
 // natural index -> (tm, tn) such that 8 consecutive tn of one tm-run are adjacent: groups of (up to) 8 tn, tm walks inside a group.
-// Tile counts are far below 2^24 (a 2^32-row shard has 2^24 256-row tiles only together with 1 column tile).
+// Used by the encoder projections only: at most 65535 x 512 tokens = 131k token tiles x 16 feature tiles = 2^21 tiles < 2^24.
 __device__ __forceinline__ void patch_coord(int64_t n, int64_t tm_count, int64_t tn_count, int64_t& tm, int64_t& tn) {
     uint32_t g, rem, q, r;
     fast_divmod((uint32_t)n, 8u * (uint32_t)tm_count, g, rem);

@@ -181,9 +181,10 @@ __global__ __launch_bounds__(ShapeC::NTHREADS, 2) void k_coarse(CoarseArgs a) {
     gemm_nt_pingpong<T, false, true>(
         a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
-            uint32_t tslot, tn, tile; uint64_t qq;                        // the query blocks of one corpus tile are adjacent
-            fast_divmod((uint32_t)nat, (uint32_t)tn_count, tslot, tn);   // (no 64-bit integer divisions: they cost ~150 VALU each, per tile, per wave)
-            fast_divmod64((uint64_t)(a.tile_begin + tslot) * (uint64_t)a.perm_mul, (uint32_t)a.ntiles, qq, tile);
+            uint32_t tn, tile; uint64_t tslot, qq;                        // the query blocks of one corpus tile are adjacent
+            // no 64-bit integer divisions (~150 VALU each, per tile, per wave); the fp64 form is exact below 2^53, which covers a 2^32-row shard
+            fast_divmod64((uint64_t)nat, (uint32_t)tn_count, tslot, tn);
+            fast_divmod64((uint64_t)(a.tile_begin + (int64_t)tslot) * (uint64_t)a.perm_mul, (uint32_t)a.ntiles, qq, tile);
             m0 = (int64_t)tile * ShapeC::BM; n0 = (int64_t)tn * ShapeC::BN;
         },
         [&](AccTile<ShapeC>& acc, int64_t m0, int64_t n0, int64_t nat) {
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(ShapeC::NTHREADS, 2) void k_coarse(CoarseArgs a) {
                 for (int ni = 0; ni < ShapeC::TN; ++ni) {
                     const int q = (int)n0 + acc.col(ni);
                     if (q < a.nq) {
-                        uint32_t tslot_d, tn_d; fast_divmod((uint32_t)nat, (uint32_t)tn_count, tslot_d, tn_d);
+                        uint64_t tslot_d; uint32_t tn_d; fast_divmod64((uint64_t)nat, (uint32_t)tn_count, tslot_d, tn_d);
                         uint64_t* cq = a.cand + (int64_t)q * a.cand_cap + (int64_t)tslot_d * ShapeC::BM + lane_row0;
 #pragma unroll
                         for (int mi = 0; mi < ShapeC::TM; ++mi)
