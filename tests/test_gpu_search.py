@@ -241,3 +241,34 @@ def test_seeded_random_shape_sweep_vs_canonical():
         so, io = S.search_canonical(q, x, k)
         assert np.array_equal(i, io), (case, n, d, nq, k)
         assert np.array_equal(s.view(np.uint32), so.view(np.uint32)), (case, n, d, nq, k)
+
+
+def test_many_rows_small_dim_tile_permutation_64bit():
+    """24M rows x d=4: 93750 corpus tiles, so (tile slot x permutation multiplier) exceeds 2^32 and the multi-round schedule runs 5 rounds:
+    exercises the tile-coordinate arithmetic of the coarse scan at a row count no d=1024 shard reaches.  Each query has 50 planted rows
+    (scaled copies of the query, scattered over the whole row range incl. the last tile) far above the background (norm 0.5), so the fast path
+    must certify: a tile that the permutation skipped or visited twice would lose / duplicate a planted row.  Bit-exact vs the oracle."""
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 24_000_000, 4, 8, 50
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    x *= (0.5 / np.linalg.norm(x, axis=1, keepdims=True))
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    pos = rng.choice(n - 1, nq * k - 1, replace=False).reshape(-1)
+    pos = np.concatenate([pos, [n - 1]]).reshape(nq, k)            # one planted row is the very last row
+    for qi in range(nq):
+        for j in range(k):
+            x[pos[qi, j]] = q[qi] * np.float32(1.0 - 1e-3 * j)
+    from kirag_amd.retriever.index import FlatIPIndex
+    ix = FlatIPIndex(d)
+    ix.reserve(n)
+    for s0 in range(0, n, 4_000_000):
+        ix.add(x[s0:s0 + 4_000_000])
+    s, i = ix.search(q, k)
+    so, io = S.search_canonical(q, x, k)
+    st = ix.stats()
+    print(f"[24M x 4] certified {st['certified']} fallback {st['fallback']} rounds {st['coarse_rounds']}")
+    assert np.array_equal(i, io)
+    assert np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    assert np.array_equal(np.sort(i, axis=1), np.sort(pos, axis=1))
+    assert st["certified"] == nq and st["fallback"] == 0 and st["coarse_rounds"] == 5
