@@ -21,4 +21,4 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 fl = BS.encoder_flops(enc.cfg, mask.sum(1))
-print(f"PROJ={os.environ.get('KIRAG_AMD_PROJ','bbbb')} n={n} S={S} ragged={ragged}: {dt*1e3:.2f} ms  {n/dt:.0f} seq/s  {fl/dt/1e12:.0f} TFLOP/s")
+print(f"tile={os.environ.get('KIRAG_AMD_PROJ_TILE','auto')} n={n} S={S} ragged={ragged}: {dt*1e3:.2f} ms  {n/dt:.0f} seq/s  {fl/dt/1e12:.0f} TFLOP/s")
