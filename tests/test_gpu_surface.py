@@ -115,3 +115,48 @@ def test_corpus_encode_files_index_and_search(golden, tmp_path):
         so, io = S.search_canonical(q, x, 3)
         for r in range(3):
             assert res[r][0] == [str(3 * j + 10) for j in io[r]] and np.array_equal(res[r][1], so[r])
+
+
+def test_setup_retriever_model_wiring(golden, tmp_path):
+    """retrieve.py:86-118 on the HIP path: index folder written by the corpus-encode + index-build entry points, loaded back through
+    setup_retriever_model, queried through DenseRetriever.__call__ with a corpus object; results equal the oracle on the stored embeddings."""
+    from kirag_amd import compute_corpus_embeddings as CC
+    from kirag_amd import faiss_index_corpus as FI
+    from kirag_amd.collators import E5Collator
+    from kirag_amd.retrieve import setup_retriever_model
+    from kirag_amd.retriever import e5 as e5mod
+    from kirag_amd.retriever.retrievers import InBatchRetriever
+    with tempfile.TemporaryDirectory() as td:
+        g, tok, w, heads = _setup(td, golden)
+        rng = np.random.default_rng(3)
+        words = [str(v) for v in g["vocab"] if str(v).isalpha() and len(str(v)) > 1]
+
+        class Corpus:
+            def __init__(self, n):
+                self.p = ["title:  " + " ".join(rng.choice(words, 2)) + ", text:  " + " ".join(rng.choice(words, int(rng.integers(3, 25)))) for _ in range(n)]
+                self.index_to_passage_id = {i: str(7 * i + 1) for i in range(n)}
+            def __len__(self): return len(self.p)
+            def __getitem__(self, i): return {"index": i, "passage": self.p[i]}
+            def get_document(self, docid): return {"id": docid, "text": self.p[(int(docid) - 1) // 7]}
+        corpus = Corpus(120)
+        ret = InBatchRetriever("E5Retriever", td, temperature=0.01)
+        col = E5Collator(tokenizer=tok, query_maxlength=16, doc_maxlength=32)
+        enc_args = SimpleNamespace(local_rank=-1, save_dir=str(tmp_path), name="e5", index_folder="c", per_gpu_batch_size=8,
+                                   num_passage_per_index_file=1000, encode_batch_size=64)
+        CC.cal_doc_embeddings(enc_args, ret, corpus, col)
+        folder = os.path.join(str(tmp_path), "e5", "c")
+        FI.build_faiss_index(SimpleNamespace(index_folder=folder, embedding_size=ret.hidden_size))
+        args = SimpleNamespace(retriever_name="E5Retriever", tokenizer_name_or_path=td, query_maxlength=16, doc_maxlength=32,
+                               retriever_model_name_or_path=td, local_rank=-1, corpus="unused", index_folder=folder,
+                               embedding_size=ret.hidden_size, per_gpu_batch_size=8)
+        dr, cds = setup_retriever_model(args, corpus_dataset=corpus, tokenizer=tok)
+        assert cds is corpus and dr.indexer.index.ntotal == 120 and e5mod.model is dr.retriever.encoder
+        qs = [corpus.p[40].split("text:  ")[1], "capital of france"]
+        out = dr(qs, topk=4)
+        single = dr(qs[0], topk=4)
+        assert single == out[0]
+        x = dr.indexer.index.reconstruct_n(0, 120)
+        so, io = S.search_canonical(dr.calculate_query_embeddings(qs).numpy(), x, 4)
+        for r in range(2):
+            assert [d["id"] for d in out[r]] == [str(7 * j + 1) for j in io[r]]
+            assert all(isinstance(d["score"], float) for d in out[r]) and out[r][0]["text"] == corpus.p[io[r][0]]
