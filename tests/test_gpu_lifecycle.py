@@ -1,0 +1,66 @@
+"""Handle life cycle through the C ABI: repeated create / use / destroy of indexes and encoders returns all device memory (no leak), growing an
+index keeps its rows, workspaces adapt to changing query counts / k / batch shapes, and error returns leave handles usable."""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder_np as E
+from oracle import search_np as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_bytes():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+def test_index_create_use_destroy_does_not_leak_and_grows():
+    from kirag_amd.retriever.index import FlatIPIndex
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((6000, 128)).astype(np.float32); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    q = x[:37] + 0.01
+    ref = {}
+    for k in (1, 10, 150):
+        ref[k] = S.search_canonical(q, x, k)
+    ix = FlatIPIndex(128); ix.add(x[:10]); ix.search(q[:1], 1); del ix          # warm every lazily created context / attribute
+    base = _free_bytes()
+    for it in range(12):
+        ix = FlatIPIndex(128)
+        for s0 in range(0, 6000, 1700):                                       # regrowth without reserve(): rows must survive the copies
+            ix.add(x[s0:s0 + 1700])
+        for k in (10, 1, 150, 10):                                            # workspaces re-sized up and down
+            s, i = ix.search(q[: 5 + it], k)
+            assert np.array_equal(i, ref[k][1][: 5 + it]) and np.array_equal(s.view(np.uint32), ref[k][0][: 5 + it].view(np.uint32))
+        with pytest.raises(ValueError):
+            ix.search(q, 7000)                                                # k > ntotal: error, handle still fine
+        s, i = ix.search(q, 10)
+        assert np.array_equal(i, ref[10][1])
+        del ix
+    assert base - _free_bytes() < (8 << 20), f"leaked {(base - _free_bytes()) >> 20} MiB over 12 index life cycles"
+
+
+def test_encoder_create_use_destroy_does_not_leak():
+    from kirag_amd.retriever.encoders import HipBertForward
+    cfg = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
+                          max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    w = E.synth_weights(128, 2, 512, 1000, 512, seed=5)
+    ids, mask = E.synth_tokens(33, 40, seed=1, ragged=True, vocab_lo=5, vocab_hi=1000, min_len=3)
+    ref = E.e5_encode(w, ids, mask, 2)
+    h = HipBertForward(cfg, 0); h.load_state(w); h.forward_np(ids, mask, 0); del h
+    base = _free_bytes()
+    for it in range(8):
+        h = HipBertForward(cfg, 0); h.load_state(w)
+        for B, S_ in ((33, 40), (5, 40), (33, 17), (33, 40)):                  # workspace re-allocation in both directions
+            out = h.forward_np(ids[:B, :S_], mask[:B, :S_], 0)
+            if S_ == 40:
+                assert np.abs(out - ref[:B]).max() < 4e-3
+        bad = ids.copy(); bad[0, 0] = 5000
+        with pytest.raises(Exception):
+            h.forward_np(bad, mask, 0)                                        # token id out of range: error, handle still usable
+        assert np.abs(h.forward_np(ids, mask, 0) - ref).max() < 4e-3
+        del h
+    assert base - _free_bytes() < (8 << 20), f"leaked {(base - _free_bytes()) >> 20} MiB over 8 encoder life cycles"
