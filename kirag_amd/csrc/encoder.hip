@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id
 }
 
 // LayerNorm(y + (xb + xlo)) -> xb, xlo     (one wave per token; y holds dense + bias as bf16, xb + xlo the residual stream, updated in place)
-__global__ __launch_bounds__(256) void k_ln(const uint16_t* __restrict__ y, const int* __restrict__ Tp, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void k_ln(const uint16_t* __restrict__ y, const float* __restrict__ ybias, const int* __restrict__ Tp, const float* __restrict__ g,
                                             const float* __restrict__ bta, float eps, int H, uint16_t* xlo, uint16_t* xb) {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -228,8 +228,9 @@ __global__ __launch_bounds__(256) void k_ln(const uint16_t* __restrict__ y, cons
             const ushort4 a = *reinterpret_cast<const ushort4*>(y + t * H + i);
             const ushort4 rh = *reinterpret_cast<const ushort4*>(xb + t * H + i);
             const ushort4 rl = *reinterpret_cast<const ushort4*>(xlo + t * H + i);
-            v[j] = make_float4(BF16::to_f32(a.x) + (BF16::to_f32(rh.x) + BF16::to_f32(rl.x)), BF16::to_f32(a.y) + (BF16::to_f32(rh.y) + BF16::to_f32(rl.y)),
-                               BF16::to_f32(a.z) + (BF16::to_f32(rh.z) + BF16::to_f32(rl.z)), BF16::to_f32(a.w) + (BF16::to_f32(rh.w) + BF16::to_f32(rl.w)));
+            const float4 bb = *reinterpret_cast<const float4*>(ybias + i);       // bias of the dense layer that produced y
+            v[j] = make_float4((BF16::to_f32(a.x) + bb.x) + (BF16::to_f32(rh.x) + BF16::to_f32(rl.x)), (BF16::to_f32(a.y) + bb.y) + (BF16::to_f32(rh.y) + BF16::to_f32(rl.y)),
+                               (BF16::to_f32(a.z) + bb.z) + (BF16::to_f32(rh.z) + BF16::to_f32(rl.z)), (BF16::to_f32(a.w) + bb.w) + (BF16::to_f32(rh.w) + BF16::to_f32(rl.w)));
         }
     }
     ln_row_store(v, H, lane, g, bta, eps, xlo + t * H, xb + t * H);
@@ -292,6 +293,9 @@ template <class Shape, class F>
 __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ out, int64_t ld, int64_t row0, int col0, F&& f) {
     static_assert(Shape::TN == 2, "stage geometry assumes 64 features per wave");
     const int c = acc.lane & 31, h = acc.lane >> 5;
+    const int r8 = acc.lane >> 3, ch = acc.lane & 7;
+    const char* st_rd = stage + r8 * 128 + ((ch ^ r8) << 4);
+    uint16_t* g_base = out + (row0 + r8) * ld + col0 + ch * 8;
 #pragma unroll
     for (int mi = 0; mi < Shape::TM; ++mi) {
 #pragma unroll
@@ -305,9 +309,9 @@ __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage
             }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int rl = p * 8 + (acc.lane >> 3), ch = acc.lane & 7;
-            const uint4 d = *reinterpret_cast<const uint4*>(stage + rl * 128 + ((ch ^ (rl & 7)) << 4));
-            __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d), reinterpret_cast<u32x4_t*>(out + (row0 + mi * 32 + rl) * ld + col0 + ch * 8));
+            // rl & 7 == lane >> 3 for every p: one lane-dependent LDS / global base, the rest are wave-uniform steps (8 rows per store)
+            const uint4 d = *reinterpret_cast<const uint4*>(st_rd + p * 8 * 128);
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d), reinterpret_cast<u32x4_t*>(g_base + (int64_t)(mi * 32 + p * 8) * ld));
         }
     }
 }
@@ -338,7 +342,7 @@ __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char*
 // test (rows >= T are written with values computed from clamped loads and never read).
 // Tiles are walked in patches of (token tiles x 8 feature tiles) per XCD so operand slices are reused from that XCD's L2.
 //   EPI_QKV:   F = 3H: features [0,H) -> q (bias, 1/8 folded into the weights), [H,2H) -> k, [2H,3H) -> V^T (its bias lives in bo_eff)
-//   EPI_DENSE: out0[T,F] = acc + bias as bf16 (k_ln adds the fp32 residual)
+//   EPI_DENSE: out0[T,F] = acc as bf16 (k_ln adds the bias and the residual in fp32)
 //   EPI_GELU:  out0[T,F] = gelu(acc + bias)
 template <int EPI, class ShapeE, int STAGES>
 __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
@@ -359,10 +363,12 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
             if (f0 >= a.F) return;
             const int h = acc.lane >> 5;
             f32x4 b[2][4];                                // bias of the lane's 32 features: (ni, g) -> features ni*32 + 8g + 4h .. +3
+            if constexpr (EPI != EPI_DENSE) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) b[ni][g] = *reinterpret_cast<const f32x4*>(a.bias + f0 + ni * 32 + 8 * g + 4 * h);
+                    for (int g = 0; g < 4; ++g) b[ni][g] = *reinterpret_cast<const f32x4*>(a.bias + f0 + ni * 32 + 8 * g + 4 * h);
+            }
             if constexpr (EPI == EPI_QKV) {
                 const int region = f0 / a.H;              // H % 64 == 0: a wave's columns never straddle q | k | v
                 if (region == 2) {
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
                                             [&](f32x4 v, int ni, int g) { return v + b[ni][g]; });
                 }
             } else if constexpr (EPI == EPI_DENSE) {
-                store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int ni, int g) { return v + b[ni][g]; });
+                store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int, int) { return v; });   // the bias is added in k_ln (fp32)
             } else {
                 store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int ni, int g) {
                     const f32x4 x = v + b[ni][g];
@@ -874,14 +880,14 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
-        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln1g, l.ln1b, eps, H, e->xlo, e->xb);
+        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, l.bo_eff, e->d_T, l.ln1g, l.ln1b, eps, H, e->xlo, e->xb);
         // intermediate.dense + GELU
         a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h;
         KR_TRY(launch_proj(EPI_GELU, a, maxT, e->num_cu, e->device, st));
         // output.dense + residual -> LayerNorm
         a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->y;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
-        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, e->d_T, l.ln2g, l.ln2b, eps, H, e->xlo, e->xb);
+        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, l.b2, e->d_T, l.ln2g, l.ln2b, eps, H, e->xlo, e->xb);
     }
     hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);
     KR_HIP(hipGetLastError());
