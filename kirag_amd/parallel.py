@@ -50,6 +50,11 @@ class ShardedSearcher:
             return s, i + self.row_offset
         on_gpu = torch.is_tensor(q) and q.is_cuda
         dev = q.device if on_gpu else torch.device("cpu")
+        if not on_gpu and dist.get_backend(self.group) == "nccl":
+            # host queries (the reference hands numpy arrays to search_knn) under RCCL: the collective needs device tensors
+            q = torch.as_tensor(np.ascontiguousarray(q, dtype=np.float32)) if not torch.is_tensor(q) else q
+            dev = torch.device("cuda", int(getattr(self.index, "device", torch.cuda.current_device())))
+            q = q.to(dev); on_gpu = True
         sc = torch.full((nq, k), float("-inf"), dtype=torch.float32, device=dev)
         ids = torch.full((nq, k), -1, dtype=torch.int64, device=dev)
         if kl > 0:

@@ -184,6 +184,74 @@ class Indexer(object):
         self.index_id_to_db_id = np.concatenate((self.index_id_to_db_id, new_ids), axis=0)
 
 
+class ShardedIndexer(Indexer):
+    """``Indexer`` whose rows are split contiguously over the ranks of a ``torch.distributed`` group — BASELINE config 3 (5M-passage corpus
+    row-sharded over the 8 GPUs of a node, RCCL all-gather of per-shard top-k) behind the reference's own ``Indexer`` surface.
+
+    Rank r holds rows ``[r * ceil(N / W), (r + 1) * ceil(N / W))`` of the index in its own HBM and the FULL ``index_id_to_db_id`` map
+    (8 bytes per row).  ``search_knn`` is collective: every rank passes the same queries and gets the global top-k — local exact top-k,
+    ONE all-gather of ``nq * k * 12`` bytes per rank, host-side merge by (score desc, global row asc) — identical to the unsharded
+    ``Indexer`` (tested).  ``index.ntotal`` is the LOCAL row count; ``ntotal_global`` the corpus size."""
+
+    def __init__(self, vector_sz, metric="inner_product", n_subquantizers=0, n_bits=8, device=None, coarse_dtype="bf16", group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        super().__init__(vector_sz, metric=metric, n_subquantizers=n_subquantizers, n_bits=n_bits, device=device, coarse_dtype=coarse_dtype)
+        self.row_offset = 0
+        self.ntotal_global = 0
+
+    def index_data(self, ids, embeddings):
+        raise NotImplementedError("ShardedIndexer is filled by deserialize_from() (this rank's share of index.faiss) or by set_local_shard()")
+
+    def set_local_shard(self, local_ids, embeddings):
+        """Resident-shard build path (``compute_corpus_embeddings.cal_doc_embeddings(..., indexer=...)`` on every rank): this rank contributes
+        its contiguous rows; the global id map and the row offsets are assembled with one ``all_gather_object``.  Collective."""
+        import torch.distributed as dist
+        if isinstance(embeddings, np.ndarray):
+            embeddings = embeddings.astype('float32')
+        self.index.add(embeddings)
+        local = np.array(local_ids, dtype=np.int64)
+        parts = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(parts, local, group=self.group)
+        else:
+            parts = [local]
+        self.row_offset = int(sum(len(p) for p in parts[: self.rank]))
+        self.index_id_to_db_id = np.concatenate(parts, axis=0)
+        self.ntotal_global = len(self.index_id_to_db_id)
+
+    def deserialize_from(self, dir_path):
+        index_file = os.path.join(dir_path, "index.faiss")
+        meta_file = os.path.join(dir_path, "index_meta.faiss")
+        logger.info(f'Loading rank {self.rank}/{self.world} share of {index_file}, meta data from {meta_file}')
+        self.index = read_faiss_flat_ip(index_file, device=self.index.device, coarse_dtype=self.index.coarse_dtype, row_range=(self.rank, self.world))
+        with open(meta_file, "rb") as reader:
+            self.index_id_to_db_id = pickle.load(reader)
+        self.row_offset, self.ntotal_global = self.index.row_offset, self.index.file_ntotal
+        assert len(self.index_id_to_db_id) == self.ntotal_global, 'Deserialized index_id_to_db_id should match faiss index size'
+
+    def serialize(self, dir_path):
+        raise NotImplementedError("serialize() a ShardedIndexer from rank-local shards is not implemented; build the files with faiss_index_corpus")
+
+    def search_knn(self, query_vectors, top_docs: int, index_batch_size=1024, verbose: bool = True):
+        from ..parallel import ShardedSearcher
+        if isinstance(query_vectors, np.ndarray):
+            query_vectors = query_vectors.astype('float32')
+        if top_docs > self.ntotal_global:
+            raise ValueError(f"top_docs={top_docs} must satisfy 0 < k <= ntotal={self.ntotal_global}")
+        searcher = ShardedSearcher(self.index, row_offset=self.row_offset, world=self.world, group=self.group)
+        result = []
+        for start_idx in range(0, len(query_vectors), index_batch_size):
+            q = query_vectors[start_idx: start_idx + index_batch_size]
+            scores, rows = searcher.search(q, top_docs)
+            ext = self.index_id_to_db_id[rows]
+            db_ids = [[str(v) for v in row] for row in ext.tolist()]
+            result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
+        return result
+
+
 # ---------------------------------------------------------------------------------------------------------
 # faiss flat-index file layout.  faiss is a third-party dependency of the reference (requirements.txt:10) and
 # its source is not on disk here: the layout below restates faiss 1.8 `write_index` for IndexFlat from its
@@ -207,7 +275,9 @@ def write_faiss_flat_ip(index: FlatIPIndex, path: str) -> None:
             f.write(index.reconstruct_n(s, m).tobytes())
 
 
-def read_faiss_flat_ip(path: str, device: Optional[int] = None, coarse_dtype: str = "bf16") -> FlatIPIndex:
+def read_faiss_flat_ip(path: str, device: Optional[int] = None, coarse_dtype: str = "bf16", row_range=None) -> FlatIPIndex:
+    """``row_range = (rank, world)`` loads only that rank's contiguous share of the rows (``ShardedIndexer``); the returned index carries
+    ``file_ntotal`` (rows in the file) and ``row_offset`` (first row held)."""
     with open(path, "rb") as f:
         (fourcc,) = struct.unpack("<I", f.read(4))
         if fourcc != _FOURCC_IXFI:
@@ -218,10 +288,17 @@ def read_faiss_flat_ip(path: str, device: Optional[int] = None, coarse_dtype: st
         (nfloat,) = struct.unpack("<Q", f.read(8))
         if nfloat != n * d:
             raise ValueError(f"{path}: payload {nfloat} floats != ntotal*d = {n * d}")
+        a, b = 0, n
+        if row_range is not None:
+            rank, world = row_range
+            per = (n + world - 1) // world
+            a, b = min(rank * per, n), min((rank + 1) * per, n)
+            f.seek(a * d * 4, os.SEEK_CUR)
         index = FlatIPIndex(d, device=device, coarse_dtype=coarse_dtype)
-        index.reserve(n)
-        for s in range(0, n, _IO_CHUNK_ROWS):
-            m = min(_IO_CHUNK_ROWS, n - s)
+        index.reserve(b - a)
+        for s in range(a, b, _IO_CHUNK_ROWS):
+            m = min(_IO_CHUNK_ROWS, b - s)
             buf = np.frombuffer(f.read(m * d * 4), dtype=np.float32).reshape(m, d)
             index.add(buf)
+        index.file_ntotal, index.row_offset = n, a
     return index

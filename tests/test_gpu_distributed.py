@@ -52,3 +52,60 @@ def test_sharded_search_world2_device_shards():
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret.get(0) == "ok" and ret.get(1) == "ok", (ret.get(0), ret.get(1))
+
+
+def _worker_indexer(rank, world, port, folder, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kirag_amd.retriever.index import Indexer, ShardedIndexer
+        import pickle
+        with open(os.path.join(folder, "expected.pkl"), "rb") as f:
+            q, expected = pickle.load(f)
+        sh = ShardedIndexer(64)
+        sh.deserialize_from(folder)
+        assert sh.ntotal_global == 3001 and sh.index.ntotal in (1501, 1500) and sh.row_offset == (0 if rank == 0 else 1501)
+        got = sh.search_knn(q, 25, index_batch_size=16, verbose=False)          # 3 query blocks
+        assert len(got) == len(expected)
+        for (ids, sc), (eids, esc) in zip(got, expected):
+            assert ids == eids and np.array_equal(np.asarray(sc).view(np.uint32), np.asarray(esc).view(np.uint32))
+        # resident-shard build path: each rank contributes its own rows + ids
+        full = Indexer(64); full.deserialize_from(folder)
+        x = full.index.reconstruct_n(0, 3001)
+        a, b = (0, 1501) if rank == 0 else (1501, 3001)
+        sh2 = ShardedIndexer(64)
+        sh2.set_local_shard([str(v) for v in full.index_id_to_db_id[a:b]], x[a:b])
+        assert sh2.row_offset == a and sh2.ntotal_global == 3001 and np.array_equal(sh2.index_id_to_db_id, full.index_id_to_db_id)
+        got2 = sh2.search_knn(q, 25, verbose=False)
+        for (ids, sc), (eids, esc) in zip(got2, expected):
+            assert ids == eids and np.array_equal(np.asarray(sc).view(np.uint32), np.asarray(esc).view(np.uint32))
+        with pytest.raises(ValueError):
+            sh.search_knn(q, 4000, verbose=False)
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_indexer_equals_unsharded_indexer(tmp_path):
+    """One index.faiss / index_meta.faiss pair written by the unsharded Indexer; two ranks load their shares through ShardedIndexer and
+    return exactly the unsharded search_knn results (ids as strings, scores bit for bit)."""
+    import pickle
+    from kirag_amd.retriever.index import Indexer
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((3001, 64)).astype(np.float32); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x[2000] = x[7]                                                 # a tie across the shard boundary
+    q = x[rng.choice(3001, 40)] + 0.05 * rng.standard_normal((40, 64)).astype(np.float32)
+    ix = Indexer(64)
+    ix.index_data([str(10 * i + 3) for i in range(3001)], x)
+    ix.serialize(str(tmp_path))
+    expected = ix.search_knn(q, 25, verbose=False)
+    with open(os.path.join(str(tmp_path), "expected.pkl"), "wb") as f:
+        pickle.dump((q, expected), f)
+    del ix
+    port = _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_worker_indexer, args=(2, port, str(tmp_path), ret), nprocs=2, join=True)
+    assert ret.get(0) == "ok" and ret.get(1) == "ok", (ret.get(0), ret.get(1))
