@@ -390,8 +390,9 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// attention, LDS-staged: one block (4 waves) per (sequence, group of HPB heads).  K [keys][64] and V^T [64][keys] of
-// the block's heads are staged ONCE in LDS (every q-tile of the head re-reads them from there instead of from L2):
+// attention, LDS-staged: one block (4 waves) per (sequence, group of HPB heads, group of 4 / HPB q-tiles).  K [keys][64] and V^T [64][keys] of
+// the block's heads are staged in LDS in chunks of (at most) 128 keys — 49 KiB per block for any sequence length, three blocks per CU; the
+// online-softmax state of a wave's q-tile lives in registers across the chunks:
 //   K image   128-B rows, 16-B chunk index XOR ((key >> 1) & 7): the ds_read_b128 of an MFMA A fragment (lane -> key l&31,
 //             d-chunk 2s + (l>>5)) is bank-conflict free (same image as the GEMM ring);
 //   V^T image row pitch 2*cap + 8 bytes (pitch / 8 odd): the two ds_read_b64 of a P.V A fragment (lane -> d = l&31) hit 32
@@ -404,89 +405,94 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
 template <int HPB>
 __global__ __launch_bounds__(256) void k_attn_lds(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vT, int64_t ldv,
                                                   const int* __restrict__ seq_off, const int* __restrict__ seq_nk, const int* __restrict__ seq_nq,
-                                                  int H, int heads, int cap, uint16_t* __restrict__ ctx) {
+                                                  int H, int heads, int kchunk, uint16_t* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hb = blockIdx.x, b = blockIdx.y;            // heads fastest: the heads of one sequence (same 2-KiB q/k rows) run together
     const int nq = seq_nq[b];
-    if (nq == 0) return;
+    constexpr int QT = 4 / HPB;                           // q-tiles per block (one per wave and head)
+    const int q0 = ((int)blockIdx.z * QT + wave / HPB) * 32;
+    if ((int)blockIdx.z * QT * 32 >= nq) return;          // block-uniform: no q-tile of this block exists (nq == 0 included)
     const int nk = seq_nk[b];
     const int64_t off = seq_off[b];
-    const int nkp = (nk + 31) & ~31;                      // <= cap
-    const int vpitch = cap * 2 + 8;
-    char* Ks = smem;                                      // [HPB][cap][128 B]
-    char* Vs = smem + (size_t)HPB * cap * 128;            // [HPB][64][vpitch]
+    const int vpitch = kchunk * 2 + 8;
+    char* Ks = smem;                                      // [HPB][kchunk][128 B]
+    char* Vs = smem + (size_t)HPB * kchunk * 128;         // [HPB][64][vpitch]
     char* Os = Vs + (size_t)HPB * 64 * vpitch + wave * 4096;
-    // staging: every global load of a batch is issued before the first LDS store (a load -> store loop would serialise one memory
-    // round trip per iteration)
-    constexpr int NB = 8;
-    const int cpr = nkp >> 2;                             // 8-byte chunks (4 keys) per V^T row
-    const unsigned cpr_magic = cpr ? 0xFFFFFFFFu / (unsigned)cpr + 1u : 0u;
-#pragma unroll
-    for (int hs = 0; hs < HPB; ++hs) {
-        const int head = hb * HPB + hs;
-        if (head >= heads) break;
-        char* Kh = Ks + (size_t)hs * cap * 128;
-        char* Vh = Vs + (size_t)hs * 64 * vpitch;
-        const int nkc = nkp * 8, nvc = 64 * cpr;
-        for (int base = 0; base < nkc || base < nvc; base += 256 * NB) {
-            uint4 kv[NB]; uint2 vv[NB]; int vd[NB], vk[NB];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int i = base + j * 256 + tid;
-                const int key = i >> 3, ch = i & 7;
-                kv[j] = make_uint4(0u, 0u, 0u, 0u);
-                if (i < nkc && key < nk) kv[j] = *reinterpret_cast<const uint4*>(k + (off + key) * H + head * 64 + ch * 8);
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int i = base + j * 256 + tid;
-                const int d = (int)__umulhi((unsigned)i, cpr_magic), kc = i - d * cpr;   // i / cpr (exact: i < 2^16, cpr <= 128)
-                vd[j] = d; vk[j] = kc;
-                vv[j] = make_uint2(0u, 0u);
-                if (i < nvc && kc * 4 < nk) vv[j] = *reinterpret_cast<const uint2*>(vT + (int64_t)(head * 64 + d) * ldv + off + kc * 4);   // off % 4 == 0: 8-B aligned
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int i = base + j * 256 + tid;
-                const int key = i >> 3, ch = i & 7;
-                if (i < nkc) *reinterpret_cast<uint4*>(Kh + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kv[j];
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int i = base + j * 256 + tid;
-                const int key0 = vk[j] * 4;
-                uint2 v = vv[j];
-                if (key0 + 4 > nk) {      // keys >= nk (padding / the next sequence) are stored as zero
-                    v.x &= (key0 + 0 < nk ? 0xffffu : 0u) | (key0 + 1 < nk ? 0xffff0000u : 0u);
-                    v.y &= (key0 + 2 < nk ? 0xffffu : 0u) | (key0 + 3 < nk ? 0xffff0000u : 0u);
-                }
-                if (i < nvc) *reinterpret_cast<uint2*>(Vh + vd[j] * vpitch + vk[j] * 8) = v;
-            }
-        }
-    }
-    __syncthreads();
     const int hs = wave % HPB;
     const int head = hb * HPB + hs;
-    if (head >= heads) return;
-    const char* Kh = Ks + (size_t)hs * cap * 128;
+    const bool active = head < heads && q0 < nq;          // inactive waves still stage and meet every barrier
+    const char* Kh = Ks + (size_t)hs * kchunk * 128;
     const char* Vh = Vs + (size_t)hs * 64 * vpitch;
     const int c = lane & 31, hf = lane >> 5;
     const float LOG2E = 1.4426950408889634f;
-    for (int q0 = (wave / HPB) * 32; q0 < nq; q0 += (4 / HPB) * 32) {
-        // Q^T as the B operand: lane (c, hf) holds Q[q0 + c][16 s + 8 hf .. +7], s = 0..3
-        uint4 qf[4];
-        {
-            const int qi = (q0 + c < nq) ? (q0 + c) : (nq - 1);
-            const uint16_t* qrow = q + (off + qi) * H + head * 64;
+    // Q^T as the B operand: lane (c, hf) holds Q[q0 + c][16 s + 8 hf .. +7], s = 0..3
+    uint4 qf[4] = {};
+    if (active) {
+        const int qi = (q0 + c < nq) ? (q0 + c) : (nq - 1);
+        const uint16_t* qrow = q + (off + qi) * H + head * 64;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(qrow + 16 * s + 8 * hf);
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(qrow + 16 * s + 8 * hf);
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    constexpr int NB = 8;
+    for (int kc0 = 0; kc0 < nk; kc0 += kchunk) {
+        // ---- stage keys [kc0, kc0 + kchunk) of the block's heads: every global load of a batch is issued before the first LDS store
+        // (a load -> store loop would serialise one memory round trip per iteration)
+        const int nkc = min(nk - kc0, kchunk);            // keys of this chunk
+        const int nkp = (nkc + 31) & ~31;
+        const int cpr = nkp >> 2;                         // 8-byte chunks (4 keys) per V^T row
+        const unsigned cpr_magic = 0xFFFFFFFFu / (unsigned)cpr + 1u;
+        if (kc0 > 0) __syncthreads();                     // every wave is done with the previous chunk
+#pragma unroll
+        for (int h2 = 0; h2 < HPB; ++h2) {
+            const int head2 = hb * HPB + h2;
+            if (head2 >= heads) break;
+            char* Kw = Ks + (size_t)h2 * kchunk * 128;
+            char* Vw = Vs + (size_t)h2 * 64 * vpitch;
+            const int nkcs = nkp * 8, nvc = 64 * cpr;
+            for (int base = 0; base < nkcs || base < nvc; base += 256 * NB) {
+                uint4 kv[NB]; uint2 vv[NB]; int vd[NB], vk[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int i = base + j * 256 + tid;
+                    const int key = i >> 3, ch = i & 7;
+                    kv[j] = make_uint4(0u, 0u, 0u, 0u);
+                    if (i < nkcs && key < nkc) kv[j] = *reinterpret_cast<const uint4*>(k + (off + kc0 + key) * H + head2 * 64 + ch * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int i = base + j * 256 + tid;
+                    const int d = (int)__umulhi((unsigned)i, cpr_magic), kc = i - d * cpr;   // i / cpr (exact: i < 2^16, cpr <= 128)
+                    vd[j] = d; vk[j] = kc;
+                    vv[j] = make_uint2(0u, 0u);
+                    if (i < nvc && kc * 4 < nkc) vv[j] = *reinterpret_cast<const uint2*>(vT + (int64_t)(head2 * 64 + d) * ldv + off + kc0 + kc * 4);   // off, kc0 % 4 == 0: 8-B aligned
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int i = base + j * 256 + tid;
+                    const int key = i >> 3, ch = i & 7;
+                    if (i < nkcs) *reinterpret_cast<uint4*>(Kw + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kv[j];
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int i = base + j * 256 + tid;
+                    const int key0 = vk[j] * 4;
+                    uint2 v = vv[j];
+                    if (key0 + 4 > nkc) {      // keys >= nk (padding / the next sequence) are stored as zero
+                        v.x &= (key0 + 0 < nkc ? 0xffffu : 0u) | (key0 + 1 < nkc ? 0xffff0000u : 0u);
+                        v.y &= (key0 + 2 < nkc ? 0xffffu : 0u) | (key0 + 3 < nkc ? 0xffff0000u : 0u);
+                    }
+                    if (i < nvc) *reinterpret_cast<uint2*>(Vw + vd[j] * vpitch + vk[j] * 8) = v;
+                }
+            }
         }
-        f32x16 o0, o1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-        float m = -INFINITY, l = 0.f;
-        for (int k0 = 0; k0 < nk; k0 += 32) {
+        __syncthreads();
+        if (!active) continue;
+        for (int k0 = 0; k0 < nkc; k0 += 32) {            // k0: key offset inside the chunk
             f32x16 st;
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
@@ -500,10 +506,10 @@ __global__ __launch_bounds__(256) void k_attn_lds(const uint16_t* __restrict__ q
                     st = BF16::mfma(kf, qf[s], st);
                 }
             }
-            // register r of this lane is key k0 + (r&3) + 8 (r>>2) + 4 hf, query q0 + c
-            if (k0 + 32 > nk) {   // only the last key tile can hold keys >= nk
+            // register r of this lane is key kc0 + k0 + (r&3) + 8 (r>>2) + 4 hf, query q0 + c
+            if (k0 + 32 > nkc) {   // only the last key tile can hold keys >= nk
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[r] = (k0 + (r & 3) + 8 * (r >> 2) + 4 * hf < nk) ? st[r] : -INFINITY;
+                for (int r = 0; r < 16; ++r) st[r] = (k0 + (r & 3) + 8 * (r >> 2) + 4 * hf < nkc) ? st[r] : -INFINITY;
             }
             float tmax = fmaxf(fmaxf(st[0], st[1]), st[2]);
 #pragma unroll
@@ -537,24 +543,25 @@ __global__ __launch_bounds__(256) void k_attn_lds(const uint16_t* __restrict__ q
                 o1 = BF16::mfma(make_uint4(b0.x, b0.y, b1.x, b1.y), pf, o1);
             }
         }
-        // a query with no attendable key (all-masked sequence) is 0/0 = NaN, as under HF's -inf masking
-        const float inv = 1.0f / l;
+    }
+    if (!active) return;
+    // a query with no attendable key (all-masked sequence) is 0/0 = NaN, as under HF's -inf masking
+    const float inv = 1.0f / l;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            uint2 w0, w1;
-            w0.x = pack_bf16x2(o0[4 * gq + 0] * inv, o0[4 * gq + 1] * inv); w0.y = pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
-            w1.x = pack_bf16x2(o1[4 * gq + 0] * inv, o1[4 * gq + 1] * inv); w1.y = pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
-            const int j8 = 2 * gq + hf;     // 8-byte chunk (4 features) of the 128-B row of query c
-            *reinterpret_cast<uint2*>(Os + c * 128 + ((j8 ^ (c & 15)) << 3)) = w0;
-            *reinterpret_cast<uint2*>(Os + c * 128 + (((8 + j8) ^ (c & 15)) << 3)) = w1;
-        }
+    for (int gq = 0; gq < 4; ++gq) {
+        uint2 w0, w1;
+        w0.x = pack_bf16x2(o0[4 * gq + 0] * inv, o0[4 * gq + 1] * inv); w0.y = pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
+        w1.x = pack_bf16x2(o1[4 * gq + 0] * inv, o1[4 * gq + 1] * inv); w1.y = pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
+        const int j8 = 2 * gq + hf;     // 8-byte chunk (4 features) of the 128-B row of query c
+        *reinterpret_cast<uint2*>(Os + c * 128 + ((j8 ^ (c & 15)) << 3)) = w0;
+        *reinterpret_cast<uint2*>(Os + c * 128 + (((8 + j8) ^ (c & 15)) << 3)) = w1;
+    }
 #pragma unroll
-        for (int p4 = 0; p4 < 4; ++p4) {
-            const int rq = p4 * 8 + (lane >> 3), ch = lane & 7;
-            const uint2 lo = *reinterpret_cast<const uint2*>(Os + rq * 128 + (((2 * ch) ^ (rq & 15)) << 3));
-            const uint2 hi = *reinterpret_cast<const uint2*>(Os + rq * 128 + (((2 * ch + 1) ^ (rq & 15)) << 3));
-            if (q0 + rq < nq) *reinterpret_cast<uint4*>(ctx + (off + q0 + rq) * H + head * 64 + ch * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
+    for (int p4 = 0; p4 < 4; ++p4) {
+        const int rq = p4 * 8 + (lane >> 3), ch = lane & 7;
+        const uint2 lo = *reinterpret_cast<const uint2*>(Os + rq * 128 + (((2 * ch) ^ (rq & 15)) << 3));
+        const uint2 hi = *reinterpret_cast<const uint2*>(Os + rq * 128 + (((2 * ch + 1) ^ (rq & 15)) << 3));
+        if (q0 + rq < nq) *reinterpret_cast<uint4*>(ctx + (off + q0 + rq) * H + head * 64 + ch * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
 }
 
@@ -681,17 +688,19 @@ static int parse_name(const Encoder* e, const char* name, int& slot, int64_t& nu
 }
 
 template <int HPB>
-static int launch_attn(const Encoder* e, int B, int cap, hipStream_t st) {
+static int launch_attn(const Encoder* e, int B, int cap, int nqt, hipStream_t st) {
     const int H = e->cfg.hidden, heads = e->cfg.heads;
-    const int lds = HPB * (cap * 128 + 64 * (cap * 2 + 8)) + 4 * 4096;
+    const int kchunk = cap < 128 ? cap : 128;            // keys staged at a time: K 16 KiB + V^T 16.5 KiB per head -> 49 KiB per block, 3 blocks per CU for any S
+    const int lds = HPB * (kchunk * 128 + 64 * (kchunk * 2 + 8)) + 4 * 4096;
     static int attr_lds_dev[64] = {};   // per device: function attributes belong to the device's code object instance
     int& attr_lds = attr_lds_dev[e->device & 63];
     if (lds > attr_lds) {
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_lds<HPB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL((k_attn_lds<HPB>), dim3((unsigned)((heads + HPB - 1) / HPB), (unsigned)B), dim3(256), lds, st, e->q, e->k, e->vT, e->ldv,
-                       e->seq_off, e->seq_nk, e->seq_nq, H, heads, cap, e->ctx);
+    const int qgroups = (nqt + (4 / HPB) - 1) / (4 / HPB);   // blocks per (sequence, head group): 4 / HPB q-tiles each
+    hipLaunchKernelGGL((k_attn_lds<HPB>), dim3((unsigned)((heads + HPB - 1) / HPB), (unsigned)B, (unsigned)qgroups), dim3(256), lds, st, e->q, e->k, e->vT,
+                       e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, kchunk, e->ctx);
     return 0;
 }
 
@@ -873,9 +882,9 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         {
             const int cap = (int)round_up(S, 32);
             const int nqt = (S + (pool == KR_POOL_CLS ? 1 : 0) + 31) / 32;      // q-tiles of the longest possible sequence
-            if (nqt >= 3) KR_TRY(launch_attn<1>(e, B, cap, st));
-            else if (nqt == 2) KR_TRY(launch_attn<2>(e, B, cap, st));
-            else KR_TRY(launch_attn<4>(e, B, cap, st));
+            if (nqt >= 3) KR_TRY(launch_attn<1>(e, B, cap, nqt, st));
+            else if (nqt == 2) KR_TRY(launch_attn<2>(e, B, cap, nqt, st));
+            else KR_TRY(launch_attn<4>(e, B, cap, nqt, st));
         }
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y;
