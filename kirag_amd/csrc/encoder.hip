@@ -565,27 +565,47 @@ __global__ __launch_bounds__(256) void k_attn_lds(const uint16_t* __restrict__ q
     }
 }
 
-// pooling + L2 normalisation: one block per sequence
+// pooling + L2 normalisation: one block per sequence.  Mean pooling: wave w sums the tokens t = w, w+4, ... (8-byte loads of the (hi, lo)
+// stream, 4 columns per lane and step), the four partial sums are combined in a fixed order (w = 0..3), so the result is deterministic.
 __global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, const uint16_t* __restrict__ xlo, const int* __restrict__ seq_off, const int* __restrict__ seq_nk,
                                               const int* __restrict__ seq_cls, int H, int pool, float* __restrict__ out) {
+    __shared__ float part[4][2048];   // H <= 2048
     __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t off = seq_off[b];
     const int nk = seq_nk[b];
-    float v[8];   // H <= 2048
+    float4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int t_begin = pool == KR_POOL_CLS ? (wave == 0 ? seq_cls[b] : 1 << 30) : wave;
+    const int t_end = pool == KR_POOL_CLS ? (wave == 0 ? seq_cls[b] + 1 : 0) : nk;
+    for (int t = t_begin; t < t_end; t += 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = lane * 4 + j * 256;
+            if (i < H) {
+                const ushort4 hi = *reinterpret_cast<const ushort4*>(xb + (off + t) * H + i);
+                const ushort4 lo = *reinterpret_cast<const ushort4*>(xlo + (off + t) * H + i);
+                acc[j].x += BF16::to_f32(hi.x) + BF16::to_f32(lo.x); acc[j].y += BF16::to_f32(hi.y) + BF16::to_f32(lo.y);
+                acc[j].z += BF16::to_f32(hi.z) + BF16::to_f32(lo.z); acc[j].w += BF16::to_f32(hi.w) + BF16::to_f32(lo.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = lane * 4 + j * 256;
+        if (i < H) *reinterpret_cast<float4*>(&part[wave][i]) = acc[j];
+    }
+    __syncthreads();
+    float v[8];
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int i = tid + j * 256;
         v[j] = 0.f;
         if (i < H) {
-            if (pool == KR_POOL_CLS) {
-                v[j] = BF16::to_f32(xb[(off + seq_cls[b]) * H + i]) + BF16::to_f32(xlo[(off + seq_cls[b]) * H + i]);
-            } else {
-                float s = 0.f;
-                for (int t = 0; t < nk; ++t) s += BF16::to_f32(xb[(off + t) * H + i]) + BF16::to_f32(xlo[(off + t) * H + i]);
-                v[j] = s / (float)nk;   // nk == 0 -> 0/0 = NaN like average_pool (encoders.py:56-58)
-            }
+            const float s = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
+            v[j] = pool == KR_POOL_CLS ? s : s / (float)nk;   // nk == 0 -> 0/0 = NaN like average_pool (encoders.py:56-58)
             ss += v[j] * v[j];
         }
     }
