@@ -402,8 +402,10 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
 // The O tile is staged through a wave-private 4-KiB LDS block and stored as whole 128-B rows of ctx.
 // HPB = heads per block: 1 when a sequence has >= 3 q-tiles, 2 / 4 for short sequences so that all four waves have work.
 // ---------------------------------------------------------------------------------------------------------
+// __launch_bounds__(256, 2): at most 256 registers per lane, which makes hipcc keep the MFMA accumulators in VGPRs; with the default bound it put
+// them in AGPRs and spent 112 of the 276 VALU instructions of a key tile on v_accvgpr_read / _write around the softmax rescale
 template <int HPB>
-__global__ __launch_bounds__(256) void k_attn_lds(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vT, int64_t ldv,
+__global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vT, int64_t ldv,
                                                   const int* __restrict__ seq_off, const int* __restrict__ seq_nk, const int* __restrict__ seq_nq,
                                                   int H, int heads, int kchunk, uint16_t* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void k_attn_lds(const uint16_t* __restrict__ q
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m = -INFINITY, l = 0.f;
-    constexpr int NB = 8;
+    constexpr int NB = 4;                                 // loads in flight per thread and batch (register budget: 3 blocks per CU = 168 VGPRs)
     for (int kc0 = 0; kc0 < nk; kc0 += kchunk) {
         // ---- stage keys [kc0, kc0 + kchunk) of the block's heads: every global load of a batch is issued before the first LDS store
         // (a load -> store loop would serialise one memory round trip per iteration)
