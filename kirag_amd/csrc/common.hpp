@@ -108,6 +108,33 @@ __device__ __forceinline__ double canonical_dot_wave(const float* __restrict__ q
     return acc;
 }
 
+// Same canonical score for TWO rows at once with the query chunks already in registers (qr[j] = q[lane*4 + j*256 .. +3], zero beyond d):
+// every global load of both rows is issued before the first use, so a wave pays one memory round trip per pair of rows instead of one
+// per 256-element step (the re-rank gathers one 4-KiB fp32 row per candidate from HBM).  NCH = number of 256-element steps (d <= 256 NCH).
+// The per-lane summation order is exactly canonical_dot_wave's (products with zero-filled tails add +0.0, which changes nothing).
+template <int NCH>
+__device__ __forceinline__ void canonical_dot_wave2(const float4 (&qr)[NCH], const float* __restrict__ x0, const float* __restrict__ x1, int d, int lane,
+                                                    double& e0, double& e1) {
+    float4 a[NCH], b[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int i = lane * 4 + j * 256;
+        a[j] = make_float4(0.f, 0.f, 0.f, 0.f); b[j] = a[j];
+        if (i < d) { a[j] = *reinterpret_cast<const float4*>(x0 + i); b[j] = *reinterpret_cast<const float4*>(x1 + i); }
+    }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (lane * 4 + j * 256 < d) {
+            s0 += (double)qr[j].x * (double)a[j].x; s0 += (double)qr[j].y * (double)a[j].y; s0 += (double)qr[j].z * (double)a[j].z; s0 += (double)qr[j].w * (double)a[j].w;
+            s1 += (double)qr[j].x * (double)b[j].x; s1 += (double)qr[j].y * (double)b[j].y; s1 += (double)qr[j].z * (double)b[j].z; s1 += (double)qr[j].w * (double)b[j].w;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { s0 += shfl_xor_f64(s0, m); s1 += shfl_xor_f64(s1, m); }
+    e0 = s0; e1 = s1;
+}
+
 // in-LDS bitonic sort of n (power of two) uint64 keys, DESCENDING, by a block of nthreads threads
 __device__ __forceinline__ void bitonic_sort_desc(uint64_t* s, int n, int tid, int nthreads) {
     for (int k = 2; k <= n; k <<= 1) {

@@ -22,6 +22,7 @@
 #include "gemm_nt.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(256) void k_select(uint64_t* __restrict__ cand, int
 
 // exactness certificate + fp64 re-rank of the candidates with coarse score >= b_k - 2 eps   (buffer order is arbitrary)
 constexpr int RERANK_MAX = 2048;
+template <int NCH>   // NCH 256-element steps cover a row: d <= 256 NCH
 __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ cand, int cand_cap, const uint32_t* __restrict__ cnt,
                                                 uint32_t* __restrict__ flags, const float* __restrict__ thr, const float* __restrict__ eps,
                                                 const float* __restrict__ qf, const float* __restrict__ xf, int d, int k, int preset,
@@ -386,14 +388,23 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
     if (P < 1) P = 1;
     __syncthreads();
     const float* qv = qf + (int64_t)q * d;
-    for (int i = wave; i < P; i += 4) {
-        uint64_t key = 0ull;
-        if (i < r) {
-            const uint32_t row = key_row(sel[i]);
-            const double e = canonical_dot_wave(qv, xf + (int64_t)row * d, d, lane);
-            key = make_key((float)e, row);
+    {
+        float4 qr[NCH];                                        // the query stays in registers for all rows of this wave
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int i = lane * 4 + j * 256;
+            qr[j] = (i < d) ? *reinterpret_cast<const float4*>(qv + i) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (lane == 0) sel[i] = key;
+        for (int i = wave; i < P; i += 8) {                    // two candidate rows per wave and step: i and i + 4
+            const bool v0 = i < r, v1 = i + 4 < r;
+            const uint32_t row0 = v0 ? key_row(sel[i]) : 0u, row1 = v1 ? key_row(sel[i + 4]) : row0;
+            double e0 = 0.0, e1 = 0.0;
+            if (v0) canonical_dot_wave2<NCH>(qr, xf + (int64_t)row0 * d, xf + (int64_t)row1 * d, d, lane, e0, e1);
+            if (lane == 0) {
+                sel[i] = v0 ? make_key((float)e0, row0) : 0ull;
+                if (i + 4 < P) sel[i + 4] = v1 ? make_key((float)e1, row1) : 0ull;
+            }
+        }
     }
     bitonic_sort_desc(sel, P, tid, 256);
     for (int j = tid; j < k && j < P; j += 256) {
@@ -588,7 +599,9 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         bool& sel_attr_set = sel_attr_set_dev[ix->device & 63];
         if (!sel_attr_set) {   // cap = 8192 needs 64 KiB + 16 B of dynamic LDS
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + RERANK_MAX * 8 + 264 * 4));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + RERANK_MAX * 8 + 264 * 4));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + RERANK_MAX * 8 + 264 * 4));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + RERANK_MAX * 8 + 264 * 4));
             sel_attr_set = true;
         }
         // Round schedule (any thresholds are SAFE: the certificate in k_rerank decides exactness; the schedule only sets speed):
@@ -623,7 +636,8 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
             }
             hipLaunchKernelGGL(k_select, dim3(nq), dim3(256), sel_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, K1, rank, preset);
         }
-        hipLaunchKernelGGL(k_rerank, dim3(nq), dim3(256), rer_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags,
+        auto rerank = ix->d <= 1024 ? &k_rerank<4> : ix->d <= 2048 ? &k_rerank<8> : &k_rerank<16>;   // row steps held in registers
+        hipLaunchKernelGGL(rerank, dim3(nq), dim3(256), rer_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags,
                            ix->thr, ix->eps, ix->q_f, ix->xf, ix->d, k, final_preset, ix->out_s, ix->out_r, ix->nrer);
         KR_HIP(hipGetLastError());
         // one round trip: status words into pinned memory and (optimistically) the results into the caller's buffers, ONE stream sync;
