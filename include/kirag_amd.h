@@ -93,6 +93,12 @@ int kr_score_topk(const float* q, int nq, const float* x, int64_t n, int d, int 
  *   Host pointers only. */
 int kr_topk_merge(const float* scores, const int64_t* ids, int nshards, int nq, int k, float* out_scores, int64_t* out_ids);
 
+/* The same merge on the device, for lists that are already in HBM (the output of the all-gather): asynchronous on `stream`, no host round trip.
+ *   scores + s * score_shard_stride -> list block [nq,k] of shard s (strides in elements), likewise ids; out_* [nq,k] device (or pinned host) pointers.
+ *   nshards * k <= 8192.  Result identical to kr_topk_merge (lists sorted by (score desc, id asc), id < 0 = padding at the tail, ids unique). */
+int kr_topk_merge_device(const float* scores, int64_t score_shard_stride, const int64_t* ids, int64_t id_shard_stride, int nshards, int nq, int k,
+                         float* out_scores, int64_t* out_ids, int device, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * BERT-family sentence encoder — replaces HF BertModel.forward + pooling + F.normalize behind
  * retriever/encoders.py (E5Encoder.forward :67-77, BGEEncoder.forward :106-118) and retriever/e5.py:51-61.

@@ -48,6 +48,7 @@ SIGNATURES = {
     "kr_index_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "kr_score_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kr_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "kr_topk_merge_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kr_encoder_create": (C.c_int, [C.POINTER(BertCfg), C.c_int, C.POINTER(C.c_void_p)]),
     "kr_encoder_destroy": (None, [C.c_void_p]),
     "kr_encoder_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),

@@ -30,6 +30,7 @@ using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LD
 // with 4 slots = 3 K-tiles in flight (4 x 32 KiB + 4 x 4 KiB of epilogue stage = 144 KiB: one block per CU)
 
 using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB ring, two blocks per CU: for launches with too few 256x256 tiles to fill the chip
+using ShapeSmall8 = GemmShape<128, 128, 4, 2>;  // the same tile on 8 waves of 32 tokens x 64 features: two waves per SIMD cover each other's LDS / barrier stalls when a CU holds ONE block
 
 // both main loops run with exchanged MFMA operands (accumulators hold 4 consecutive features per lane):
 // 256x256 tiles -> ping-pong loop; 128x128 tiles (small token counts: 4x the tiles, a quarter of the latency each) -> streaming loop
@@ -752,7 +753,10 @@ static int launch_proj(int epi, const ProjArgs& a, int64_t max_tokens, int num_c
     const int force = fe ? atoi(fe) : 0;
     const bool small = force == 128 || (force != 256 && big_tiles * 8 < (int64_t)num_cu * 5);   // measured crossover: ~5/8 of the CUs busy with 256x256 tiles
     if (!small) return launch_proj_shape<ShapeBig, 2>(epi, a, num_cu, device, st);
-    if (small_tiles <= num_cu && force != 128) return launch_proj_shape<ShapeSmall, 4>(epi, a, num_cu, device, st);
+    if (small_tiles <= num_cu && force != 128) {
+        if (force == 129) return launch_proj_shape<ShapeSmall, 4>(epi, a, num_cu, device, st);
+        return launch_proj_shape<ShapeSmall8, 4>(epi, a, num_cu, device, st);
+    }
     return launch_proj_shape<ShapeSmall, 2>(epi, a, 2 * num_cu, device, st);
 }
 

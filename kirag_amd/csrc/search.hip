@@ -22,6 +22,7 @@
 #include "gemm_nt.hpp"
 
 #include <algorithm>
+#include <thread>
 #include <type_traits>
 #include <cmath>
 #include <cstdlib>
@@ -677,6 +678,53 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
     return 0;
 }
 
+// device-side final merge of per-shard top-k lists (the gathered lists are already in HBM after the RCCL all-gather): one block per query.
+// Every list is sorted by (score desc, id asc) with id < 0 padding at its tail, ids are globally unique, so the merged position of entry j of
+// list s is j + sum over the other lists t of the number of entries of t that precede it (binary search in LDS): no sort, no atomics on the
+// output, the result is exactly kr_topk_merge's.
+constexpr int MERGE_MAX = 8192;   // nshards * k entries per query (8 shards x k = 1024): 96 KiB of LDS
+__global__ __launch_bounds__(256) void k_merge_lists(const float* __restrict__ scores, int64_t s_stride, const int64_t* __restrict__ ids, int64_t i_stride,
+                                                     int nshards, int k, float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = nshards * k;
+    int64_t* si = reinterpret_cast<int64_t*>(smem);                 // [n]
+    float* ss = reinterpret_cast<float*>(si + n);                   // [n]
+    __shared__ int valid;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) valid = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int s = 0; s < nshards; ++s)
+        for (int j = tid; j < k; j += 256) {
+            const int64_t id = ids[s * i_stride + (int64_t)q * k + j];
+            si[s * k + j] = id; ss[s * k + j] = scores[s * s_stride + (int64_t)q * k + j];
+            mine += id >= 0;
+        }
+    if (mine) atomicAdd(&valid, mine);
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) {
+        const int64_t id = si[e];
+        if (id < 0) continue;
+        const float sc = ss[e];
+        const int s = e / k;
+        int rank = e - s * k;
+        for (int t = 0; t < nshards && rank < k; ++t) {
+            if (t == s) continue;
+            int lo = 0, hi = k;                                     // first entry of list t that does NOT precede (sc, id)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const int64_t oid = si[t * k + mid];
+                const float os = ss[t * k + mid];
+                const bool before = oid >= 0 && (os > sc || (os == sc && oid < id));
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) { out_s[(int64_t)q * k + rank] = sc; out_i[(int64_t)q * k + rank] = id; }
+    }
+    for (int j = valid + tid; j < k; j += 256) { out_s[(int64_t)q * k + j] = -INFINITY; out_i[(int64_t)q * k + j] = -1; }
+}
+
 }  // namespace kr
 
 using namespace kr;
@@ -836,23 +884,53 @@ int kr_index_stats(kr_index* h, kr_search_stats* out, int reset) {
 
 int kr_topk_merge(const float* scores, const int64_t* ids, int nshards, int nq, int k, float* out_scores, int64_t* out_ids) {
     if (!scores || !ids || !out_scores || !out_ids || nshards <= 0 || nq < 0 || k <= 0) return fail(KR_EINVAL, "bad merge arguments");
-    // every shard list is already sorted by (score desc, id asc): k-way merge by repeated head selection
-    std::vector<int> head(nshards);
-    for (int q = 0; q < nq; ++q) {
-        std::fill(head.begin(), head.end(), 0);
-        for (int j = 0; j < k; ++j) {
-            int best = -1; float bs = 0.f; int64_t bi = 0;
-            for (int s = 0; s < nshards; ++s) {
-                if (head[s] >= k) continue;
-                const size_t o = ((size_t)s * nq + q) * k + head[s];
-                const float sc = scores[o]; const int64_t id = ids[o];
-                if (id < 0) { head[s] = k; continue; }   // shard shorter than k (padding)
-                if (best < 0 || sc > bs || (sc == bs && id < bi)) { best = s; bs = sc; bi = id; }
+    // every shard list is already sorted by (score desc, id asc): k-way merge by repeated head selection.  Queries are independent: large merges
+    // (8 shards x 1000 queries x 100 = 0.75 ms on one core, on the critical path of every multi-GPU step) are split over up to 8 host threads.
+    auto merge_range = [=](int q_begin, int q_end) {
+        std::vector<int> head(nshards);
+        for (int q = q_begin; q < q_end; ++q) {
+            std::fill(head.begin(), head.end(), 0);
+            for (int j = 0; j < k; ++j) {
+                int best = -1; float bs = 0.f; int64_t bi = 0;
+                for (int s = 0; s < nshards; ++s) {
+                    if (head[s] >= k) continue;
+                    const size_t o = ((size_t)s * nq + q) * k + head[s];
+                    const float sc = scores[o]; const int64_t id = ids[o];
+                    if (id < 0) { head[s] = k; continue; }   // shard shorter than k (padding)
+                    if (best < 0 || sc > bs || (sc == bs && id < bi)) { best = s; bs = sc; bi = id; }
+                }
+                if (best < 0) { out_scores[(size_t)q * k + j] = -INFINITY; out_ids[(size_t)q * k + j] = -1; continue; }
+                out_scores[(size_t)q * k + j] = bs; out_ids[(size_t)q * k + j] = bi; head[best]++;
             }
-            if (best < 0) { out_scores[(size_t)q * k + j] = -INFINITY; out_ids[(size_t)q * k + j] = -1; continue; }
-            out_scores[(size_t)q * k + j] = bs; out_ids[(size_t)q * k + j] = bi; head[best]++;
         }
+    };
+    const int64_t work = (int64_t)nq * k * nshards;
+    int nthreads = (int)std::min<int64_t>(std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())), work / 65536);
+    nthreads = std::min(nthreads, nq);
+    if (nthreads <= 1) { merge_range(0, nq); return 0; }
+    std::vector<std::thread> pool;
+    pool.reserve(nthreads - 1);
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(merge_range, (int)((int64_t)nq * t / nthreads), (int)((int64_t)nq * (t + 1) / nthreads));
+    merge_range(0, nq / nthreads);
+    for (auto& th : pool) th.join();
+    return 0;
+}
+
+int kr_topk_merge_device(const float* scores, int64_t score_shard_stride, const int64_t* ids, int64_t id_shard_stride, int nshards, int nq, int k,
+                         float* out_scores, int64_t* out_ids, int device, void* stream) {
+    if (!scores || !ids || !out_scores || !out_ids || nshards <= 0 || nq < 0 || k <= 0) return fail(KR_EINVAL, "bad merge arguments");
+    if ((int64_t)nshards * k > MERGE_MAX) return fail(KR_EINVAL, "nshards * k = %lld exceeds %d (use kr_topk_merge)", (long long)nshards * k, MERGE_MAX);
+    if (device < 0 || device >= 64) return fail(KR_EINVAL, "device %d out of range", device);
+    if (nq == 0) return 0;
+    KR_TRY(select_device(device));
+    static bool attr_set_dev[64] = {};
+    if (!attr_set_dev[device]) {
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_lists), hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_MAX * 12));
+        attr_set_dev[device] = true;
     }
+    hipLaunchKernelGGL(k_merge_lists, dim3((unsigned)nq), dim3(256), (size_t)nshards * k * 12, reinterpret_cast<hipStream_t>(stream), scores, score_shard_stride,
+                       ids, id_shard_stride, nshards, k, out_scores, out_ids);
+    KR_HIP(hipGetLastError());
     return 0;
 }
 

@@ -73,6 +73,22 @@ def test_host_merge_matches_oracle():
     assert np.array_equal(mi, io) and np.array_equal(ms, so)
 
 
+def test_host_merge_threaded_path_matches_numpy():
+    """8 shards x 600 queries x 50: large enough for kr_topk_merge to split the queries over several host threads; compared with a lexsort of the
+    concatenated lists (score desc, id asc), with duplicated scores across shards."""
+    from kirag_amd.parallel import merge_topk
+    rng = np.random.default_rng(5)
+    W, nq, k = 8, 600, 50
+    sc = np.round(rng.standard_normal((W, nq, k)).astype(np.float32), 1)          # coarse grid -> many ties between shards
+    ids = np.stack([rng.permuted(np.tile(np.arange(w * 10_000, w * 10_000 + 5_000), (nq, 1)), axis=1)[:, :k] for w in range(W)]).astype(np.int64)
+    order = np.lexsort((ids, -sc), axis=2)                                         # every shard list sorted by (score desc, id asc)
+    sc = np.take_along_axis(sc, order, 2); ids = np.take_along_axis(ids, order, 2)
+    ms, mi = merge_topk(sc, ids, k)
+    cs = np.transpose(sc, (1, 0, 2)).reshape(nq, W * k); ci = np.transpose(ids, (1, 0, 2)).reshape(nq, W * k)
+    o = np.lexsort((ci, -cs), axis=1)[:, :k]
+    assert np.array_equal(mi, np.take_along_axis(ci, o, 1)) and np.array_equal(ms, np.take_along_axis(cs, o, 1))
+
+
 def _tiny_model_dir(td, golden):
     from transformers import BertConfig
     from kirag_amd.retriever.encoders import E5Encoder

@@ -1,5 +1,5 @@
 """world_size-2 test of the N>1 search path with REAL device shards: two processes share the one GPU of the test box (each holds half of
-the corpus in a FlatIPIndex), queries live on the device, ShardedSearcher goes through search_into + all_gather + host merge.  The collective
+the corpus in a FlatIPIndex), queries live on the device, ShardedSearcher goes through search_into + ONE all_gather + the device merge.  The collective
 backend is gloo here (RCCL refuses two ranks on one device); on a multi-GPU node the same code runs over backend "nccl" = RCCL."""
 import os
 import socket
@@ -37,6 +37,12 @@ def _worker(rank, world, port, ret):
         s, i = ShardedSearcher(ix, row_offset=a, world=world).search(torch.from_numpy(q).cuda(), k)
         so, io = S.search_canonical(q, x, k)
         assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+        # a shard with fewer rows than k contributes what it has (padded lists through the device merge)
+        lo, hi = (0, 5) if rank == 0 else (5, 605)
+        small = FlatIPIndex(d, device=0); small.add(torch.from_numpy(x[lo:hi]).cuda())
+        s2, i2 = ShardedSearcher(small, row_offset=lo, world=world).search(torch.from_numpy(q).cuda(), 8)
+        so2, io2 = S.search_canonical(q, x[:605], 8)
+        assert np.array_equal(i2, io2) and np.array_equal(s2.view(np.uint32), so2.view(np.uint32))
         ret[rank] = "ok"
     except Exception:
         import traceback

@@ -156,6 +156,39 @@ def test_shard_merge_equals_unsharded_on_gpu():
     assert np.array_equal(oi, mi) and np.array_equal(om, ms)
 
 
+def test_device_merge_equals_host_merge():
+    """kr_topk_merge_device (rank-by-binary-search over the gathered lists in HBM) == kr_topk_merge, with ties across shards, padded
+    (short) shards, an all-padding shard and strided list blocks (the [ids | scores] byte blocks of ShardedSearcher)."""
+    import torch
+    from kirag_amd import _lib
+    from kirag_amd.parallel import merge_topk
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    for W, nq, k in ((8, 300, 100), (3, 17, 1), (2, 5, 1024), (5, 40, 37)):
+        sc = np.round(rng.standard_normal((W, nq, k)).astype(np.float32), 1)
+        ids = np.stack([rng.permuted(np.tile(np.arange(w * 100_000, w * 100_000 + max(2 * k, 64)), (nq, 1)), axis=1)[:, :k] for w in range(W)]).astype(np.int64)
+        order = np.lexsort((ids, -sc), axis=2)
+        sc = np.take_along_axis(sc, order, 2); ids = np.take_along_axis(ids, order, 2)
+        if k > 1:
+            sc[1, :, k // 2:] = -np.inf; ids[1, :, k // 2:] = -1          # a short shard
+        if W > 2:
+            sc[2, 0] = -np.inf; ids[2, 0] = -1                              # nothing from shard 2 for query 0
+        hs, hi = merge_topk(sc, ids, k)
+        block = (nq * k * 12 + 15) // 16 * 16
+        buf = torch.zeros(W * block, dtype=torch.uint8)
+        for w in range(W):
+            buf[w * block:w * block + nq * k * 8] = torch.from_numpy(ids[w].reshape(-1).view(np.uint8))
+            buf[w * block + nq * k * 8:w * block + nq * k * 12] = torch.from_numpy(sc[w].reshape(-1).view(np.uint8))
+        dbuf = buf.cuda()
+        os_ = torch.empty((nq, k), dtype=torch.float32, device="cuda"); oi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        _lib.check(lib.kr_topk_merge_device(dbuf.data_ptr() + nq * k * 8, block // 4, dbuf.data_ptr(), block // 8, W, nq, k,
+                                            os_.data_ptr(), oi.data_ptr(), 0, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(oi.cpu().numpy(), hi) and np.array_equal(os_.cpu().numpy().view(np.uint32), hs.view(np.uint32))
+    with pytest.raises(_lib.KiragAmdError):
+        _lib.check(lib.kr_topk_merge_device(dbuf.data_ptr(), 1, dbuf.data_ptr(), 1, 9, 1, 1024, os_.data_ptr(), oi.data_ptr(), 0, None))
+
+
 def test_serialize_roundtrip(tmp_path):
     rng = np.random.default_rng(14)
     x = _unit(rng, 1234, 64)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Per-rank work of `bench.py --gpus W` measured on ONE GPU (no collectives): for W in 1, 2, 4, 8 the rank's share of the strong-scaling job
+(5M x 1024 corpus / W rows resident, 1000 / W queries x 32 tokens through the encoder, all 1000 query vectors searched top-100 over the
+local shard, device merge of W lists + D2H of the result).  The sum of the stages bounds the step time of the W-GPU run from below (the two all-gathers, 4 MB of
+query vectors and 1.2 MB of results per rank, come on top).  Usage: python tools/scale_emulate.py [total_rows]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from kirag_amd import bench_support as BS
+from kirag_amd import _lib
+from kirag_amd.retriever.index import FlatIPIndex
+
+total = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+nq, k, d = 1000, 100, 1024
+dev = torch.device("cuda:0")
+enc = BS.make_hip_encoder(dev)
+ids, mask = BS.synthetic_tokens(dev, nq, 32, seed=2)
+
+
+def timed(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3, out
+
+
+base = None
+for world in (1, 2, 4, 8):
+    n = (total + world - 1) // world
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    ix = FlatIPIndex(d, device=0); ix.reserve(n)
+    for s0 in range(0, n, 250_000):
+        m = min(250_000, n - s0)
+        ix.add(torch.nn.functional.normalize(torch.randn(m, d, generator=g, device=dev), dim=1))
+    mine = nq // world
+    ms_e, _ = timed(lambda: enc.forward(ids[:mine], mask[:mine], 0))
+    qv = enc.forward(ids, mask, 0)
+    sc = torch.empty((nq, k), dtype=torch.float32, device=dev); rows = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    ms_s, _ = timed(lambda: ix.search_into(qv, k, sc, rows))
+    coarse = ix.stats()["last_coarse_ms"]
+    # the W gathered lists (here: W copies of the local one, with distinct id ranges) merged on the device + the D2H of the final [nq, k]
+    block = (nq * k * 12 + 15) // 16 * 16
+    allb = torch.empty(world * block, dtype=torch.uint8, device=dev)
+    for w in range(world):
+        allb[w * block:w * block + nq * k * 8].view(torch.int64).copy_((rows + w * n).view(-1))
+        allb[w * block + nq * k * 8:w * block + nq * k * 12].view(torch.float32).copy_(sc.view(-1))
+    out_s = torch.empty_like(sc); out_i = torch.empty_like(rows)
+    pin_s = torch.empty((nq, k), dtype=torch.float32, pin_memory=True); pin_i = torch.empty((nq, k), dtype=torch.int64, pin_memory=True)
+    lib = _lib.load()
+
+    def merge():
+        _lib.check(lib.kr_topk_merge_device(allb.data_ptr() + nq * k * 8, block // 4, allb.data_ptr(), block // 8, world, nq, k,
+                                            out_s.data_ptr(), out_i.data_ptr(), 0, torch.cuda.current_stream().cuda_stream))
+        pin_s.copy_(out_s, non_blocking=True); pin_i.copy_(out_i, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return pin_s.numpy().copy(), pin_i.numpy().copy()
+    ms_m = timed(merge)[0] if world > 1 else 0.0
+    tot = ms_e + ms_s + ms_m
+    base = base or tot
+    print(f"W={world}: encode {mine} queries {ms_e:.2f} ms | search 1000 x {n} rows {ms_s:.2f} ms (coarse {coarse:.2f}) | device merge + D2H of the result {ms_m:.2f} ms | "
+          f"sum {tot:.2f} ms -> {nq / tot * 1e3:.0f} q/s, x{base / tot:.2f} vs W=1", flush=True)
+    del ix
+    torch.cuda.empty_cache()
