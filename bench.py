@@ -234,7 +234,7 @@ def main():
                        "rows_per_gpu": n, "dim": d, "queries": nq, "topk": k, "total_rows": total,
                        "encoder_in_step": encoder is not None,
                        "parallelism": f"corpus row-sharded x{world}, query batch split x{world} for encoding, all-gather of query vectors and of "
-                                      f"per-shard top-k, host merge"},
+                                      f"per-shard top-k, device merge"},
             "roofline": {"bound": "mfma", "achieved": flops / coarse / 1e12, "peak": PEAK_MFMA_DENSE_16BIT / 1e12, "unit": "TFLOP/s",
                          "frac": flops / coarse / PEAK_MFMA_DENSE_16BIT, "traffic": traffic, "traffic_unit": "GB per scan (FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src, "algorithmic_gb": n * d * 2 / 1e9, "kernel": "k_coarse", "rows_scanned": n,

@@ -30,7 +30,6 @@ using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LD
 // with 4 slots = 3 K-tiles in flight (4 x 32 KiB + 4 x 4 KiB of epilogue stage = 144 KiB: one block per CU)
 
 using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB ring, two blocks per CU: for launches with too few 256x256 tiles to fill the chip
-using ShapeSmall8 = GemmShape<128, 128, 4, 2>;  // the same tile on 8 waves of 32 tokens x 64 features: two waves per SIMD cover each other's LDS / barrier stalls when a CU holds ONE block
 
 // both main loops run with exchanged MFMA operands (accumulators hold 4 consecutive features per lane):
 // 256x256 tiles -> ping-pong loop; 128x128 tiles (small token counts: 4x the tiles, a quarter of the latency each) -> streaming loop
@@ -345,6 +344,38 @@ __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char*
 //   EPI_QKV:   F = 3H: features [0,H) -> q (bias, 1/8 folded into the weights), [H,2H) -> k, [2H,3H) -> V^T (its bias lives in bo_eff)
 //   EPI_DENSE: out0[T,F] = acc as bf16 (k_ln adds the bias and the residual in fp32)
 //   EPI_GELU:  out0[T,F] = gelu(acc + bias)
+template <int EPI, class ShapeE>
+__device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>& acc, int64_t m0, int64_t n0, char* stage) {
+    const int64_t t0 = m0 + acc.m_wave;
+    const int f0 = (int)n0 + acc.n_wave;          // first feature of this wave's 64 columns; F % 64 == 0, so a wave is never partial
+    if (f0 >= a.F) return;
+    const int h = acc.lane >> 5;
+    f32x4 b[2][4];                                // bias of the lane's 32 features: (ni, g) -> features ni*32 + 8g + 4h .. +3
+    if constexpr (EPI != EPI_DENSE) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b[ni][g] = *reinterpret_cast<const f32x4*>(a.bias + f0 + ni * 32 + 8 * g + 4 * h);
+    }
+    if constexpr (EPI == EPI_QKV) {
+        const int region = f0 / a.H;              // H % 64 == 0: a wave's columns never straddle q | k | v
+        if (region == 2) {
+            store_transposed_bf16<ShapeE>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H);   // value bias lives in bo_eff
+        } else {
+            store_rows_bf16<ShapeE>(acc, stage, region ? a.out1 : a.out0, a.H, t0, f0 - region * a.H,
+                                    [&](f32x4 v, int ni, int g) { return v + b[ni][g]; });
+        }
+    } else if constexpr (EPI == EPI_DENSE) {
+        store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int, int) { return v; });   // the bias is added in k_ln (fp32)
+    } else {
+        store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int ni, int g) {
+            const f32x4 x = v + b[ni][g];
+            const f32x2 lo = gelu_erf_fast2(f32x2{x.x, x.y}), hi = gelu_erf_fast2(f32x2{x.z, x.w});
+            return f32x4{lo.x, lo.y, hi.x, hi.y};
+        });
+    }
+}
+
 template <int EPI, class ShapeE, int STAGES>
 __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -358,36 +389,25 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
             patch_coord(nat, tm_count, tn_count, tm, tn);
             m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
         },
-        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) {
-            const int64_t t0 = m0 + acc.m_wave;
-            const int f0 = (int)n0 + acc.n_wave;          // first feature of this wave's 64 columns; F % 64 == 0, so a wave is never partial
-            if (f0 >= a.F) return;
-            const int h = acc.lane >> 5;
-            f32x4 b[2][4];                                // bias of the lane's 32 features: (ni, g) -> features ni*32 + 8g + 4h .. +3
-            if constexpr (EPI != EPI_DENSE) {
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) b[ni][g] = *reinterpret_cast<const f32x4*>(a.bias + f0 + ni * 32 + 8 * g + 4 * h);
-            }
-            if constexpr (EPI == EPI_QKV) {
-                const int region = f0 / a.H;              // H % 64 == 0: a wave's columns never straddle q | k | v
-                if (region == 2) {
-                    store_transposed_bf16<ShapeE>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H);   // value bias lives in bo_eff
-                } else {
-                    store_rows_bf16<ShapeE>(acc, stage, region ? a.out1 : a.out0, a.H, t0, f0 - region * a.H,
-                                            [&](f32x4 v, int ni, int g) { return v + b[ni][g]; });
-                }
-            } else if constexpr (EPI == EPI_DENSE) {
-                store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int, int) { return v; });   // the bias is added in k_ln (fp32)
-            } else {
-                store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int ni, int g) {
-                    const f32x4 x = v + b[ni][g];
-                    const f32x2 lo = gelu_erf_fast2(f32x2{x.x, x.y}), hi = gelu_erf_fast2(f32x2{x.z, x.w});
-                    return f32x4{lo.x, lo.y, hi.x, hi.y};
-                });
-            }
-        });
+        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeE>(a, acc, m0, n0, stage); });
+}
+
+// the same projections on the producer / consumer 128x128 loop (gemm_nt_split): 4 multiplying + 4 staging waves, 4-slot ring + one 4-KiB epilogue
+// stage per multiplying wave = 144 KiB, one persistent block per CU
+template <int EPI>
+__global__ __launch_bounds__(SPLIT_THREADS) void k_proj_split(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = *a.Tp;
+    const int64_t tm_count = (T + 127) / 128, tn_count = (a.F + 127) / 128;
+    char* stage = smem + SPLIT_RING * ShapeSplit::STAGE_BYTES + ((threadIdx.x >> 6) & 3) * EPI_STAGE_BYTES;
+    gemm_nt_split<BF16, true>(
+        a.X, a.K, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
+        [&](int64_t nat, int64_t& m0, int64_t& n0) {
+            int64_t tm, tn;
+            patch_coord(nat, tm_count, tn_count, tm, tn);
+            m0 = tm * 128; n0 = tn * 128;
+        },
+        [&](AccTile<ShapeSplit>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeSplit>(a, acc, m0, n0, stage); });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -753,9 +773,22 @@ static int launch_proj(int epi, const ProjArgs& a, int64_t max_tokens, int num_c
     const int force = fe ? atoi(fe) : 0;
     const bool small = force == 128 || (force != 256 && big_tiles * 8 < (int64_t)num_cu * 5);   // measured crossover: ~5/8 of the CUs busy with 256x256 tiles
     if (!small) return launch_proj_shape<ShapeBig, 2>(epi, a, num_cu, device, st);
-    if (small_tiles <= num_cu && force != 128) {
+    // producer/consumer loop (one persistent block per CU): at most one tile per CU, or more than two (measured: 600 tiles -7 % vs the streaming loop
+    // with two blocks per CU; between one and two tiles per CU the two co-resident streaming blocks quantise better).  130 forces it, 128 / 129 the others
+    if (((small_tiles <= num_cu || small_tiles > 2 * num_cu) && force != 128) || force == 130) {
         if (force == 129) return launch_proj_shape<ShapeSmall, 4>(epi, a, num_cu, device, st);
-        return launch_proj_shape<ShapeSmall8, 4>(epi, a, num_cu, device, st);
+        constexpr int lds = SPLIT_RING * ShapeSplit::STAGE_BYTES + 4 * EPI_STAGE_BYTES;
+        static bool attr_set_dev[64] = {};
+        if (!attr_set_dev[device & 63]) {
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_split<EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_split<EPI_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_split<EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set_dev[device & 63] = true;
+        }
+        if (epi == EPI_QKV) hipLaunchKernelGGL(k_proj_split<EPI_QKV>, dim3(num_cu), dim3(SPLIT_THREADS), lds, st, a);
+        else if (epi == EPI_DENSE) hipLaunchKernelGGL(k_proj_split<EPI_DENSE>, dim3(num_cu), dim3(SPLIT_THREADS), lds, st, a);
+        else hipLaunchKernelGGL(k_proj_split<EPI_GELU>, dim3(num_cu), dim3(SPLIT_THREADS), lds, st, a);
+        return 0;
     }
     return launch_proj_shape<ShapeSmall, 2>(epi, a, 2 * num_cu, device, st);
 }

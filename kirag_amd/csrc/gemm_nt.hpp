@@ -214,6 +214,141 @@ __device__ __forceinline__ void gemm_nt_stream(const uint16_t* __restrict__ A, i
 }
 
 // =====================================================================================================================
+// split main loop: PRODUCER / CONSUMER waves on a 128x128x64 tile, for launches whose 256x256 tiling has too few tiles to fill the chip.
+// A block has 8 waves (two per SIMD): waves 0..3 only multiply (64x64 each: per K-tile 16 MFMAs + the 16 ds_read_b128 of the fragments two
+// k-steps ahead, nothing else), waves 4..7 only stage (8 LDS-DMA pieces each per K-tile, counted waits).  A wave issues in order, so in the
+// streaming loop above every DMA issue (~45 cycles per 1-KiB piece), every LDS round trip at a K-tile start and every barrier skew is time in
+// which that wave's SIMD issues no MFMA; with one block per CU nothing covers it (the 128x128 streaming loop reaches ~50 % MFMA duty).  Here
+// the matrix pipe of each SIMD has a wave that never touches global memory.
+// Ring of 4 K-tiles (4 x 32 KiB), ONE s_barrier per K-tile g (plus one start barrier), executed by all 8 waves:
+//   producers: wait until tiles g and g+1 have landed (vmcnt: only tile g+2 may be in flight) -> barrier g -> issue tile g+3 into slot (g+3)&3
+//              = the slot of tile g-1, which every consumer has finished reading before it arrived at barrier g;
+//   consumers: barrier g -> k-steps 0..3 of tile g; the fragments of k-step s+2 are loaded during k-step s, so during k-steps 2, 3 they come
+//              from tile g+1, which barrier g already guarantees to be resident: no LDS latency is exposed at a K-tile boundary.
+// The K-tile stream runs across output tiles; producers run up to 3 K-tiles ahead while the consumers are in an epilogue.
+// Accumulation order per output element is the same as in the other two loops (K-tiles in order, k-steps in order): results are bit-identical.
+// =====================================================================================================================
+using ShapeSplit = GemmShape<128, 128, 2, 2>;   // the consumer waves' view of the tile (the block has 2 x NWAVE waves)
+constexpr int SPLIT_RING = 4;
+constexpr int SPLIT_THREADS = 512;
+
+template <class T, bool SWAP = false, class Coord, class Epilogue>
+__device__ __forceinline__ void gemm_nt_split(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb,
+                                              int64_t N, int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
+    using Shape = ShapeSplit;
+    constexpr int BK = Shape::BK, STAGE = Shape::STAGE_BYTES, ABYTES = Shape::A_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t G = gridDim.x;
+    const int64_t my = (total_tiles > (int64_t)blockIdx.x) ? (total_tiles - blockIdx.x + G - 1) / G : 0;
+    if (my == 0) return;
+    const int nk = K / BK;
+    const int64_t total_g = my * nk;
+
+    if (wave >= 4) {
+        // ---------------------------------------------------------------- producers ----------------------------------------------------------------
+        const int lw = wave - 4;                       // pieces lw, lw+4, lw+8, lw+12 of A and of B (a piece = 8 rows x 128 B = 1 KiB)
+        const char* pfA; const char* pfB;
+        uint32_t a_off[4], b_off[4];
+        auto setup_src = [&](int64_t i) {
+            int64_t m0, n0;
+            coord(xcd_chunk_map((int64_t)blockIdx.x + i * G, total_tiles), m0, n0);
+            pfA = reinterpret_cast<const char*>(A + m0 * lda);
+            pfB = reinterpret_cast<const char*>(B + n0 * ldb);
+            const int64_t a_left = M - m0, b_left = N - n0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = (lw + 4 * p) * 8 + (lane >> 3);
+                const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+                const int ra = row >= a_left ? (int)a_left - 1 : row, rb = row >= b_left ? (int)b_left - 1 : row;
+                a_off[p] = (uint32_t)(ra * lda * 2 + chunk * 16);
+                b_off[p] = (uint32_t)(rb * ldb * 2 + chunk * 16);
+            }
+        };
+        int64_t pf_g = 0, pf_tile = 0;
+        int pf_kt = 0;
+        setup_src(0);
+        auto stage_next = [&]() {
+            char* sa = smem + (int)(pf_g & (SPLIT_RING - 1)) * STAGE;
+            char* sb = sa + ABYTES;
+            const int64_t kbyte = (int64_t)pf_kt * BK * 2;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(pfA + kbyte + a_off[p]), (lds_void*)(sa + (lw + 4 * p) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(pfB + kbyte + b_off[p]), (lds_void*)(sb + (lw + 4 * p) * 1024), 16, 0, 0);
+            ++pf_g;
+            if (++pf_kt == nk) { pf_kt = 0; if (++pf_tile < my) setup_src(pf_tile); }
+        };
+#pragma unroll
+        for (int p = 0; p < SPLIT_RING - 1; ++p)
+            if (pf_g < total_g) stage_next();
+        if (total_g > 2) wait_vmcnt<8>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                                        // start barrier: tiles 0 and 1 are resident (the consumers load their first fragments)
+        for (int64_t g = 0; g < total_g; ++g) {
+            if (g + 2 < total_g) wait_vmcnt<8>(); else wait_vmcnt<0>();      // tiles g and g+1 landed; g+2 may still be in flight
+            __builtin_amdgcn_s_barrier();
+            if (pf_g < total_g) stage_next();                                // tile g+3 -> the slot of tile g-1
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumers ----------------------------------------------------------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int fswz = (frow >> 1) & 7;
+    const int a_row_byte = (wm * 64 + frow) * 128;
+    const int b_row_byte = ABYTES + (wn * 64 + frow) * 128;
+    uint4 af[4][2], bf[4][2];                              // fragment buffers, one per k-step of a K-tile (loaded two k-steps ahead)
+    auto load_frags = [&](int64_t g, int ks, int buf) {
+        const char* st = smem + (int)(g & (SPLIT_RING - 1)) * STAGE;
+        const int coff = ((2 * ks + fh) ^ fswz) << 4;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[buf][mi] = *reinterpret_cast<const uint4*>(st + a_row_byte + mi * 32 * 128 + coff);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bf[buf][ni] = *reinterpret_cast<const uint4*>(st + b_row_byte + ni * 32 * 128 + coff);
+    };
+    int64_t g = 0;
+    __builtin_amdgcn_s_barrier();                          // start barrier (see the producers)
+    load_frags(0, 0, 0); load_frags(0, 1, 1);
+    for (int64_t i = 0; i < my; ++i) {
+        int64_t m0, n0;
+        const int64_t nat = xcd_chunk_map((int64_t)blockIdx.x + i * G, total_tiles);
+        coord(nat, m0, n0);
+        AccTile<Shape> acc;
+        acc.m_wave = wm * 64;
+        acc.n_wave = wn * 64;
+        acc.lane = lane;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.v[mi][ni][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                // unconditional (no branch in the loop body, so the compiler keeps COUNTED lgkmcnt waits): past the end of the stream the reads
+                // hit a stale ring slot and are never used
+                if (ks < 2) load_frags(g, ks + 2, ks + 2);
+                else load_frags(g + 1, ks - 2, ks - 2);
+                __builtin_amdgcn_sched_barrier(0);         // keep the two-k-step prefetch distance (the scheduler would sink the reads next to their use)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc.v[mi][ni] = SWAP ? T::mfma(bf[ks][ni], af[ks][mi], acc.v[mi][ni]) : T::mfma(af[ks][mi], bf[ks][ni], acc.v[mi][ni]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        epi(acc, m0, n0, nat);
+    }
+}
+
+// =====================================================================================================================
 // v3 main loop: PING-PONG.  256x256x64 tiles, 8 waves = two groups of four (group = wave >> 2 owns tile rows
 // [128*group, +128), wave & 3 owns 64 columns; waves w and w+4 share a SIMD, so every SIMD hosts one wave of each group).
 // Time is cut into intervals separated by ONE s_barrier each; in every interval one group multiplies (16 MFMAs of

@@ -40,6 +40,28 @@ __global__ __launch_bounds__(Shape::NTHREADS, (Shape::NTHREADS / 256)) void k_st
         });
 }
 
+// producer / consumer 128x128 loop, same epilogue (threads 0..255 are the consumers, same wave -> sub-tile map as k_stream<128,128,2,2>)
+__global__ __launch_bounds__(512) void k_split(const uint16_t* A, const uint16_t* B, float* out, float* sums, int64_t M, int64_t N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Shape = ShapeSplit;
+    const int64_t tm_count = M / Shape::BM, tn_count = N / Shape::BN;
+    gemm_nt_split<BF16>(
+        A, K, M, B, K, N, K, tm_count * tn_count, smem,
+        [&](int64_t nat, int64_t& m0, int64_t& n0) { int64_t tm, tn; patch_coord(nat, tm_count, tn_count, tm, tn); m0 = tm * Shape::BM; n0 = tn * Shape::BN; },
+        [&](AccTile<Shape>& acc, int64_t m0, int64_t n0, int64_t) {
+            float s = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < Shape::TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < Shape::TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += acc.v[mi][ni][r];
+            if (s == 12345.678f) out[0] = s;
+            if (threadIdx.x == 0 && m0 == 0 && n0 == 0) out[1] = acc.v[0][0][0];
+            if (sums) sums[((m0 / Shape::BM) * tn_count + n0 / Shape::BN) * Shape::NTHREADS + threadIdx.x] = s;
+        });
+}
+
 // v3 ping-pong main loop, same epilogue
 __global__ __launch_bounds__(512, 2) void k_pp(const uint16_t* A, const uint16_t* B, float* out, float* sums, int64_t M, int64_t N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -241,6 +263,30 @@ int main(int argc, char** argv) {
         run("filter " #bm_ "x" #bn_ " waves " #wm_ "x" #wn_ " stages " #ST " thr " #THR, [&] {                             \
             hipLaunchKernelGGL((k_stream_filter<S, ST>), dim3(256), dim3(S::NTHREADS), lds, 0, A, B, out, lists, M, N, K, THR); \
         });                                                                                                                 \
+    }
+    if (getenv("SPLIT_ONLY")) {   // producer/consumer 128x128 loop vs the 128x128 streaming loop: bit-identical per-thread checksums, timing at 1 block per CU
+        const size_t nsum = (size_t)(M / 128) * (N / 128) * 256;
+        float *s2, *s3; CK(hipMalloc(&s2, nsum * 4)); CK(hipMalloc(&s3, nsum * 4));
+        using S = GemmShape<128, 128, 2, 2>;
+        const int lds = 4 * S::STAGE_BYTES;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream<S, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream<S, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 2));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_split), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CK(hipMemset(s2, 0xff, nsum * 4));
+        run("stream 128x128 stages 4, grid 256 (+sums)", [&] { hipLaunchKernelGGL((k_stream<S, 4>), dim3(256), dim3(256), lds, 0, A, B, out, s2, M, N, K); });
+        for (int grid : {256, 248, 64}) {
+            char nm[64]; snprintf(nm, sizeof nm, "split 128x128 grid %d (+sums)", grid);
+            CK(hipMemset(s3, 0xee, nsum * 4));
+            run(nm, [&] { hipLaunchKernelGGL(k_split, dim3(grid), dim3(512), lds, 0, A, B, out, s3, M, N, K); });
+            std::vector<float> h2(nsum), h3(nsum);
+            CK(hipMemcpy(h2.data(), s2, nsum * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h3.data(), s3, nsum * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0; for (size_t i = 0; i < nsum; ++i) bad += memcmp(&h2[i], &h3[i], 4) != 0;
+            printf("    split vs stream checksums: %zu / %zu differ %s\n", bad, nsum, bad ? "MISMATCH" : "ok");
+        }
+        run("stream 128x128 stages 4, grid 256 (no sums)", [&] { hipLaunchKernelGGL((k_stream<S, 4>), dim3(256), dim3(256), lds, 0, A, B, out, (float*)nullptr, M, N, K); });
+        run("stream 128x128 stages 2, grid 512 (no sums)", [&] { hipLaunchKernelGGL((k_stream<S, 2>), dim3(512), dim3(256), lds / 2, 0, A, B, out, (float*)nullptr, M, N, K); });
+        run("split 128x128 grid 256 (no sums)", [&] { hipLaunchKernelGGL(k_split, dim3(256), dim3(512), lds, 0, A, B, out, (float*)nullptr, M, N, K); });
+        return 0;
     }
     // ---- v3 ping-pong vs v2 stream: per-thread checksums of every output tile must agree bit for bit
     {
