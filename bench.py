@@ -224,7 +224,7 @@ def main():
         coarse = float(np.mean(coarse_ms)) * 1e-3           # seconds per coarse scan (sum of its round launches)
         flops = 2.0 * nq * n * d                             # algorithmic: every query against every row of the shard
         out = {
-            "metric": f"queries/sec (encode + exact top-{k} search), e5-large-v2 shape, {total / 1e6:g}M x {d} corpus",
+            "metric": f"queries/sec ({'encode + ' if encoder is not None else 'search only: '}exact top-{k} search), e5-large-v2 shape, {total / 1e6:g}M x {d} corpus",
             "value": nq * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": args.coarse_dtype + " MFMA coarse scan / fp64 exact re-rank",
