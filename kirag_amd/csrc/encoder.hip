@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace kr {
@@ -410,6 +411,44 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_proj_split(ProjArgs a) {
         [&](AccTile<ShapeSplit>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeSplit>(a, acc, m0, n0, stage); });
 }
 
+// the same projections for a handful of token rows on the skinny loop (gemm_nt_skinny): one 32-token x 32-feature tile per block, grid = (F / 32, T / 32).
+// Epilogue straight from the accumulator (swapped layout: a lane holds 4 consecutive features of one token per register quad): 8-byte row stores,
+// 2-byte stores for V^T — at these sizes the stores are noise next to the operand stream.
+template <int EPI, int RING>
+__global__ __launch_bounds__(SKINNY_THREADS) void k_proj_skinny(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = *a.Tp;
+    const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+    if (m0 >= T) return;                                  // block-uniform, before any barrier
+    gemm_nt_skinny<BF16, RING, true>(a.X, a.K, T, m0, a.W, a.K, a.F, n0, a.K, smem, [&](AccTile<ShapeSkinny>& acc, int64_t t0, int64_t f0) {
+        const int c = acc.lane & 31, h = acc.lane >> 5;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {acc.v[0][0][4 * g], acc.v[0][0][4 * g + 1], acc.v[0][0][4 * g + 2], acc.v[0][0][4 * g + 3]};
+            const int f = (int)f0 + 8 * g + 4 * h;        // first of the lane's 4 consecutive features
+            if constexpr (EPI == EPI_QKV) {
+                const int region = (int)f0 / a.H;
+                if (region == 2) {                        // V^T [feature, token]; its bias lives in bo_eff
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a.outT[(int64_t)(f - 2 * a.H + j) * a.ldT + t0 + c] = BF16::from_f32(v[j]);
+                    continue;
+                }
+                v = v + *reinterpret_cast<const f32x4*>(a.bias + f);
+                uint2 w; w.x = pack_bf16x2(v.x, v.y); w.y = pack_bf16x2(v.z, v.w);
+                *reinterpret_cast<uint2*>((region ? a.out1 : a.out0) + (t0 + c) * a.H + (f - region * a.H)) = w;
+            } else {
+                if constexpr (EPI == EPI_GELU) {
+                    v = v + *reinterpret_cast<const f32x4*>(a.bias + f);
+                    const f32x2 lo = gelu_erf_fast2(f32x2{v.x, v.y}), hi = gelu_erf_fast2(f32x2{v.z, v.w});
+                    v = f32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+                uint2 w; w.x = pack_bf16x2(v.x, v.y); w.y = pack_bf16x2(v.z, v.w);
+                *reinterpret_cast<uint2*>(a.out0 + (t0 + c) * a.F + f) = w;
+            }
+        }
+    });
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // attention, LDS-staged: one block (4 waves) per (sequence, group of HPB heads, group of 4 / HPB q-tiles).  K [keys][64] and V^T [64][keys] of
 // the block's heads are staged in LDS in chunks of (at most) 128 keys — 49 KiB per block for any sequence length, three blocks per CU; the
@@ -772,6 +811,28 @@ static int launch_proj(int epi, const ProjArgs& a, int64_t max_tokens, int num_c
     const char* fe = getenv("KIRAG_AMD_PROJ_TILE");   // 128 / 256 force a path (tests run every parity case through both); read per call
     const int force = fe ? atoi(fe) : 0;
     const bool small = force == 128 || (force != 256 && big_tiles * 8 < (int64_t)num_cu * 5);   // measured crossover: ~5/8 of the CUs busy with 256x256 tiles
+    // a handful of token rows: 32x32 tiles, one per block (latency chain: the operand stream of the launch spread over as many CUs as it has tiles).
+    // Used while the launch has at most 4 tiles per CU (measured crossover against the 128x128 producer / consumer loop); 32 forces it
+    const int64_t skinny_tiles = ((max_tokens + 31) / 32) * (a.F / 32);
+    if (force == 32 || (force == 0 && skinny_tiles <= 4 * (int64_t)num_cu && (max_tokens + 31) / 32 <= 65535)) {
+        const dim3 grid((unsigned)(a.F / 32), (unsigned)((max_tokens + 31) / 32));
+        auto launch = [&](auto ring_tag) -> int {
+            constexpr int RING = decltype(ring_tag)::value;
+            constexpr int lds = RING * SKINNY_STAGE;
+            static bool sk_attr_set_dev[64] = {};
+            if (!sk_attr_set_dev[device & 63]) {
+                KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_skinny<EPI_QKV, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_skinny<EPI_DENSE, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_skinny<EPI_GELU, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                sk_attr_set_dev[device & 63] = true;
+            }
+            if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj_skinny<EPI_QKV, RING>), grid, dim3(SKINNY_THREADS), lds, st, a);
+            else if (epi == EPI_DENSE) hipLaunchKernelGGL((k_proj_skinny<EPI_DENSE, RING>), grid, dim3(SKINNY_THREADS), lds, st, a);
+            else hipLaunchKernelGGL((k_proj_skinny<EPI_GELU, RING>), grid, dim3(SKINNY_THREADS), lds, st, a);
+            return 0;
+        };
+        return skinny_tiles <= num_cu ? launch(std::integral_constant<int, 16>{}) : launch(std::integral_constant<int, 4>{});
+    }
     if (!small) return launch_proj_shape<ShapeBig, 2>(epi, a, num_cu, device, st);
     // producer/consumer loop (one persistent block per CU): at most one tile per CU, or more than two (measured: 600 tiles -7 % vs the streaming loop
     // with two blocks per CU; between one and two tiles per CU the two co-resident streaming blocks quantise better).  130 forces it, 128 / 129 the others

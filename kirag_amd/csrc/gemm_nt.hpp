@@ -349,6 +349,96 @@ __device__ __forceinline__ void gemm_nt_split(const uint16_t* __restrict__ A, in
 }
 
 // =====================================================================================================================
+// skinny main loop: ONE 32x32 output tile per block, for launches with a handful of token rows (a query or two, the reference's batches of 4-8 passages).
+// Such a GEMM is a latency chain, not a throughput problem: a CU that streams B bytes of operands with R bytes in flight needs (B / R) memory round
+// trips, so the time falls with the number of CUs the operand stream is spread over — 32 x 32 tiles give F/32 x T/32 of them (FF2 at 32 tokens: 32 CUs
+// x 512 KiB instead of 8 CUs x 2 MiB with 128x128 tiles) — and with the ring depth.  Split-K would spread further but changes the summation order;
+// here every output element is still ONE accumulator chain over k in increasing order with the same MFMA instruction, so rows stay bit-identical to
+// the other loops.
+// Block = 5 waves: wave 0 multiplies (2 ds_read_b128 + 1 MFMA per k-step, fragments two k-steps ahead), waves 1..4 stage (per K-tile 4 + 4 pieces
+// of 1 KiB: 32 rows x 128 B of each operand, 2 pieces per staging wave) into a ring of RING K-tiles of 8 KiB; one s_barrier per K-tile, same
+// protocol as gemm_nt_split with the ring depth as the only difference (tiles g, g+1 resident at barrier g, tile g+RING-1 issued after it).
+// =====================================================================================================================
+using ShapeSkinny = GemmShape<32, 32, 1, 1>;
+// ring depth (template parameter RING): 16 x 8 KiB = 128 KiB, 13 K-tiles in flight, one block per CU — for launches with at most one tile per CU;
+// 4 x 8 KiB with up to five co-resident blocks per CU (the same bytes in flight per CU) when there are more tiles than CUs
+constexpr int SKINNY_THREADS = 320;
+constexpr int SKINNY_STAGE = 8192;
+
+template <class T, int RING, bool SWAP = false, class Epilogue>
+__device__ __forceinline__ void gemm_nt_skinny(const uint16_t* __restrict__ A, int64_t lda, int64_t M, int64_t m0, const uint16_t* __restrict__ B, int64_t ldb,
+                                               int64_t N, int64_t n0, int K, char* smem, Epilogue&& epi) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = K / 64;
+    if (wave >= 1) {
+        // ---------------------------------------------------------------- producers ----------------------------------------------------------------
+        const int lw = wave - 1;                       // piece lw of A and of B: rows 8 lw .. 8 lw + 7
+        const int row = lw * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int64_t a_left = M - m0, b_left = N - n0;
+        const int64_t ra = row >= a_left ? a_left - 1 : row, rb = row >= b_left ? b_left - 1 : row;
+        const char* pa = reinterpret_cast<const char*>(A + (m0 + ra) * lda) + chunk * 16;
+        const char* pb = reinterpret_cast<const char*>(B + (n0 + rb) * ldb) + chunk * 16;
+        int pf = 0;
+        auto stage_next = [&]() {
+            char* sa = smem + (pf & (RING - 1)) * SKINNY_STAGE + lw * 1024;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(pa + (int64_t)pf * 128), (lds_void*)sa, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(pb + (int64_t)pf * 128), (lds_void*)(sa + 4096), 16, 0, 0);
+            ++pf;
+        };
+        for (int p = 0; p < RING - 1; ++p)
+            if (pf < nk) stage_next();
+        // tiles 0 and 1 resident: at most min(nk, RING-1) - 2 tiles (2 pieces each) may stay in flight
+        auto wait_keep = [&](int tiles_in_flight) {
+            // counted wait with a run-time count: s_waitcnt takes an immediate, so pick from the few values that occur (ring full, or the tail)
+            if (tiles_in_flight >= RING - 3) wait_vmcnt<2 * (RING - 3)>();
+            else if (RING - 3 > 8 && tiles_in_flight >= 8) wait_vmcnt<16>();
+            else if (RING - 3 > 4 && tiles_in_flight >= 4) wait_vmcnt<8>();
+            else if (RING - 3 > 2 && tiles_in_flight >= 2) wait_vmcnt<4>();
+            else if (RING - 3 > 1 && tiles_in_flight >= 1) wait_vmcnt<2>();
+            else wait_vmcnt<0>();
+        };
+        wait_keep(pf - 2);
+        __builtin_amdgcn_s_barrier();                                        // start barrier
+        for (int g = 0; g < nk; ++g) {
+            wait_keep(pf - (g + 2));                                         // tiles g, g+1 landed; younger ones may be in flight
+            __builtin_amdgcn_s_barrier();
+            if (pf < nk) stage_next();                                       // tile g + RING - 1 -> the slot of tile g - 1
+        }
+        return;
+    }
+    // -------------------------------------------------------------------- consumer -----------------------------------------------------------------
+    const int frow = lane & 31, fh = lane >> 5;
+    const int fswz = (frow >> 1) & 7;
+    uint4 af[4], bf[4];
+    auto load_frags = [&](int g, int ks, int buf) {
+        const char* st = smem + (g & (RING - 1)) * SKINNY_STAGE + frow * 128 + (((2 * ks + fh) ^ fswz) << 4);
+        af[buf] = *reinterpret_cast<const uint4*>(st);
+        bf[buf] = *reinterpret_cast<const uint4*>(st + 4096);
+    };
+    AccTile<ShapeSkinny> acc;
+    acc.m_wave = 0; acc.n_wave = 0; acc.lane = lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc.v[0][0][r] = 0.f;
+    __builtin_amdgcn_s_barrier();                          // start barrier
+    load_frags(0, 0, 0); load_frags(0, 1, 1);
+    for (int g = 0; g < nk; ++g) {
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 2) load_frags(g, ks + 2, ks + 2);
+            else load_frags(g + 1, ks - 2, ks - 2);        // past the end: a stale slot, never used
+            __builtin_amdgcn_sched_barrier(0);
+            acc.v[0][0] = SWAP ? T::mfma(bf[ks], af[ks], acc.v[0][0]) : T::mfma(af[ks], bf[ks], acc.v[0][0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    epi(acc, m0, n0);
+}
+
+// =====================================================================================================================
 // v3 main loop: PING-PONG.  256x256x64 tiles, 8 waves = two groups of four (group = wave >> 2 owns tile rows
 // [128*group, +128), wave & 3 owns 64 columns; waves w and w+4 share a SIMD, so every SIMD hosts one wave of each group).
 // Time is cut into intervals separated by ONE s_barrier each; in every interval one group multiplies (16 MFMAs of

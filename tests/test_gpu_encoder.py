@@ -173,11 +173,11 @@ def test_long_and_many_sequences_vs_oracle(B, S):
         _check(out, ref, 4e-3, f"B{B} S{S} pool{pool}")
 
 
-@pytest.mark.parametrize("tile", ["256", "128"])
+@pytest.mark.parametrize("tile", ["256", "128", "130", "32"])
 def test_every_projection_path_on_every_shape(golden, tile, monkeypatch):
-    """The launcher picks the 256x256 ping-pong loop, the 128x128 2-slot loop or the 128x128 4-slot loop from the token count; force the
-    256x256 path and the 128x128 2-slot path on the full-size golden batch and on a ragged tiny-config batch (the default choice, covered by
-    the other tests, is the 4-slot path for these sizes)."""
+    """The launcher picks the 256x256 ping-pong loop, the 128x128 producer / consumer loop, the 128x128 2-slot streaming loop or the 32x32 skinny
+    loop from the token count; force each of them (KIRAG_AMD_PROJ_TILE = 256 / 130 / 128 / 32) on the full-size golden batch and on a ragged
+    tiny-config batch."""
     monkeypatch.setenv("KIRAG_AMD_PROJ_TILE", tile)
     g = golden("g2_encoder_large.npz")
     cfg = _cfg(g["cfg"])
@@ -194,3 +194,24 @@ def test_every_projection_path_on_every_shape(golden, tile, monkeypatch):
     h2 = _hip(cfg2, w2)
     ids, mask = E.synth_tokens(700, 48, seed=3, ragged=True, vocab_lo=5, vocab_hi=1000, min_len=3)
     _check(h2.forward_np(ids, mask, 0), E.e5_encode(w2, ids, mask, 2), 4e-3, f"tile{tile} tiny ragged")
+
+
+def test_projection_paths_are_bit_identical(golden, monkeypatch):
+    """Every output element is one MFMA accumulator chain over k in increasing order whatever the tile shape, so the four main loops must agree
+    BIT FOR BIT (the embedding cache and batch-size independence rely on it): full-size golden batch and a ragged tiny-config batch."""
+    g = golden("g2_encoder_large.npz")
+    cfg = _cfg(g["cfg"])
+    w = E.synth_weights(cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
+                        seed=int(g["weight_seed"]))
+    h = _hip(cfg, w)
+    cfg2 = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
+                           max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    h2 = _hip(cfg2, E.synth_weights(128, 2, 512, 1000, 512, seed=11))
+    ids2, mask2 = E.synth_tokens(700, 48, seed=3, ragged=True, vocab_lo=5, vocab_hi=1000, min_len=3)
+    outs = {}
+    for tile in ("256", "128", "130", "32"):
+        monkeypatch.setenv("KIRAG_AMD_PROJ_TILE", tile)
+        outs[tile] = (h.forward_np(g["e5.c1.ids"], g["e5.c1.mask"], 0), h2.forward_np(ids2, mask2, 0))
+    for tile in ("128", "130", "32"):
+        assert np.array_equal(outs[tile][0].view(np.uint32), outs["256"][0].view(np.uint32)), tile
+        assert np.array_equal(outs[tile][1].view(np.uint32), outs["256"][1].view(np.uint32)), tile
