@@ -641,17 +641,30 @@ __global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, c
     for (int j = 0; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int t_begin = pool == KR_POOL_CLS ? (wave == 0 ? seq_cls[b] : 1 << 30) : wave;
     const int t_end = pool == KR_POOL_CLS ? (wave == 0 ? seq_cls[b] + 1 : 0) : nk;
-    for (int t = t_begin; t < t_end; t += 4) {
+    // four of the wave's tokens per step: all their loads are issued before the first add (a long sequence is a chain of memory round trips for its
+    // one block); the adds keep the order t, t+4, t+8, ... so the result does not depend on the unrolling
+    for (int t = t_begin; t < t_end; t += 16) {
+        ushort4 hi[4][8], lo[4][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i = lane * 4 + j * 256;
-            if (i < H) {
-                const ushort4 hi = *reinterpret_cast<const ushort4*>(xb + (off + t) * H + i);
-                const ushort4 lo = *reinterpret_cast<const ushort4*>(xlo + (off + t) * H + i);
-                acc[j].x += BF16::to_f32(hi.x) + BF16::to_f32(lo.x); acc[j].y += BF16::to_f32(hi.y) + BF16::to_f32(lo.y);
-                acc[j].z += BF16::to_f32(hi.z) + BF16::to_f32(lo.z); acc[j].w += BF16::to_f32(hi.w) + BF16::to_f32(lo.w);
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = lane * 4 + j * 256;
+                if (i < H && t + 4 * u < t_end) {
+                    hi[u][j] = *reinterpret_cast<const ushort4*>(xb + (off + t + 4 * u) * H + i);
+                    lo[u][j] = *reinterpret_cast<const ushort4*>(xlo + (off + t + 4 * u) * H + i);
+                }
             }
-        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = lane * 4 + j * 256;
+                if (i < H && t + 4 * u < t_end) {
+                    acc[j].x += BF16::to_f32(hi[u][j].x) + BF16::to_f32(lo[u][j].x); acc[j].y += BF16::to_f32(hi[u][j].y) + BF16::to_f32(lo[u][j].y);
+                    acc[j].z += BF16::to_f32(hi[u][j].z) + BF16::to_f32(lo[u][j].z); acc[j].w += BF16::to_f32(hi[u][j].w) + BF16::to_f32(lo[u][j].w);
+                }
+            }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
