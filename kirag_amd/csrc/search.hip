@@ -157,14 +157,20 @@ struct CoarseArgs {
 //   moves the lists into the per-query buffers.
 constexpr int WLISTCAP = 8192;                      // entries per wave list (expected nq*cap/2/(8*num_blocks) ~ 1k-2k)
 constexpr int COARSE_LDS = COARSE_STAGES * ShapeC::STAGE_BYTES + QBLK * 4;
+constexpr int COARSE_LDS_SMALLQ = SPLIT_RING * ShapeSplit::STAGE_BYTES + QBLK * 4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // The 16-bit copy is padded with NaN rows up to a multiple of 256 (k_pad_nan): a partial last tile then needs no row test,
 // because NaN scores fail every `>=` and sort below every real key.
-template <class T, bool DIRECT>
-__global__ __launch_bounds__(ShapeC::NTHREADS, 2) void k_coarse(CoarseArgs a) {
+// SMALLQ (at most 128 queries in the block: the KiRAG loop's 1-2 queries per hop, single-question retrieval): 128-row x 128-query tiles on the
+// producer / consumer loop (gemm_nt_split) instead of 256 x 256 on the ping-pong loop.  With a 256-query tile a small batch pays the MFMA time of 256
+// queries (2.0 ms per 5M rows, above the 1.3-1.6 ms the corpus needs to cross HBM); with 128 the scan is HBM-bound.
+template <class T, bool DIRECT, bool SMALLQ = false>
+__global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
+    using S = std::conditional_t<SMALLQ, ShapeSplit, ShapeC>;      // S::NWAVE = waves that own accumulators (4 of the 8 with SMALLQ)
+    constexpr int RING_BYTES = SMALLQ ? SPLIT_RING * ShapeSplit::STAGE_BYTES : COARSE_STAGES * ShapeC::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* thr_s = reinterpret_cast<float*>(smem + COARSE_STAGES * ShapeC::STAGE_BYTES);
+    float* thr_s = reinterpret_cast<float*>(smem + RING_BYTES);
     if (!DIRECT) {
         for (int i = threadIdx.x; i < a.nq_pad; i += ShapeC::NTHREADS) thr_s[i] = a.thr[i];
         __syncthreads();
@@ -174,34 +180,32 @@ __global__ __launch_bounds__(ShapeC::NTHREADS, 2) void k_coarse(CoarseArgs a) {
     const __amdgpu_buffer_rsrc_t wlist = __builtin_amdgcn_make_buffer_rsrc(
         a.blk_list + ((int64_t)blockIdx.x * ShapeC::NWAVE + wave_id) * WLISTCAP, 0, WLISTCAP * 16, 0x00020000);
     unsigned int wcnt = 0;   // wave-uniform cursor into the list
-    const int64_t tn_count = a.nq_pad / ShapeC::BN;
+    const int64_t tn_count = a.nq_pad / S::BN;
     const int64_t total = a.tile_count * tn_count;
-    const int64_t n_pad = (a.n + ShapeC::BM - 1) / ShapeC::BM * ShapeC::BM;
+    const int64_t n_pad = (a.n + S::BM - 1) / S::BM * S::BM;
     // corpus loads are non-temporal: the corpus is a once-through stream (shared by the 4 CUs of an XCD that hold the other query tiles of the
     // same rows at about the same time), while the 2-MiB query block is re-read by every job; with default-policy corpus loads the stream
     // pushed the queries out of the 4-MiB L2 once per job (FETCH_SIZE 1.54x the corpus bytes; 1.18x with nt, profiles/)
-    gemm_nt_pingpong<T, false, true>(
-        a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem,
-        [&](int64_t nat, int64_t& m0, int64_t& n0) {
+    auto coord =         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             uint32_t tn, tile; uint64_t tslot, qq;                        // the query blocks of one corpus tile are adjacent
             // no 64-bit integer divisions (~150 VALU each, per tile, per wave); the fp64 form is exact below 2^53, which covers a 2^32-row shard
             fast_divmod64((uint64_t)nat, (uint32_t)tn_count, tslot, tn);
             fast_divmod64((uint64_t)(a.tile_begin + (int64_t)tslot) * (uint64_t)a.perm_mul, (uint32_t)a.ntiles, qq, tile);
-            m0 = (int64_t)tile * ShapeC::BM; n0 = (int64_t)tn * ShapeC::BN;
-        },
-        [&](AccTile<ShapeC>& acc, int64_t m0, int64_t n0, int64_t nat) {
+            m0 = (int64_t)tile * S::BM; n0 = (int64_t)tn * S::BN;
+        };
+    auto epi = [&](AccTile<S>& acc, int64_t m0, int64_t n0, int64_t nat) {
             const int lane_row0 = acc.m_wave + 4 * (acc.lane >> 5);    // register (mi, r) is tile row lane_row0 + mi*32 + (r&3) + 8*(r>>2)
             const uint32_t row_base = (uint32_t)m0 + (uint32_t)lane_row0;
             if constexpr (DIRECT) {
                 // round 0, thr = -inf: every score goes to slot (tile slot in round)*BM + row in tile of its query's buffer
 #pragma unroll
-                for (int ni = 0; ni < ShapeC::TN; ++ni) {
+                for (int ni = 0; ni < S::TN; ++ni) {
                     const int q = (int)n0 + acc.col(ni);
                     if (q < a.nq) {
                         uint64_t tslot_d; uint32_t tn_d; fast_divmod64((uint64_t)nat, (uint32_t)tn_count, tslot_d, tn_d);
-                        uint64_t* cq = a.cand + (int64_t)q * a.cand_cap + (int64_t)tslot_d * ShapeC::BM + lane_row0;
+                        uint64_t* cq = a.cand + (int64_t)q * a.cand_cap + (int64_t)tslot_d * S::BM + lane_row0;
 #pragma unroll
-                        for (int mi = 0; mi < ShapeC::TM; ++mi)
+                        for (int mi = 0; mi < S::TM; ++mi)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
@@ -211,11 +215,11 @@ __global__ __launch_bounds__(ShapeC::NTHREADS, 2) void k_coarse(CoarseArgs a) {
                 }
             } else {
 #pragma unroll
-                for (int ni = 0; ni < ShapeC::TN; ++ni) {
+                for (int ni = 0; ni < S::TN; ++ni) {
                     const uint32_t q = (uint32_t)n0 + (uint32_t)acc.col(ni);
                     const float t = thr_s[q];
 #pragma unroll
-                    for (int mi = 0; mi < ShapeC::TM; ++mi) {
+                    for (int mi = 0; mi < S::TM; ++mi) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
@@ -234,7 +238,9 @@ __global__ __launch_bounds__(ShapeC::NTHREADS, 2) void k_coarse(CoarseArgs a) {
                     }
                 }
             }
-        });
+        };
+    if constexpr (SMALLQ) gemm_nt_split<T, false>(a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem, coord, epi);
+    else gemm_nt_pingpong<T, false, true>(a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem, coord, epi);
     if constexpr (!DIRECT) {
         // ---- fused scatter: this block's 8 wave lists -> the per-query candidate buffers.  One global atomic per (block, query)
         // reserves a range (instead of one per survivor), the position inside the range comes from an LDS counter.
@@ -561,7 +567,8 @@ static int exact_scan(Index* ix, int nqf, int k, hipStream_t st) {
 
 template <class T>
 static int search_block(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int mode, hipStream_t st) {
-    const int nq_pad = (int)round_up(nq, ShapeC::BN);   // <= QBLK = 1024 = 4 x 256
+    const bool smallq = nq <= ShapeSplit::BN;             // one 128-query tile: HBM-bound scan on the producer / consumer loop
+    const int nq_pad = (int)round_up(nq, smallq ? ShapeSplit::BN : ShapeC::BN);   // <= QBLK = 1024 = 4 x 256
     // over-fetch K1 and buffer capacity: K1 = max(64, pow2 >= 2.5 k); cap = 16 K1; growth 8x per round
     int K1 = std::max(64, next_pow2((5 * k + 1) / 2));
     int cap = 16 * K1;
@@ -580,18 +587,20 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         a.thr = ix->thr; a.cnt = ix->cnt; a.flags = ix->flags; a.cand = ix->cand; a.cand_cap = ix->cand_cap;
         a.blk_list = ix->blk_list; a.blk_cnt = ix->blk_cnt; a.list_overflow = ix->blk_cnt + ix->num_cu * ShapeC::NWAVE;
         KR_HIP(hipMemsetAsync(ix->blk_cnt, 0, ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int), st));
-        constexpr int bm = ShapeC::BM;
+        const int bm = smallq ? ShapeSplit::BM : ShapeC::BM;
         a.ntiles = (ix->n + bm - 1) / bm;
         // interleaving permutation: multiplier near ntiles / golden ratio, coprime to ntiles
         int64_t mul = std::max<int64_t>(1, (int64_t)((double)a.ntiles * 0.6180339887498949));
         while (gcd64(mul, a.ntiles) != 1) ++mul;
         a.perm_mul = mul % a.ntiles; if (a.perm_mul == 0) a.perm_mul = 1;
-        constexpr int lds = COARSE_LDS;
+        const int lds = smallq ? COARSE_LDS_SMALLQ : COARSE_LDS;
         static bool attr_set_dev[64] = {};   // per device: function attributes belong to the device's code object instance
         bool& attr_set = attr_set_dev[ix->device & 63];
         if (!attr_set) {
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
             attr_set = true;
         }
         const size_t sel_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int);
@@ -617,7 +626,10 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
             const int64_t cnt_t = std::min<int64_t>(step, a.ntiles - done);
             a.tile_begin = done; a.tile_count = cnt_t;
             if (round < 16) KR_HIP(hipEventRecord(ix->evc[2 * round], st));
-            if (a.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
+            if (smallq) {
+                if (a.direct) hipLaunchKernelGGL((k_coarse<T, true, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
+                else hipLaunchKernelGGL((k_coarse<T, false, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
+            } else if (a.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
             else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
             if (round < 16) KR_HIP(hipEventRecord(ix->evc[2 * round + 1], st));
             const int preset = a.direct ? (int)(cnt_t * bm) : 0;
