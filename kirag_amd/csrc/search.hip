@@ -160,6 +160,41 @@ constexpr int COARSE_LDS = COARSE_STAGES * ShapeC::STAGE_BYTES + QBLK * 4;
 constexpr int COARSE_LDS_SMALLQ = SPLIT_RING * ShapeSplit::STAGE_BYTES + QBLK * 4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+// fused scatter: this block's 8 wave lists -> the per-query candidate buffers.  One global atomic per (block, query) reserves a range (instead of one
+// per survivor), the position inside the range comes from an LDS counter.  Called by every thread of the block after the main loop (the LDS ring is free).
+__device__ __forceinline__ void scatter_wave_lists(const CoarseArgs& a, char* smem, int wave_id, unsigned int wcnt, int nthreads) {
+    constexpr int NW = ShapeC::NWAVE;                                    // list slots per block (waves without accumulators have empty lists)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's list stores have reached L2
+    unsigned int* hist = reinterpret_cast<unsigned int*>(smem);          // [QBLK]
+    unsigned int* base = hist + QBLK;                                    // [QBLK]
+    unsigned int* wc = base + QBLK;                                      // [NW]
+    __syncthreads();
+    if ((int)threadIdx.x < NW) wc[threadIdx.x] = 0u;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        wc[wave_id] = wcnt < (unsigned)WLISTCAP ? wcnt : (unsigned)WLISTCAP;
+        if (wcnt > (unsigned)WLISTCAP) *a.list_overflow = 1u;
+    }
+    for (int i = threadIdx.x; i < a.nq_pad; i += nthreads) hist[i] = 0u;
+    __syncthreads();
+    const uint4* lists = a.blk_list + (int64_t)blockIdx.x * NW * WLISTCAP;
+    for (int w = 0; w < NW; ++w)
+        for (unsigned i = threadIdx.x; i < wc[w]; i += nthreads) atomicAdd(&hist[lists[(int64_t)w * WLISTCAP + i].z], 1u);
+    __syncthreads();
+    for (int q = threadIdx.x; q < a.nq_pad; q += nthreads) {
+        const unsigned c = hist[q];
+        base[q] = c ? atomicAdd(&a.cnt[q], c) : 0u;
+        hist[q] = 0u;
+    }
+    __syncthreads();
+    for (int w = 0; w < NW; ++w)
+        for (unsigned i = threadIdx.x; i < wc[w]; i += nthreads) {
+            const uint4 e = lists[(int64_t)w * WLISTCAP + i];
+            const unsigned pos = base[e.z] + atomicAdd(&hist[e.z], 1u);
+            if (pos < (unsigned)a.cand_cap) a.cand[(int64_t)e.z * a.cand_cap + pos] = make_key(__uint_as_float(e.x), e.y);
+        }
+}
+
 // The 16-bit copy is padded with NaN rows up to a multiple of 256 (k_pad_nan): a partial last tile then needs no row test,
 // because NaN scores fail every `>=` and sort below every real key.
 // SMALLQ (at most 128 queries in the block: the KiRAG loop's 1-2 queries per hop, single-question retrieval): 128-row x 128-query tiles on the
@@ -241,37 +276,132 @@ __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
         };
     if constexpr (SMALLQ) gemm_nt_split<T, false>(a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem, coord, epi);
     else gemm_nt_pingpong<T, false, true>(a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem, coord, epi);
-    if constexpr (!DIRECT) {
-        // ---- fused scatter: this block's 8 wave lists -> the per-query candidate buffers.  One global atomic per (block, query)
-        // reserves a range (instead of one per survivor), the position inside the range comes from an LDS counter.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's list stores have reached L2
-        unsigned int* hist = reinterpret_cast<unsigned int*>(smem);          // [QBLK]  (the LDS ring is free now)
-        unsigned int* base = hist + QBLK;                                    // [QBLK]
-        unsigned int* wc = base + QBLK;                                      // [NWAVE]
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) {
-            wc[wave_id] = wcnt < (unsigned)WLISTCAP ? wcnt : (unsigned)WLISTCAP;
-            if (wcnt > (unsigned)WLISTCAP) *a.list_overflow = 1u;
-        }
-        for (int i = threadIdx.x; i < a.nq_pad; i += ShapeC::NTHREADS) hist[i] = 0u;
-        __syncthreads();
-        const uint4* lists = a.blk_list + (int64_t)blockIdx.x * ShapeC::NWAVE * WLISTCAP;
-        for (int w = 0; w < ShapeC::NWAVE; ++w)
-            for (unsigned i = threadIdx.x; i < wc[w]; i += ShapeC::NTHREADS) atomicAdd(&hist[lists[(int64_t)w * WLISTCAP + i].z], 1u);
-        __syncthreads();
-        for (int q = threadIdx.x; q < a.nq_pad; q += ShapeC::NTHREADS) {
-            const unsigned c = hist[q];
-            base[q] = c ? atomicAdd(&a.cnt[q], c) : 0u;
-            hist[q] = 0u;
-        }
-        __syncthreads();
-        for (int w = 0; w < ShapeC::NWAVE; ++w)
-            for (unsigned i = threadIdx.x; i < wc[w]; i += ShapeC::NTHREADS) {
-                const uint4 e = lists[(int64_t)w * WLISTCAP + i];
-                const unsigned pos = base[e.z] + atomicAdd(&hist[e.z], 1u);
-                if (pos < (unsigned)a.cand_cap) a.cand[(int64_t)e.z * a.cand_cap + pos] = make_key(__uint_as_float(e.x), e.y);
-            }
+    if constexpr (!DIRECT) scatter_wave_lists(a, smem, wave_id, wcnt, ShapeC::NTHREADS);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Coarse scan for at most 32 queries (one question per hop of the KiRAG loop, interactive retrieval): a pure corpus STREAM.  The scan is HBM-bound
+// (one MFMA per 1 KiB of corpus), so the kernel is built around bytes in flight, not around the matrix pipe:
+//   * the queries' fragments for the WHOLE dimension live in registers (KT x 4 x 16 B per lane = 256 VGPRs at d = 1024; one wave per SIMD, the
+//     unified 512-register file makes that possible), loaded once per launch: LDS holds nothing but corpus bytes;
+//   * every wave streams its own 32-row tiles through a wave-private ring of RING K-tiles of 4 KiB (32 rows x 128 B, LDS-DMA, the same swizzled
+//     image as the GEMM rings): no barrier anywhere in the loop, one counted s_waitcnt vmcnt per K-tile; 4 waves x 7 x 4 KiB = 112 KiB of corpus
+//     bytes in flight per CU (48 KiB with the 128 x 128 producer / consumer tile);
+//   * per 32 rows: KT x 4 MFMAs into ONE 32 x 32 accumulator, then the same threshold filter / direct store as k_coarse.
+// Tile slots are 32 rows here (a.ntiles, a.tile_begin, a.tile_count, a.perm_mul are in units of 32 rows).
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+constexpr int Q32_THREADS = 256;
+template <int KT> struct Q32Ring { static constexpr int value = (KT % 8 == 0) ? 8 : (KT % 6 == 0) ? 6 : 4; };
+template <int KT> constexpr int q32_lds() { return 4 * Q32Ring<KT>::value * 4096 > 2 * QBLK * 4 + 64 ? 4 * Q32Ring<KT>::value * 4096 : 2 * QBLK * 4 + 64; }
+
+// (the body is a function with a __restrict__ corpus pointer on purpose: after inlining, the LDS-DMA carries that pointer's alias scope and the ring's
+// ds_reads are marked as not aliasing it, which is what lets the compiler's waitcnt pass leave the counted vmcnt waits alone; without it it inserts
+// s_waitcnt vmcnt(0) before every LDS read that follows an LDS-DMA, i.e. no K-tile would ever be in flight)
+template <class T, bool DIRECT, int KT>
+__device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint16_t* __restrict__ xc, const uint16_t* __restrict__ qc, char* smem) {
+    constexpr int RING = Q32Ring<KT>::value;
+    static_assert(KT % RING == 0, "ring slots must be static in the unrolled K loop");
+    const int lane = threadIdx.x & 63;
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* ring = smem + wave_id * (RING * 4096);
+    const __amdgpu_buffer_rsrc_t wlist = __builtin_amdgcn_make_buffer_rsrc(
+        a.blk_list + ((int64_t)blockIdx.x * ShapeC::NWAVE + wave_id) * WLISTCAP, 0, WLISTCAP * 16, 0x00020000);
+    unsigned int wcnt = 0;
+    // query fragments (B operand of mfma(a, b)): lane -> query lane & 31, k = 16 ks + 8 (lane >> 5) .. + 7
+    uint4 bq[KT * 4];
+    {
+        const uint16_t* qrow = qc + (int64_t)(lane & 31) * a.dpad + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KT * 4; ++ks) bq[ks] = *reinterpret_cast<const uint4*>(qrow + ks * 16);
     }
+    const float thr = DIRECT ? 0.f : a.thr[lane & 31];
+    const uint32_t q = (uint32_t)(lane & 31);
+    // this wave's tile slots: s = w, w + W, w + 2W, ... of the round's [0, tile_count)
+    const int64_t W = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + wave_id;
+    const int64_t my = a.tile_count > w0 ? (a.tile_count - w0 + W - 1) / W : 0;
+    if (my > 0) {
+        auto tile_row0 = [&](int64_t i) -> int64_t {          // first corpus row of this wave's i-th tile (i clamped: dummy re-loads past the end)
+            const int64_t slot = w0 + (i < my ? i : my - 1) * W;
+            uint64_t qq; uint32_t tile;
+            fast_divmod64((uint64_t)(a.tile_begin + slot) * (uint64_t)a.perm_mul, (uint32_t)a.ntiles, qq, tile);
+            return (int64_t)tile * 32;
+        };
+        // DMA cursor: (tile index, K-tile); per-lane source: piece p = rows 8p .. 8p+7, lane -> row 8p + (lane >> 3), 16-B chunk (lane & 7) ^ swizzle
+        const int r8 = lane >> 3;
+        int64_t pf_tile = 0; int pf_kt = 0;
+        const char* pf_base = reinterpret_cast<const char*>(xc + tile_row0(0) * a.dpad);
+        uint32_t src_off[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = 8 * p + r8;
+            src_off[p] = (uint32_t)(row * a.dpad * 2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+        }
+        auto stage = [&](int slot) {
+            char* dst = ring + slot * 4096;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(pf_base + pf_kt * 128 + src_off[p]), (lds_void*)(dst + p * 1024), 16, 0, 2);   // nt: once-through stream
+            if (++pf_kt == KT) { pf_kt = 0; ++pf_tile; pf_base = reinterpret_cast<const char*>(xc + tile_row0(pf_tile) * a.dpad); }
+        };
+#pragma unroll
+        for (int p = 0; p < RING - 1; ++p) stage(p);
+        const int frow = lane & 31, fh = lane >> 5, fswz = (frow >> 1) & 7;
+        const int lane_row0 = 4 * fh;
+        for (int64_t i = 0; i < my; ++i) {
+            const int64_t m0 = tile_row0(i);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                // the slot of the PREVIOUS K-tile is free (its fragments were consumed by MFMAs that are already issued): refill it first, then wait
+                // for this K-tile: RING-1 younger ones stay in flight
+                stage((kt + RING - 1) % RING);
+                wait_vmcnt<4 * (RING - 1)>();
+                const char* st = ring + (kt % RING) * 4096 + frow * 128;
+                uint4 af[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) af[ks] = *reinterpret_cast<const uint4*>(st + (((2 * ks + fh) ^ fswz) << 4));
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = T::mfma(af[ks], bq[kt * 4 + ks], acc);
+                asm volatile("" ::: "memory");                // keep the next refill behind these LDS reads in program order
+            }
+            const uint32_t row_base = (uint32_t)m0 + (uint32_t)lane_row0;
+            if constexpr (DIRECT) {
+                if (q < (uint32_t)a.nq) {
+                    uint64_t* cq = a.cand + (int64_t)q * a.cand_cap + (w0 + i * W) * 32 + lane_row0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        cq[ro] = make_key(acc[r], row_base + (uint32_t)ro);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    const float sc = acc[r];
+                    const bool p = (sc >= thr);
+                    const unsigned long long mask = __ballot(p);
+                    if (mask) {
+                        if (p) {
+                            const unsigned int slot = wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                            u32x4 e = {__float_as_uint(sc), row_base + (uint32_t)ro, q, 0u};
+                            __builtin_amdgcn_raw_buffer_store_b128(e, wlist, slot * 16u, 0, 0);
+                        }
+                        wcnt += (unsigned)__popcll(mask);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (!DIRECT) scatter_wave_lists(a, smem, wave_id, wcnt, Q32_THREADS);
+}
+
+template <class T, bool DIRECT, int KT>
+__global__ __launch_bounds__(Q32_THREADS, 1) void k_coarse_q32(CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    coarse_q32_body<T, DIRECT, KT>(a, a.xc, a.qc, smem);
 }
 
 // rows [n, round_up(n, 256)) of the 16-bit copy <- NaN
@@ -565,10 +695,36 @@ static int exact_scan(Index* ix, int nqf, int k, hipStream_t st) {
     return 0;
 }
 
+template <class T, int KT>
+static int launch_q32_kt(const CoarseArgs& a, int num_cu, int device, hipStream_t st) {
+    constexpr int lds = q32_lds<KT>();
+    static bool attr_set_dev[64] = {};
+    if (!attr_set_dev[device & 63]) {
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse_q32<T, true, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse_q32<T, false, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set_dev[device & 63] = true;
+    }
+    if (a.direct) hipLaunchKernelGGL((k_coarse_q32<T, true, KT>), dim3(num_cu), dim3(Q32_THREADS), lds, st, a);
+    else hipLaunchKernelGGL((k_coarse_q32<T, false, KT>), dim3(num_cu), dim3(Q32_THREADS), lds, st, a);
+    return 0;
+}
+template <class T>
+static int launch_q32(const CoarseArgs& a, int kt64, int num_cu, int device, hipStream_t st) {
+    switch (kt64) {
+        case 16: return launch_q32_kt<T, 16>(a, num_cu, device, st);
+        case 12: return launch_q32_kt<T, 12>(a, num_cu, device, st);
+        case 8: return launch_q32_kt<T, 8>(a, num_cu, device, st);
+        case 6: return launch_q32_kt<T, 6>(a, num_cu, device, st);
+    }
+    return fail(KR_EINVAL, "no k_coarse_q32 instance for dpad/64 = %d", kt64);
+}
+
 template <class T>
 static int search_block(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int mode, hipStream_t st) {
     const bool smallq = nq <= ShapeSplit::BN;             // one 128-query tile: HBM-bound scan on the producer / consumer loop
-    const int nq_pad = (int)round_up(nq, smallq ? ShapeSplit::BN : ShapeC::BN);   // <= QBLK = 1024 = 4 x 256
+    const int kt64 = ix->dpad / 64;
+    const bool q32 = nq <= 32 && (kt64 == 16 || kt64 == 12 || kt64 == 8 || kt64 == 6) && !getenv("KIRAG_AMD_NO_Q32");   // register-resident queries, pure stream
+    const int nq_pad = q32 ? 32 : (int)round_up(nq, smallq ? ShapeSplit::BN : ShapeC::BN);   // <= QBLK = 1024 = 4 x 256
     // over-fetch K1 and buffer capacity: K1 = max(64, pow2 >= 2.5 k); cap = 16 K1; growth 8x per round
     int K1 = std::max(64, next_pow2((5 * k + 1) / 2));
     int cap = 16 * K1;
@@ -587,7 +743,7 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         a.thr = ix->thr; a.cnt = ix->cnt; a.flags = ix->flags; a.cand = ix->cand; a.cand_cap = ix->cand_cap;
         a.blk_list = ix->blk_list; a.blk_cnt = ix->blk_cnt; a.list_overflow = ix->blk_cnt + ix->num_cu * ShapeC::NWAVE;
         KR_HIP(hipMemsetAsync(ix->blk_cnt, 0, ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int), st));
-        const int bm = smallq ? ShapeSplit::BM : ShapeC::BM;
+        const int bm = q32 ? 32 : smallq ? ShapeSplit::BM : ShapeC::BM;
         a.ntiles = (ix->n + bm - 1) / bm;
         // interleaving permutation: multiplier near ntiles / golden ratio, coprime to ntiles
         int64_t mul = std::max<int64_t>(1, (int64_t)((double)a.ntiles * 0.6180339887498949));
@@ -616,7 +772,7 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         }
         // Round schedule (any thresholds are SAFE: the certificate in k_rerank decides exactness; the schedule only sets speed):
         //   round 0: cap rows, every score stored (direct slots);  growth rounds: 7x the rows seen, thr = K1-th best;
-        //   as soon as rows_seen * 64 >= rows_left the rest is ONE final round whose threshold is the r-th best seen with
+        //   as soon as rows_seen * (cap / 64) >= rows_left the rest is ONE final round whose threshold is the r-th best seen with
         //   r = (cap/2) * seen / left  (expected cap/2 survivors), 32 <= r <= K1.
         int64_t done = 0;
         int64_t step = std::max<int64_t>(1, cap / bm);
@@ -626,7 +782,9 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
             const int64_t cnt_t = std::min<int64_t>(step, a.ntiles - done);
             a.tile_begin = done; a.tile_count = cnt_t;
             if (round < 16) KR_HIP(hipEventRecord(ix->evc[2 * round], st));
-            if (smallq) {
+            if (q32) {
+                KR_TRY((launch_q32<T>(a, kt64, ix->num_cu, ix->device, st)));
+            } else if (smallq) {
                 if (a.direct) hipLaunchKernelGGL((k_coarse<T, true, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
                 else hipLaunchKernelGGL((k_coarse<T, false, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
             } else if (a.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
@@ -640,7 +798,9 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
             if (done >= a.ntiles) { final_preset = preset; break; }   // last round: k_rerank reads the buffer as it is; thr stays
             const int64_t seen = done * bm, left = ix->n - seen;
             int rank = K1;
-            if (seen * 64 >= left) {
+            // final round only once the rank it needs is >= 32 WITHOUT clamping: (cap/2) * seen / left >= 32.  (With a fixed "seen * 64 >= left" the
+            // small buffer of k <= 25 (cap = 1024) got rank 32 with up to 32 * 64 = 2048 expected survivors: overflow -> exact-scan fallback.)
+            if (seen * std::max(1, cap / 64) >= left) {
                 step = a.ntiles - done;
                 rank = (int)std::min<int64_t>(K1, std::max<int64_t>(32, ((int64_t)(cap / 2) * seen + left - 1) / left));
                 rank = std::min(rank, K1);

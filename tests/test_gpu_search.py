@@ -42,6 +42,24 @@ def test_small_exact_vs_canonical(n, d, nq, k):
     assert np.array_equal(i2, io) and np.array_equal(s2.view(np.uint32), so.view(np.uint32))
 
 
+@pytest.mark.parametrize("n,d,nq,k", [(40000, 1024, 2, 10), (30000, 768, 9, 50), (25000, 512, 32, 100), (20000, 384, 1, 10), (33333, 1024, 31, 1)])
+def test_few_queries_stream_scan_vs_canonical(n, d, nq, k):
+    """At most 32 queries with d in {384, 512, 768, 1024}: the register-resident-queries stream kernel (k_coarse_q32; 32-row tile slots, several
+    rounds, wave-private LDS-DMA rings), bit-exact vs the C oracle, certified, and identical to the exact-scan mode."""
+    rng = np.random.default_rng(n + d + nq)
+    x = _unit(rng, n, d)
+    x[n - 5] = x[3]                                             # a duplicate row far away: tie broken by row index
+    q, pick = _queries_near(rng, x, nq)
+    ix = _mk(d, x)
+    s, i = ix.index.search(q, k)
+    so, io = S.search_canonical(q, x, k)
+    assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    st = ix.index.stats()
+    assert st["queries"] == nq and st["certified"] + st["fallback"] == nq and st["certified"] >= nq - 1, st
+    s2, i2 = ix.index.search(q, k, mode=1)
+    assert np.array_equal(i2, io) and np.array_equal(s2.view(np.uint32), so.view(np.uint32))
+
+
 def test_multi_round_vs_canonical_config1_shape():
     """20k x 1024, 200 queries, top-100: two coarse rounds + certified re-rank, bit-exact vs the C oracle."""
     rng = np.random.default_rng(7)
