@@ -554,23 +554,35 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
 // exact full scan (fallback for flagged queries, and mode = 1)
 // ---------------------------------------------------------------------------------------------------------
 // grid (nchunks, nqf): canonical score of every row of the chunk for one query, chunk-local top-kk keys
+template <int NCH>   // NCH 256-element steps cover a row: d <= 256 NCH
 __global__ __launch_bounds__(256) void k_exact_scan(const float* __restrict__ qf, const int* __restrict__ qidx, const float* __restrict__ xf,
-                                                    int64_t n, int d, int kk, uint64_t* __restrict__ out, int nchunks) {
+                                                    int64_t n, int d, int kk, uint64_t* __restrict__ out, int nchunks, int rc) {
+    // rc = rows per block (a power of two, kk <= rc <= EXACT_RC): 1024 for corpus-sized scans, as little as 64 for a transient candidate set of a
+    // few hundred rows (kr_score_topk), so that the rows of ONE query are spread over several CUs instead of being a 128-step latency chain on one
     __shared__ uint64_t s[EXACT_RC];
     const int chunk = blockIdx.x, qi = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* qv = qf + (int64_t)qidx[qi] * d;
-    const int64_t r0 = (int64_t)chunk * EXACT_RC;
-    for (int i = wave; i < EXACT_RC; i += 4) {
-        const int64_t row = r0 + i;
-        uint64_t key = 0ull;
-        if (row < n) {
-            const double e = canonical_dot_wave(qv, xf + row * d, d, lane);
-            key = make_key((float)e, (uint32_t)row);
-            if (key == 0ull) key = 1ull;   // cannot happen for row < 2^32-1; keeps "0 = padding" unambiguous
-        }
-        if (lane == 0) s[i] = key;
+    const int64_t r0 = (int64_t)chunk * rc;
+    float4 qr[NCH];                                            // the query stays in registers; two rows per wave step, all their loads issued first
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int i = lane * 4 + j * 256;
+        qr[j] = (i < d) ? *reinterpret_cast<const float4*>(qv + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    bitonic_sort_desc(s, EXACT_RC, tid, 256);
+    for (int i = wave; i < rc; i += 8) {
+        const int64_t row0 = r0 + i, row1 = r0 + i + 4;
+        const bool v0 = row0 < n, v1 = row1 < n && i + 4 < rc;
+        double e0 = 0.0, e1 = 0.0;
+        if (v0) canonical_dot_wave2<NCH>(qr, xf + row0 * d, xf + (v1 ? row1 : row0) * d, d, lane, e0, e1);
+        if (lane == 0) {
+            uint64_t k0 = v0 ? make_key((float)e0, (uint32_t)row0) : 0ull, k1 = v1 ? make_key((float)e1, (uint32_t)row1) : 0ull;
+            if (v0 && k0 == 0ull) k0 = 1ull;   // cannot happen for row < 2^32-1; keeps "0 = padding" unambiguous
+            if (v1 && k1 == 0ull) k1 = 1ull;
+            s[i] = k0;
+            if (i + 4 < rc) s[i + 4] = k1;
+        }
+    }
+    bitonic_sort_desc(s, rc, tid, 256);
     uint64_t* o = out + ((int64_t)qi * nchunks + chunk) * kk;
     for (int j = tid; j < kk; j += 256) o[j] = s[j];
 }
@@ -661,8 +673,11 @@ static int64_t gcd64(int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = 
 
 // exact scan of the queries listed in ix->ex_qidx[0..nqf) -> ix->out_s / out_r rows of those queries
 static int exact_scan(Index* ix, int nqf, int k, hipStream_t st) {
-    const int64_t nchunks = (ix->n + EXACT_RC - 1) / EXACT_RC;
-    const int kk = std::min<int>(k, EXACT_RC);
+    // rows per block: 1024, or fewer for small row counts so that at least ~16 blocks share the rows of a query (never below k or 64)
+    int rc = EXACT_RC;
+    while (rc > 64 && rc / 2 >= k && ix->n < (int64_t)rc * 16) rc /= 2;
+    const int64_t nchunks = (ix->n + rc - 1) / rc;
+    const int kk = std::min<int>(k, rc);
     // queries are processed in groups so that the ping/pong buffers stay bounded (<= 256 MiB each)
     const int64_t per_q = nchunks * kk;
     int group = (int)std::max<int64_t>(1, std::min<int64_t>(nqf, (int64_t)(32u << 20) / std::max<int64_t>(per_q, 1)));
@@ -677,8 +692,9 @@ static int exact_scan(Index* ix, int nqf, int k, hipStream_t st) {
     }
     for (int g0 = 0; g0 < nqf; g0 += group) {
         const int g = std::min(group, nqf - g0);
-        hipLaunchKernelGGL(k_exact_scan, dim3((unsigned)nchunks, g), dim3(256), 0, st, ix->q_f, ix->ex_qidx + g0, ix->xf, ix->n, ix->d, kk,
-                           ix->ex_a, (int)nchunks);
+        auto scan = ix->d <= 1024 ? &k_exact_scan<4> : ix->d <= 2048 ? &k_exact_scan<8> : &k_exact_scan<16>;
+        hipLaunchKernelGGL(scan, dim3((unsigned)nchunks, g), dim3(256), 0, st, ix->q_f, ix->ex_qidx + g0, ix->xf, ix->n, ix->d, kk,
+                           ix->ex_a, (int)nchunks, rc);
         uint64_t* cur = ix->ex_a; uint64_t* nxt = ix->ex_b;
         int64_t m = per_q;
         while (m > kk) {   // reduce until one sorted list of kk keys per query remains
@@ -1035,10 +1051,15 @@ int kr_score_topk(const float* q, int nq, const float* x, int64_t n, int d, int 
     w->d = d; w->n = n;
     KR_HIP(hipMemcpyAsync(w->xf, x, (size_t)n * d * sizeof(float), hipMemcpyDefault, st));
     KR_HIP(hipMemcpyAsync(w->q_f, q, (size_t)nq * d * sizeof(float), hipMemcpyDefault, st));
-    std::vector<int> iota(nq);
-    for (int i = 0; i < nq; ++i) iota[i] = i;
-    KR_HIP(hipMemcpyAsync(w->ex_qidx, iota.data(), (size_t)nq * sizeof(int), hipMemcpyHostToDevice, st));
-    KR_HIP(hipStreamSynchronize(st));   // iota is a stack/heap host buffer
+    static thread_local int iota_filled[64] = {};      // ex_qidx[i] = i is written once per (re)allocation, not per call (it cost a stream sync)
+    if (cap_i[device] != (size_t)iota_filled[device] * sizeof(int) || iota_filled[device] < nq) {
+        const int cnt = (int)(cap_i[device] / sizeof(int));
+        std::vector<int> iota(cnt);
+        for (int i = 0; i < cnt; ++i) iota[i] = i;
+        KR_HIP(hipMemcpyAsync(w->ex_qidx, iota.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, st));
+        KR_HIP(hipStreamSynchronize(st));   // iota is a heap host buffer
+        iota_filled[device] = cnt;
+    }
     KR_TRY(exact_scan(w, nq, k, st));
     KR_HIP(hipMemcpyAsync(scores, w->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
     KR_HIP(hipMemcpyAsync(rows, w->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
