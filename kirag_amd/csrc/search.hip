@@ -72,29 +72,34 @@ struct Index {
 template <class T>
 __global__ __launch_bounds__(256) void k_add_rows(const float* __restrict__ xf, uint16_t* __restrict__ xc, int64_t n, int d, int dpad,
                                                   float* __restrict__ bounds) {
+    // grid-stride over rows (one wave per row) with the two maxima kept in registers: ONE pair of atomics per wave at the end.  (With a pair per
+    // row the 2 x 250k atomics on one cache line serialised in L2: 5.7 ms per 250k-row add instead of the 0.4 ms the 1.5 GB of traffic need.)
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
-    const float* src = xf + row * d;
-    uint16_t* dst = xc + row * dpad;
-    float e2 = 0.f, c2 = 0.f;
-    for (int i = lane * 4; i < dpad; i += 256) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < d) v = *reinterpret_cast<const float4*>(src + i);
-        ushort4 o;
-        o.x = T::from_f32(v.x); o.y = T::from_f32(v.y); o.z = T::from_f32(v.z); o.w = T::from_f32(v.w);
-        const float cx = T::to_f32(o.x), cy = T::to_f32(o.y), cz = T::to_f32(o.z), cw = T::to_f32(o.w);
-        e2 += (v.x - cx) * (v.x - cx) + (v.y - cy) * (v.y - cy) + (v.z - cz) * (v.z - cz) + (v.w - cw) * (v.w - cw);
-        c2 += cx * cx + cy * cy + cz * cz + cw * cw;
-        *reinterpret_cast<ushort4*>(dst + i) = o;
-    }
+    float emax = 0.f, cmax = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * 4) {
+        const float* src = xf + row * d;
+        uint16_t* dst = xc + row * dpad;
+        float e2 = 0.f, c2 = 0.f;
+        for (int i = lane * 4; i < dpad; i += 256) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < d) v = *reinterpret_cast<const float4*>(src + i);
+            ushort4 o;
+            o.x = T::from_f32(v.x); o.y = T::from_f32(v.y); o.z = T::from_f32(v.z); o.w = T::from_f32(v.w);
+            const float cx = T::to_f32(o.x), cy = T::to_f32(o.y), cz = T::to_f32(o.z), cw = T::to_f32(o.w);
+            e2 += (v.x - cx) * (v.x - cx) + (v.y - cy) * (v.y - cy) + (v.z - cz) * (v.z - cz) + (v.w - cw) * (v.w - cw);
+            c2 += cx * cx + cy * cy + cz * cz + cw * cw;
+            *reinterpret_cast<ushort4*>(dst + i) = o;
+        }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { e2 += __shfl_xor(e2, m, 64); c2 += __shfl_xor(c2, m, 64); }
-    if (lane == 0) {
+        for (int m = 32; m >= 1; m >>= 1) { e2 += __shfl_xor(e2, m, 64); c2 += __shfl_xor(c2, m, 64); }
         // slack factor covers the fp32 rounding of these sums themselves; NaN rows (never retrievable) are skipped
         const float e = sqrtf(e2) * 1.0001f, c = sqrtf(c2) * 1.0001f;
-        if (e == e) atomicMax(reinterpret_cast<unsigned int*>(bounds), __float_as_uint(e));
-        if (c == c) atomicMax(reinterpret_cast<unsigned int*>(bounds) + 1, __float_as_uint(c));
+        if (e == e) emax = fmaxf(emax, e);
+        if (c == c) cmax = fmaxf(cmax, c);
+    }
+    if (lane == 0) {   // non-negative floats order like their bit patterns
+        atomicMax(reinterpret_cast<unsigned int*>(bounds), __float_as_uint(emax));
+        atomicMax(reinterpret_cast<unsigned int*>(bounds) + 1, __float_as_uint(cmax));
     }
 }
 
@@ -968,7 +973,7 @@ int kr_index_add(kr_index* h, const float* x, int64_t n, void* stream) {
     KR_TRY(grow(ix, ix->n + n));
     float* dst = ix->xf + ix->n * ix->d;
     KR_HIP(hipMemcpyAsync(dst, x, (size_t)n * ix->d * sizeof(float), hipMemcpyDefault, st));
-    const unsigned grid = (unsigned)((n + 3) / 4);
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)ix->num_cu * 16);   // grid-stride: 16 blocks of 4 waves per CU
     if (ix->coarse == KR_COARSE_BF16)
         hipLaunchKernelGGL(k_add_rows<BF16>, dim3(grid), dim3(256), 0, st, dst, ix->xc + ix->n * ix->dpad, n, ix->d, ix->dpad, ix->bounds);
     else
