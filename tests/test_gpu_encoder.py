@@ -54,7 +54,12 @@ def test_g1_tiny_configs_match_reference(golden, name):
     print(f"[{name}] worst abs err vs reference fp32: {worst:.2e}")
 
 
-def test_g1_last_hidden_state(golden):
+@pytest.mark.parametrize("residual_lo,tol", [("0", 4e-2), ("1", 3e-2)])
+def test_g1_last_hidden_state(golden, residual_lo, tol, monkeypatch):
+    """last_hidden_state of the tiny config; LayerNorm outputs are O(1) (|x| up to ~4: one bf16 ulp is 0.016-0.03).  Default build: the residual
+    stream between layers is bf16 and only the final LayerNorm keeps 16 mantissa bits; KIRAG_AMD_RESIDUAL_LO=1 (read at encoder creation) keeps
+    them in every layer."""
+    monkeypatch.setenv("KIRAG_AMD_RESIDUAL_LO", residual_lo)
     g = golden("g1_encoder_tiny.npz")
     cfg = _cfg(g["cfg.t256"])
     w = E.synth_weights(cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
@@ -66,11 +71,14 @@ def test_g1_last_hidden_state(golden):
         h.forward_np(ids, mask, 0)
         lh = h.last_hidden(*ids.shape).numpy()
         keep = mask.astype(bool)
-        assert np.abs(lh[keep] - hid[-1][keep]).max() <= 3e-2          # LayerNorm outputs are O(1)
+        assert np.abs(lh[keep] - hid[-1][keep]).max() <= tol
         assert (lh[~keep] == 0).all()
 
 
-def test_g2_full_size_e5_and_bge(golden):
+@pytest.mark.parametrize("residual_lo", ["0", "1"])
+def test_g2_full_size_e5_and_bge(golden, residual_lo, monkeypatch):
+    """Full-size (24-layer) goldens in both residual-stream modes (see encoder.hip header): the error is set by the bf16 GEMM operands."""
+    monkeypatch.setenv("KIRAG_AMD_RESIDUAL_LO", residual_lo)
     g = golden("g2_encoder_large.npz")
     cfg = _cfg(g["cfg"])
     w = E.synth_weights(cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
