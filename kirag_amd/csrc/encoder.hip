@@ -194,6 +194,47 @@ __device__ __forceinline__ void ln_row_store(float4 (&v)[8], int H, int lane, co
     }
 }
 
+// the same with gamma / beta already in registers (k_ln keeps them across its rows); NCH 256-element steps cover a row (H <= 256 NCH).
+// The reductions add the same values in the same order as the 8-step version (steps beyond H contribute nothing there).
+template <int NCH>
+__device__ __forceinline__ void ln_row_store_regs(float4 (&v)[NCH], int H, int lane, const float4 (&g)[NCH], const float4 (&bta)[NCH], float eps,
+                                                  uint16_t* __restrict__ xlo_row, uint16_t* __restrict__ xb_row) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) if (lane * 4 + j * 256 < H) s += v[j].x + v[j].y + v[j].z + v[j].w;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    const float mu = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        if (lane * 4 + j * 256 < H) {
+            const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+            q += a * a + b * b + c * c + d * d;
+        }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int i = lane * 4 + j * 256;
+        if (i < H) {
+            const float4 gg = g[j], bb = bta[j];
+            float4 o;
+            o.x = (v[j].x - mu) * rstd * gg.x + bb.x; o.y = (v[j].y - mu) * rstd * gg.y + bb.y;
+            o.z = (v[j].z - mu) * rstd * gg.z + bb.z; o.w = (v[j].w - mu) * rstd * gg.w + bb.w;
+            ushort4 ob, ol;
+            ob.x = BF16::from_f32(o.x); ob.y = BF16::from_f32(o.y); ob.z = BF16::from_f32(o.z); ob.w = BF16::from_f32(o.w);
+            *reinterpret_cast<ushort4*>(xb_row + i) = ob;
+            if (xlo_row) {   // optional low half: o = hi + lo with lo = bf16(o - hi), |o - (hi + lo)| <= 2^-18 |o|
+                ol.x = BF16::from_f32(o.x - BF16::to_f32(ob.x)); ol.y = BF16::from_f32(o.y - BF16::to_f32(ob.y));
+                ol.z = BF16::from_f32(o.z - BF16::to_f32(ob.z)); ol.w = BF16::from_f32(o.w - BF16::to_f32(ob.w));
+                *reinterpret_cast<ushort4*>(xlo_row + i) = ol;
+            }
+        }
+    }
+}
+
 // embeddings: word[id] + position[pos] + token_type[0] -> LayerNorm       (one wave per token)
 __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id, const int* __restrict__ tok_pos, const int* __restrict__ Tp,
                                                   const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
@@ -219,27 +260,50 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id
     ln_row_store(v, H, lane, g, bta, eps, xlo ? xlo + t * H : nullptr, xb + t * H);
 }
 
-// LayerNorm(y + (xb + xlo)) -> xb, xlo     (one wave per token; y holds dense + bias as bf16, xb + xlo the residual stream, updated in place)
+// LayerNorm(y + ybias + (xb + xlo)) -> xb (, xlo)     y holds the dense output as bf16, xb (+ xlo) the residual stream, updated in place.
+// One wave per token row, grid-stride: gamma, beta and the dense bias (3 x 4 KiB of fp32 per row if re-read: twice the row's own 6 KiB of HBM
+// traffic through the CU's L1) are loaded ONCE per wave into registers and reused for all its rows, and the next row's loads are issued before the
+// current row is reduced (two rows in flight per wave).
+template <int NCH>
 __global__ __launch_bounds__(256) void k_ln(const uint16_t* __restrict__ y, const float* __restrict__ ybias, const int* __restrict__ Tp, const float* __restrict__ g,
                                             const float* __restrict__ bta, float eps, int H, const uint16_t* xlo_in, uint16_t* xlo, uint16_t* xb) {
     const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= *Tp) return;
-    float4 v[8];
+    const int T = *Tp;
+    float4 gg[NCH], bb[NCH], yb[NCH];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NCH; ++j) {
         const int i = lane * 4 + j * 256;
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gg[j] = bb[j] = yb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < H) {
-            const ushort4 a = *reinterpret_cast<const ushort4*>(y + t * H + i);
-            const ushort4 rh = *reinterpret_cast<const ushort4*>(xb + t * H + i);
-            const ushort4 rl = xlo_in ? *reinterpret_cast<const ushort4*>(xlo_in + t * H + i) : make_ushort4(0, 0, 0, 0);
-            const float4 bb = *reinterpret_cast<const float4*>(ybias + i);       // bias of the dense layer that produced y
-            v[j] = make_float4((BF16::to_f32(a.x) + bb.x) + (BF16::to_f32(rh.x) + BF16::to_f32(rl.x)), (BF16::to_f32(a.y) + bb.y) + (BF16::to_f32(rh.y) + BF16::to_f32(rl.y)),
-                               (BF16::to_f32(a.z) + bb.z) + (BF16::to_f32(rh.z) + BF16::to_f32(rl.z)), (BF16::to_f32(a.w) + bb.w) + (BF16::to_f32(rh.w) + BF16::to_f32(rl.w)));
+            gg[j] = *reinterpret_cast<const float4*>(g + i); bb[j] = *reinterpret_cast<const float4*>(bta + i);
+            yb[j] = *reinterpret_cast<const float4*>(ybias + i);       // bias of the dense layer that produced y
         }
     }
-    ln_row_store(v, H, lane, g, bta, eps, xlo ? xlo + t * H : nullptr, xb + t * H);
+    const int64_t step = (int64_t)gridDim.x * 4;
+    int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    ushort4 a[NCH], rh[NCH], rl[NCH];
+    auto load_row = [&](int64_t row) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int i = lane * 4 + j * 256;
+            a[j] = rh[j] = rl[j] = make_ushort4(0, 0, 0, 0);
+            if (i < H && row < T) {
+                a[j] = *reinterpret_cast<const ushort4*>(y + row * H + i);
+                rh[j] = *reinterpret_cast<const ushort4*>(xb + row * H + i);
+                if (xlo_in) rl[j] = *reinterpret_cast<const ushort4*>(xlo_in + row * H + i);
+            }
+        }
+    };
+    load_row(t);
+    for (; t < T; t += step) {
+        float4 v[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            v[j] = make_float4((BF16::to_f32(a[j].x) + yb[j].x) + (BF16::to_f32(rh[j].x) + BF16::to_f32(rl[j].x)), (BF16::to_f32(a[j].y) + yb[j].y) + (BF16::to_f32(rh[j].y) + BF16::to_f32(rl[j].y)),
+                               (BF16::to_f32(a[j].z) + yb[j].z) + (BF16::to_f32(rh[j].z) + BF16::to_f32(rl[j].z)), (BF16::to_f32(a[j].w) + yb[j].w) + (BF16::to_f32(rh[j].w) + BF16::to_f32(rl[j].w)));
+        load_row(t + step);                                   // next row's loads in flight while this one is reduced and stored
+        ln_row_store_regs<NCH>(v, H, lane, gg, bb, eps, xlo ? xlo + t * H : nullptr, xb + t * H);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1010,6 +1074,8 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
                        e->tok_pos, e->d_err);
     const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + 3) & ~3);   // upper bound of the packed token count (each sequence is padded to 4)
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
+    const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu * 4u);   // k_ln is grid-stride (its parameters stay in registers across rows)
+    auto ln_kernel = H <= 1024 ? &k_ln<4> : &k_ln<8>;
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->use_lo ? e->xlo : nullptr, e->xb);
     uint16_t* const lo_rw = e->use_lo ? e->xlo : nullptr;      // low half read / written by the inner LayerNorms
@@ -1030,7 +1096,7 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
-        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, l.bo_eff, e->d_T, l.ln1g, l.ln1b, eps, H, lo_rw, lo_rw, e->xb);
+        hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.bo_eff, e->d_T, l.ln1g, l.ln1b, eps, H, lo_rw, lo_rw, e->xb);
         // intermediate.dense + GELU
         a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h;
         KR_TRY(launch_proj(EPI_GELU, a, maxT, e->num_cu, e->device, st));
@@ -1038,7 +1104,7 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->y;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
         // the LAST LayerNorm always writes the low half: pooling and kr_encoder_last_hidden read the final hidden state with 16 mantissa bits
-        hipLaunchKernelGGL(k_ln, dim3(row_grid), dim3(256), 0, st, e->y, l.b2, e->d_T, l.ln2g, l.ln2b, eps, H, lo_rw, last ? e->xlo : lo_rw, e->xb);
+        hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.b2, e->d_T, l.ln2g, l.ln2b, eps, H, lo_rw, last ? e->xlo : lo_rw, e->xb);
     }
     hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);
     KR_HIP(hipGetLastError());
