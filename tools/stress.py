@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Randomised soak of the HIP paths on one GPU (python tools/stress.py [seconds] [seed]): every case is checked on the device itself —
+  * index: certified MFMA scan (mode 0, every coarse kernel variant: <= 32 / <= 128 / 1024-query blocks, 1..4 rounds, incremental adds) must equal the
+    exact fp64 scan (mode 1) in rows and score bits;
+  * encoder (tiny config): the four projection main loops (KIRAG_AMD_PROJ_TILE = 256 / 130 / 128 / 32) must agree bit for bit, and a sequence's
+    embedding must not depend on the rest of the batch.
+Exits non-zero on the first mismatch; prints one line per 25 cases."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from types import SimpleNamespace
+import numpy as np
+import torch
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+from kirag_amd.retriever.index import FlatIPIndex
+from kirag_amd.retriever.encoders import HipBertForward
+
+t_end = time.time() + budget
+cases = 0
+
+
+def unit(n, d):
+    x = torch.randn(n, d, device="cuda")
+    return torch.nn.functional.normalize(x, dim=1)
+
+
+# ---- index -------------------------------------------------------------------------------------------------------------------------------
+while time.time() < t_end - budget * 0.35:
+    d = int(rng.choice([64, 128, 384, 512, 768, 1024]))
+    n = int(rng.choice([1, 7, 100, 1000, 5000, 33333, 120000, 300000])) + int(rng.integers(0, 50))
+    nq = int(rng.choice([1, 2, 5, 31, 32, 33, 100, 128, 129, 300, 1000]))
+    k = int(min(n, rng.choice([1, 3, 10, 20, 100, 256])))
+    ix = FlatIPIndex(d, device=0)
+    x = unit(n, d)
+    if n > 10 and rng.random() < 0.5:
+        cut = int(rng.integers(1, n))
+        ix.add(x[:cut]); ix.add(x[cut:])
+    else:
+        ix.add(x)
+    if n > 20:   # duplicates: ties by row
+        x2 = x.clone(); x2[n - 3] = x2[1]
+        ix = FlatIPIndex(d, device=0); ix.add(x2); x = x2
+    pick = torch.from_numpy(rng.integers(0, n, nq)).cuda()
+    q = torch.nn.functional.normalize(x[pick] + 0.3 * torch.randn(nq, d, device="cuda") / d ** 0.5, dim=1)
+    s0, i0 = ix.search(q, k)
+    s1, i1 = ix.search(q, k, mode=1)
+    if not (np.array_equal(i0, i1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32))):
+        print("INDEX MISMATCH", dict(n=n, d=d, nq=nq, k=k, seed=seed, case=cases), flush=True)
+        sys.exit(1)
+    cases += 1
+    if cases % 25 == 0:
+        print(f"[stress] {cases} cases ok (last index case n={n} d={d} nq={nq} k={k}, stats {ix.stats()['certified']}/{ix.stats()['queries']} certified)", flush=True)
+    del ix, x
+
+# ---- encoder -----------------------------------------------------------------------------------------------------------------------------
+from oracle import encoder_np as E   # weights generator only (test infrastructure; this tool is not part of the product)
+cfg = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
+                      max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+w = E.synth_weights(128, 2, 512, 1000, 512, seed=11)
+enc = HipBertForward(cfg, 0)
+enc.load_state(w)
+while time.time() < t_end:
+    B = int(rng.choice([1, 2, 3, 8, 17, 40, 130])); S = int(rng.choice([1, 5, 32, 33, 64, 100, 129, 200, 300]))
+    ids = rng.integers(5, 1000, (B, S)); mask = np.zeros((B, S), np.int64)
+    lens = rng.integers(1, S + 1, B); lens[0] = S
+    for b in range(B):
+        if b % 3 == 2: mask[b, S - lens[b]:] = 1          # left padded
+        else: mask[b, :lens[b]] = 1
+    pool = int(rng.integers(0, 2))
+    outs = []
+    for tile in ("256", "130", "128", "32"):
+        os.environ["KIRAG_AMD_PROJ_TILE"] = tile
+        outs.append(enc.forward_np(ids, mask, pool))
+    os.environ.pop("KIRAG_AMD_PROJ_TILE")
+    auto = enc.forward_np(ids, mask, pool)
+    alone = enc.forward_np(ids[:1], mask[:1], pool)           # sequence 0 on its own: batch independence
+    ok = all(np.array_equal(o.view(np.uint32), outs[0].view(np.uint32)) for o in outs[1:] + [auto]) and np.array_equal(alone[0].view(np.uint32), auto[0].view(np.uint32))
+    if not ok or not np.isfinite(auto).all():
+        print("ENCODER MISMATCH", dict(B=B, S=S, pool=pool, seed=seed, case=cases), flush=True)
+        sys.exit(1)
+    cases += 1
+    if cases % 25 == 0:
+        print(f"[stress] {cases} cases ok (last encoder case B={B} S={S} pool={pool})", flush=True)
+print(f"[stress] done: {cases} cases, no mismatch", flush=True)
