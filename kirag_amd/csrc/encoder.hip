@@ -30,14 +30,15 @@
 namespace kr {
 
 using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LDS, one block per CU: best main loop (long-K GEMMs)
-// LDS ring depth (template parameter STAGES of k_proj): the 256x256 ping-pong ring is fixed at 2 K-tiles; the 128x128 streaming loop runs with
-// 2 slots and two blocks per CU, or, for launches with at most one tile per CU (latency-bound: a tile's time is its K-tiles x the memory round trip),
-// with 4 slots = 3 K-tiles in flight (4 x 32 KiB + 4 x 4 KiB of epilogue stage = 144 KiB: one block per CU)
+// Four main loops, one per launch size (launch_proj picks; all give bit-identical rows):
+//   256x256 ping-pong (gemm_nt_pingpong)          launches with >= 5/8 of the CUs' worth of 256x256 tiles
+//   128x128 producer / consumer (gemm_nt_split)   fewer: at most one tile per CU, or more than two
+//   128x128 streaming, 2 slots, 2 blocks per CU   in between (k_proj<.., ShapeSmall, 2>)
+//   32x32 skinny (gemm_nt_skinny)                 a handful of token rows (<= 4 tiles of 32x32 per CU)
 
 using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB ring, two blocks per CU: for launches with too few 256x256 tiles to fill the chip
 
-// both main loops run with exchanged MFMA operands (accumulators hold 4 consecutive features per lane):
-// 256x256 tiles -> ping-pong loop; 128x128 tiles (small token counts: 4x the tiles, a quarter of the latency each) -> streaming loop
+// all main loops run with exchanged MFMA operands (accumulators hold 4 consecutive features per lane)
 template <class ShapeE, int STAGES, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_main(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb, int64_t N,
                                           int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
@@ -353,7 +354,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 constexpr int EPI_STAGE_BYTES = 4096;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-// Both helpers take the SWAPPED accumulator layout of gemm_nt_pingpong<.., true> / gemm_nt_stream_swapped: tile (mi, ni), register r,
+// Both helpers take the SWAPPED accumulator layout of gemm_nt_pingpong / gemm_nt_split / gemm_nt_stream / gemm_nt_skinny with SWAP = true: tile (mi, ni), register r,
 // lane (c = l & 31, h = l >> 5) is token mi*32 + c, feature ni*32 + (r & 3) + 8 (r >> 2) + 4 h of the wave's (TM*32 tokens) x (TN*32 features).
 //
 // rows: for one mi the wave's 32 tokens x 64 features are staged as bf16 [32 tokens][128 B]; registers 4g .. 4g+3 of a lane are 4
@@ -917,9 +918,8 @@ static int launch_proj(int epi, const ProjArgs& a, int64_t max_tokens, int num_c
     }
     if (!small) return launch_proj_shape<ShapeBig, 2>(epi, a, num_cu, device, st);
     // producer/consumer loop (one persistent block per CU): at most one tile per CU, or more than two (measured: 600 tiles -7 % vs the streaming loop
-    // with two blocks per CU; between one and two tiles per CU the two co-resident streaming blocks quantise better).  130 forces it, 128 / 129 the others
+    // with two blocks per CU; between one and two tiles per CU the two co-resident streaming blocks quantise better).  130 forces it, 128 the streaming loop
     if (((small_tiles <= num_cu || small_tiles > 2 * num_cu) && force != 128) || force == 130) {
-        if (force == 129) return launch_proj_shape<ShapeSmall, 4>(epi, a, num_cu, device, st);
         constexpr int lds = SPLIT_RING * ShapeSplit::STAGE_BYTES + 4 * EPI_STAGE_BYTES;
         static bool attr_set_dev[64] = {};
         if (!attr_set_dev[device & 63]) {

@@ -158,7 +158,7 @@ struct CoarseArgs {
 // memory that it has to wait for.
 //   direct != 0 (round 0, thr = -inf): every score is stored at slot = (tile slot in round)*BM + row in tile, no atomics.
 //   otherwise: thresholds sit in LDS (loaded once per launch); survivors of one accumulator register are compacted with
-//   ballot/mbcnt and stored (fire-and-forget) to THIS WAVE's private list, whose cursor lives in an SGPR; k_scatter later
+//   ballot/mbcnt and stored (fire-and-forget) to THIS WAVE's private list, whose cursor lives in an SGPR; scatter_wave_lists (end of the kernel)
 //   moves the lists into the per-query buffers.
 constexpr int WLISTCAP = 8192;                      // entries per wave list (expected nq*cap/2/(8*num_blocks) ~ 1k-2k)
 constexpr int COARSE_LDS = COARSE_STAGES * ShapeC::STAGE_BYTES + QBLK * 4;

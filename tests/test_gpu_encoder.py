@@ -162,7 +162,7 @@ def test_long_and_many_sequences_vs_oracle(B, S):
     """Sequence lengths up to max_position_embeddings (the reference's doc_maxlength default, compute_corpus_embeddings.py:32-33) and
     batches that span several attention blocks / token tiles, ragged with right and left padding, against the numpy oracle (which is
     pinned to the reference by the goldens).  Covers every heads-per-block variant of the attention kernel (S = 33 / 64 / >= 96) and
-    the large-tile, small-tile and 4-slot projection paths."""
+    the 256x256, 128x128 and 32x32 projection paths."""
     cfg = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
                           max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
     w = E.synth_weights(128, 2, 512, 1000, 512, seed=11)
