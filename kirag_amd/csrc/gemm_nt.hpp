@@ -13,6 +13,8 @@
 #pragma once
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace kr {
 
 template <int BM_, int BN_, int WM_, int WN_>
@@ -554,52 +556,61 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
         acc.m_wave = grp * 128;
         acc.n_wave = wq * 64;
         acc.lane = lane;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc.v[mi][ni][r] = 0.f;
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* sa = smem + cur * STAGE;
-            const char* sb = sa + ABYTES;
-            cur ^= 1;
+        // One interval = L(t,h) (fragments of k-half h, 4 DMA pieces, counted waits) + barrier + M(t,h) (16 MFMAs, nothing else).  The first interval of
+        // an output tile is a separate instantiation (FIRST): its first k-step takes the inline constant 0 as the C operand, so the accumulators are never
+        // zero-initialised (128 v_mov per wave and tile at the boundary, where nothing overlaps them).
+        auto interval = [&](auto first_tag, const char* sa, const char* sb, int h, bool last) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             uint4 af[2][4], bf[2][2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                // ---------------- L(t,h): fragments of k-half h, 4 DMA pieces, counted waits ----------------
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int coff = ((2 * (2 * h + k2) + fh) ^ fswz) << 4;
 #pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    const int coff = ((2 * (2 * h + k2) + fh) ^ fswz) << 4;
+                for (int ni = 0; ni < 2; ++ni) bf[k2][ni] = *reinterpret_cast<const uint4*>(sb + b_row_byte + ni * 32 * 128 + coff);
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) bf[k2][ni] = *reinterpret_cast<const uint4*>(sb + b_row_byte + ni * 32 * 128 + coff);
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) af[k2][mi] = *reinterpret_cast<const uint4*>(sa + a_row_byte + mi * 32 * 128 + coff);
-                }
-                if (h == 0) issue4(cx, false, xpiece); else issue4(cy, true, ypiece);
-                wait_vmcnt<4>();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---------------- M(t,h): 16 MFMAs, nothing else ----------------
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
-                            acc.v[mi][ni] = SWAP ? T::mfma(bf[k2][ni], af[k2][mi], acc.v[mi][ni]) : T::mfma(af[k2][mi], bf[k2][ni], acc.v[mi][ni]);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                // The barrier that ends an output tile's last M interval: group 0 passes it and then runs its epilogue, group 1
-                // (whose M interval is the one AFTER it) runs its epilogue first and only then arrives, so the two epilogues run
-                // side by side (VALU / LDS / store work of two waves per SIMD interleaves) instead of one after the other.
-                const bool last = (h == 1) && (kt == nk - 1);
-                if (!(last && grp)) __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
+                for (int mi = 0; mi < 4; ++mi) af[k2][mi] = *reinterpret_cast<const uint4*>(sa + a_row_byte + mi * 32 * 128 + coff);
             }
+            if (h == 0) issue4(cx, false, xpiece); else issue4(cy, true, ypiece);
+            wait_vmcnt<4>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        if constexpr (FIRST) {
+                            if (k2 == 0) {
+                                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                acc.v[mi][ni] = SWAP ? T::mfma(bf[k2][ni], af[k2][mi], zero) : T::mfma(af[k2][mi], bf[k2][ni], zero);
+                                continue;
+                            }
+                        }
+                        acc.v[mi][ni] = SWAP ? T::mfma(bf[k2][ni], af[k2][mi], acc.v[mi][ni]) : T::mfma(af[k2][mi], bf[k2][ni], acc.v[mi][ni]);
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // The barrier that ends an output tile's last M interval: group 0 passes it and then runs its epilogue, group 1
+            // (whose M interval is the one AFTER it) runs its epilogue first and only then arrives, so the two epilogues run
+            // side by side (VALU / LDS / store work of two waves per SIMD interleaves) instead of one after the other.
+            if (!(last && grp)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        {
+            const char* sa = smem + cur * STAGE;
+            cur ^= 1;
+            interval(std::true_type{}, sa, sa + ABYTES, 0, false);
+            interval(std::false_type{}, sa, sa + ABYTES, 1, nk == 1);
+        }
+        for (int kt = 1; kt < nk; ++kt) {
+            const char* sa = smem + cur * STAGE;
+            cur ^= 1;
+            interval(std::false_type{}, sa, sa + ABYTES, 0, false);
+            interval(std::false_type{}, sa, sa + ABYTES, 1, kt == nk - 1);
         }
         epi(acc, m0, n0, nat);
         if (grp) __builtin_amdgcn_s_barrier();
