@@ -367,22 +367,29 @@ __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage
     const int r8 = acc.lane >> 3, ch = acc.lane & 7;
     const char* st_rd = stage + r8 * 128 + ((ch ^ r8) << 4);
     uint16_t* g_base = out + (row0 + r8) * ld + col0 + ch * 8;
+    // software pipeline over the mi blocks: write(mi), read(mi), THEN the global stores of mi-1 — LDS operations of one wave complete in order, so
+    // the single 4-KiB stage is safe to overwrite right after the reads were issued, and the stores of block mi-1 only wait for their own reads
+    // (counted lgkmcnt) while the LDS round trip of block mi is in flight (one exposed round trip per tile instead of one per block)
+    uint4 d[2][4];
 #pragma unroll
-    for (int mi = 0; mi < Shape::TM; ++mi) {
+    for (int mi = 0; mi <= Shape::TM; ++mi) {
+        if (mi < Shape::TM) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = f(f32x4{acc.v[mi][ni][4 * g], acc.v[mi][ni][4 * g + 1], acc.v[mi][ni][4 * g + 2], acc.v[mi][ni][4 * g + 3]}, ni, g);
-                uint2 w;
-                w.x = pack_bf16x2(v.x, v.y); w.y = pack_bf16x2(v.z, v.w);
-                *reinterpret_cast<uint2*>(stage + c * 128 + (((ni * 4 + g) ^ (c & 7)) << 4) + h * 8) = w;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = f(f32x4{acc.v[mi][ni][4 * g], acc.v[mi][ni][4 * g + 1], acc.v[mi][ni][4 * g + 2], acc.v[mi][ni][4 * g + 3]}, ni, g);
+                    uint2 w;
+                    w.x = pack_bf16x2(v.x, v.y); w.y = pack_bf16x2(v.z, v.w);
+                    *reinterpret_cast<uint2*>(stage + c * 128 + (((ni * 4 + g) ^ (c & 7)) << 4) + h * 8) = w;
+                }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            // rl & 7 == lane >> 3 for every p: one lane-dependent LDS / global base, the rest are wave-uniform steps (8 rows per store)
-            const uint4 d = *reinterpret_cast<const uint4*>(st_rd + p * 8 * 128);
-            __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d), reinterpret_cast<u32x4_t*>(g_base + (int64_t)(mi * 32 + p * 8) * ld));
+            for (int p = 0; p < 4; ++p) d[mi & 1][p] = *reinterpret_cast<const uint4*>(st_rd + p * 8 * 128);
+        }
+        if (mi > 0) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)   // rl & 7 == lane >> 3 for every p: one lane-dependent LDS / global base, the rest are wave-uniform steps (8 rows per store)
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d[(mi - 1) & 1][p]), reinterpret_cast<u32x4_t*>(g_base + (int64_t)((mi - 1) * 32 + p * 8) * ld));
         }
     }
 }
