@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised soak of the HIP paths on one GPU (python tools/stress.py [seconds] [seed]): every case is checked on the device itself —
+"""Randomised soak of the HIP paths on one GPU (python tests/soak_gpu.py [seconds] [seed]; not collected by pytest): every case is checked on the device itself —
   * index: certified MFMA scan (mode 0, every coarse kernel variant: <= 32 / <= 128 / 1024-query blocks, 1..4 rounds, incremental adds) must equal the
     exact fp64 scan (mode 1) in rows and score bits;
   * encoder (tiny config): the four projection main loops (KIRAG_AMD_PROJ_TILE = 256 / 130 / 128 / 32) must agree bit for bit, and a sequence's
@@ -55,7 +55,7 @@ while time.time() < t_end - budget * 0.35:
     del ix, x
 
 # ---- encoder -----------------------------------------------------------------------------------------------------------------------------
-from oracle import encoder_np as E   # weights generator only (test infrastructure; this tool is not part of the product)
+from oracle import encoder_np as E   # synthetic-weights generator (this file lives under tests/: the oracle is test infrastructure)
 cfg = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
                       max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
 w = E.synth_weights(128, 2, 512, 1000, 512, seed=11)
