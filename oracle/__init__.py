@@ -11,7 +11,7 @@ Pinning status
 * encoder half (``encoder_np``): pinned against outputs of the reference's own
   ``retriever/encoders.py`` (``E5Encoder`` / ``BGEEncoder`` / ``average_pool``)
   imported in the build container; the vectors live in ``tests/golden/`` and
-  were produced by ``tools/make_golden.py``.
+  were produced by ``tests/golden/make_golden.py``.
 * search half (``search_np`` / ``search_c.c``): the reference delegates to
   faiss-cpu==1.8.0.post1 ``IndexFlatIP`` (``retriever/index.py:13,47``), which is
   neither vendored in the reference nor installed here, and the reference has

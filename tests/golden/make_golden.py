@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by IMPORTING the reference (build container only).
 
-Run:  PYTHONPATH=/root/reference python tools/make_golden.py
+Run:  PYTHONPATH=/root/reference python tests/golden/make_golden.py
 The reference never travels: only the small input/output vectors written here are committed.
 Weights are NOT stored — they are regenerated from the seeded recipe ``oracle.encoder_np.synth_weights``
 and loaded into the reference's own classes with ``load_state_dict``.
@@ -29,7 +29,7 @@ import types
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 REF = "/root/reference"
 if REF not in sys.path:

@@ -1,5 +1,5 @@
 """GPU parity tests of the encoder path (through the C ABI) against vectors produced by the reference's own
-E5Encoder / BGEEncoder (tests/golden, tools/make_golden.py) and against the numpy oracle.
+E5Encoder / BGEEncoder (tests/golden, tests/golden/make_golden.py) and against the numpy oracle.
 
 Tolerances.  The reference computes in fp32; the HIP path feeds bf16 operands to the MFMAs (fp32 accumulate,
 fp32 residual stream).  north_star: cosine scores within 1e-3.  Bars used here, on unit-norm outputs:

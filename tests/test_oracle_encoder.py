@@ -1,5 +1,5 @@
 """Pins oracle/encoder_np.py against vectors produced by the reference's own encoders
-(tools/make_golden.py, imported from /root/reference in the build container)."""
+(tests/golden/make_golden.py, imported from /root/reference in the build container)."""
 import numpy as np
 import pytest
 
