@@ -47,7 +47,27 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=64)
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="rank launch + process group + barrier / max-over-ranks + the rank-0 JSON line, NO compute and value = null "
+                         "(lets the CPU test suite exercise `--gpus N` without a GPU; never a bench result)")
     return ap.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves, one process per GPU, exactly as the
+    driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, the launch model of the reference's
+    README.md:86 / utils/utils.py:91-98).  This parent has NOT touched the GPU (no torch import, no HIP call): it only starts the launcher as a
+    child process, relays its output and exits with its code; rank 0 prints the one JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(args, q_host, with_encoder):
@@ -81,14 +101,44 @@ def cpu_baseline(args, q_host, with_encoder):
     return out
 
 
-def main():
-    args = parse()
+def plumbing_only(args, world, rank):
+    """--plumbing-only: everything of the N-rank contract except the GPU work (gloo on CPU)."""
     import torch
     import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing only (no compute)", "value": None, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": None, "data": "none", "config": {"workload": "none: --plumbing-only"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))               # before any torch / HIP call in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with --gpus N (or run `python bench.py --gpus N`, "
+                         f"which starts them itself)")
+    if args.plumbing_only:
+        return plumbing_only(args, world, rank)
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (kirag_amd has no CPU fallback)")
     # one rank per GPU; KIRAG_BENCH_BACKEND=gloo lets a 1-GPU box rehearse the N > 1 code path with several ranks on the same device

@@ -38,3 +38,45 @@ def test_bench_defaults_are_the_metric_configuration():
         sys.argv = argv
     assert (a.gpus, a.total_rows, a.queries, a.topk, a.dim, a.query_tokens, a.passage_tokens) == (1, 5_000_000, 1000, 100, 1024, 32, 128)
     assert a.steps * 35e-3 < 60 and a.coarse_dtype == "bf16"        # the default run finishes within minutes
+
+
+def _run_bench(extra, env_extra=None, timeout=600):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, lines
+
+
+def test_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE) must itself start 2 ranks and print ONE line with n_gpus == 2
+    (round-1 finding: the flag was parsed and ignored).  --plumbing-only = everything but the GPU work, gloo on CPU."""
+    p, lines = _run_bench(["--gpus", "2", "--plumbing-only"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] is None
+
+
+def test_gpus_flag_must_match_world_size():
+    p, lines = _run_bench(["--gpus", "2", "--plumbing-only"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert p.returncode != 0 and not lines and "WORLD_SIZE=3" in p.stderr
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_real_step_on_one_box():
+    """The real N = 2 step (row shards, per-rank query-slice encode, all-gather of query vectors and of per-shard top-k, device merge) started by
+    `python bench.py --gpus 2` itself; the two ranks share the box's one GPU, so the collective backend is gloo (RCCL wants one device per rank)."""
+    p, lines = _run_bench(["--gpus", "2", "--total-rows", "300000", "--queries", "256", "--steps", "2", "--warmup", "1", "--passages", "64",
+                           "--no-cpu-baseline"], {"KIRAG_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["rows_per_gpu"] == 150000
+    st = d["search_stats"]
+    assert st["certified"] + st["fallback"] == st["queries"]
