@@ -32,10 +32,16 @@ extern "C" {
 #define KR_EHIP (-5)      /* a HIP runtime call failed; see kr_last_error() */
 #define KR_ESTATE (-1)    /* handle not ready (e.g. encoder weights missing) */
 
-#define KR_ABI_VERSION 1
+#define KR_ABI_VERSION 2
 int kr_abi_version(void);
 const char* kr_last_error(void);
 int kr_device_count(void);
+/* process-wide test / diagnostic switches.  "force_exact_scores" (0/1): every canonical score goes through the integer
+ * super-accumulator instead of the certified fp64 fast path (same results by definition; exercises the rare path).
+ * Unknown names: KR_EINVAL. */
+int kr_set_option(const char* name, int value);
+/* frees the per-device scratch buffers kr_score_topk keeps between calls */
+void kr_release_scratch(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Flat inner-product index — replaces faiss.IndexFlatIP behind retriever/index.py (Indexer, :17-83).
@@ -63,21 +69,28 @@ int kr_index_get_rows(kr_index* ix, int64_t start, int64_t n, float* out, void* 
 /* Indexer.search_knn -> index.search(q, top_docs) (index.py:47): exact inner-product top-k.
  *   q       [nq,d] fp32;  scores [nq,k] fp32 (descending);  rows [nq,k] int64 = internal row numbers
  *   (the caller maps them through index_id_to_db_id exactly as index.py:49 does).
- * Result definition (identical to oracle/search_c.c): score = fp64-accumulated inner product in the canonical
- * order rounded once to fp32; ranking by (score desc, row asc).  0 < k <= ntotal, else KR_EINVAL.
- * `mode`: 0 = auto (MFMA coarse scan + certified exact re-rank, exact-scan fallback for uncertified queries),
- *         1 = force the exact full scan (slow; used by tests as an on-device cross-check). */
+ * Result definition (identical to oracle/search_c.c): score = the EXACT inner product of the fp32 inputs rounded once to
+ * fp32 (round-to-nearest-even; independent of any summation order); ranking by (score desc, row asc); rows whose score is
+ * NaN are never returned.  0 < k <= min(ntotal, 1024), else KR_EINVAL.
+ * `mode`: 0 = auto: pass 1 = 16-bit MFMA scan + certified exact re-rank for all queries; pass 2 = fp64 MFMA scan of the fp32 rows
+ *             + certified re-rank for the queries pass 1 could not certify (they share one pass over the corpus per group of
+ *             32); pass 3 = exact scan, query by query, for what is left (mass ties);
+ *         1 = exact scan only, 2 = pass 2 (+3) only — slow; used by tests as on-device cross-checks. */
 int kr_index_search(kr_index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int mode, void* stream);
 
 typedef struct {
     int64_t queries;          /* queries answered since creation / last reset */
     int64_t certified;        /* answered by the fast path with the exactness certificate holding */
-    int64_t fallback;         /* re-answered by the exact full scan */
-    int64_t overflow;         /* candidate-buffer overflows (subset of fallback) */
+    int64_t fallback;         /* not certified by pass 1 (= fine + exact) */
+    int64_t overflow;         /* candidate-buffer overflows in pass 1 (subset of fallback) */
     int64_t reranked_rows;    /* fp32 rows gathered by the re-rank kernel */
     int64_t coarse_rounds;    /* coarse GEMM launches */
     double last_coarse_ms;    /* device time of the coarse launches of the last search call (HIP events) */
     double last_total_ms;     /* device time of the whole last search call */
+    int64_t fine;             /* answered by pass 2 (fp64 MFMA scan, certified) */
+    int64_t exact;            /* answered by pass 3 (exact scan) */
+    int64_t fine_rounds;      /* pass-2 scan launches */
+    double last_fine_ms;      /* device time of pass 2 in the last search call */
 } kr_search_stats;
 int kr_index_stats(kr_index* ix, kr_search_stats* out, int reset);
 

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkirag_amd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class KiragAmdError(RuntimeError):
@@ -24,7 +24,8 @@ class KiragAmdError(RuntimeError):
 class SearchStats(C.Structure):
     _fields_ = [("queries", C.c_int64), ("certified", C.c_int64), ("fallback", C.c_int64), ("overflow", C.c_int64),
                 ("reranked_rows", C.c_int64), ("coarse_rounds", C.c_int64), ("last_coarse_ms", C.c_double),
-                ("last_total_ms", C.c_double)]
+                ("last_total_ms", C.c_double), ("fine", C.c_int64), ("exact", C.c_int64), ("fine_rounds", C.c_int64),
+                ("last_fine_ms", C.c_double)]
 
 
 class BertCfg(C.Structure):
@@ -37,6 +38,8 @@ SIGNATURES = {
     "kr_abi_version": (C.c_int, []),
     "kr_last_error": (C.c_char_p, []),
     "kr_device_count": (C.c_int, []),
+    "kr_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "kr_release_scratch": (None, []),
     "kr_index_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "kr_index_destroy": (None, [C.c_void_p]),
     "kr_index_reserve": (C.c_int, [C.c_void_p, C.c_int64]),

@@ -1,6 +1,7 @@
 // Error plumbing and device selection shared by every entry point of libkirag_amd.so.
 #include "common.hpp"
 
+#include <atomic>
 #include <cstring>
 
 namespace kr {
@@ -19,6 +20,8 @@ int fail(int code, const char* fmt, ...) {
     last_error_ref() = buf;
     return code;
 }
+
+std::atomic<int> g_force_exact{0};
 
 int select_device(int device) {
     int n = 0;
@@ -48,5 +51,9 @@ int kr_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+int kr_set_option(const char* name, int value) {
+    if (name && std::strcmp(name, "force_exact_scores") == 0) { kr::g_force_exact.store(value != 0); return 0; }
+    return kr::fail(KR_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 }

@@ -5,6 +5,7 @@
 #include <string>
 #include <cstdio>
 #include <cstdarg>
+#include <atomic>
 
 #include "../../include/kirag_amd.h"
 
@@ -34,6 +35,7 @@ int fail(int code, const char* fmt, ...);
     } while (0)
 
 int select_device(int device);  // hipSetDevice + arch check (gfx950)
+extern std::atomic<int> g_force_exact;   // kr_set_option("force_exact_scores")
 
 // ---- 16-bit element tags ------------------------------------------------------------------------------------
 struct BF16 {
@@ -90,31 +92,113 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
     return __hiloint2double(hi, lo);
 }
 
-// canonical inner product (bit-for-bit twin of oracle/search_c.c kr_oracle_dot):
-// lane l accumulates, in increasing i, the exact products of the elements with ((i>>2)&63)==l, then a
-// 6-stage XOR butterfly m = 32..1.  q and x point at d floats (d % 4 == 0, 16-B aligned rows).
-__device__ __forceinline__ double canonical_dot_wave(const float* __restrict__ q, const float* __restrict__ x, int d, int lane) {
-    double acc = 0.0;
+// ---- canonical score ----------------------------------------------------------------------------------------------------------------------
+// score(q, x) = RN32( EXACT inner product of the fp32 inputs ): the exact real sum rounded once to fp32, round-to-nearest-even.  A mathematical
+// definition, independent of any summation order; oracle/search_c.c computes it sequentially (plain fp64 + certified rounding, integer
+// super-accumulator), tests/golden/g9_exact_dot.npz holds known answers from Python rationals.  Here:
+//   fast path   lane l sums its share of the (exact) fp64 products p_i and of |p_i|, two XOR butterflies give S and A on every lane; for ANY
+//               summation order |S - exact| <= (d-1) u A / (1 - (d-1) u), u = 2^-53, so the exact sum lies in [S - E, S + E] with
+//               E = (d + 4) * 1.2e-16 * A; if both ends round to the same float, that float is the canonical score.
+//   exact path  (about 2 in 10^6 scores of unit vectors; ALWAYS with force_exact, a test hook) the wave adds every product as an integer into a
+//               704-bit fixed-point accumulator in LDS (ds_add_u64 on 22 limbs of 32 payload bits, bit 0 = 2^-298), lane 0 propagates the
+//               carries and rounds the exact integer once.
+constexpr int EXACT_NLIMB = 22;
+
+__device__ __forceinline__ void f32_decode(float f, uint32_t& sign, uint64_t& m, int& e) {   // |f| = m * 2^e, finite f
+    const uint32_t u = __float_as_uint(f);
+    sign = u >> 31;
+    const uint32_t ex = (u >> 23) & 0xffu, fr = u & 0x7fffffu;
+    if (ex == 0) { m = fr; e = -149; }
+    else { m = fr | 0x800000u; e = (int)ex - 150; }
+}
+
+// wave-cooperative; q, x: d finite floats (d % 4 == 0, 16-B aligned); limbs: EXACT_NLIMB words of LDS private to this wave.  Every lane returns the score.
+__device__ __forceinline__ float exact_dot_rn32_wave(const float* __restrict__ q, const float* __restrict__ x, int d, int lane, unsigned long long* limbs) {
+    if (lane < EXACT_NLIMB) limbs[lane] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     for (int i = lane * 4; i < d; i += 256) {
         const float4 a = *reinterpret_cast<const float4*>(q + i);
         const float4 b = *reinterpret_cast<const float4*>(x + i);
-        acc += (double)a.x * (double)b.x;
-        acc += (double)a.y * (double)b.y;
-        acc += (double)a.z * (double)b.z;
-        acc += (double)a.w * (double)b.w;
-    }
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) acc += shfl_xor_f64(acc, m);
-    return acc;
+        for (int c = 0; c < 4; ++c) {
+            uint32_t sa, sb; uint64_t ma, mb; int ea, eb;
+            f32_decode(av[c], sa, ma, ea);
+            f32_decode(bv[c], sb, mb, eb);
+            const uint64_t M = ma * mb;                          // < 2^48, exact
+            if (M == 0ull) continue;
+            const int o = ea + eb + 298;                         // bit offset of M's LSB: 0 .. 506
+            const int limb = o >> 5, sh = o & 31;
+            unsigned long long p0 = (M << sh) & 0xffffffffull;
+            unsigned long long p1 = (M >> (32 - sh)) & 0xffffffffull;
+            unsigned long long p2 = sh > 16 ? (M >> (64 - sh)) : 0ull;
+            if (sa ^ sb) { p0 = 0ull - p0; p1 = 0ull - p1; p2 = 0ull - p2; }   // two's complement: the limbs are signed
+            atomicAdd(&limbs[limb], p0);
+            if (p1) atomicAdd(&limbs[limb + 1], p1);
+            if (p2) atomicAdd(&limbs[limb + 2], p2);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        long long carry = 0;
+        for (int i = 0; i < EXACT_NLIMB; ++i) {                  // digits in [0, 2^32); the carry out of the top limb is 0 (value >= 0) or -1
+            const long long t = (long long)limbs[i] + carry;
+            carry = t >> 32;
+            limbs[i] = (unsigned long long)(t - carry * 4294967296LL);
+        }
+        const bool neg = carry < 0;
+        if (neg) {                                               // magnitude = 2^(32 NLIMB) - digits
+            unsigned long long c = 1ull;
+            for (int i = 0; i < EXACT_NLIMB; ++i) { const unsigned long long v = ((~limbs[i]) & 0xffffffffull) + c; limbs[i] = v & 0xffffffffull; c = v >> 32; }
+        }
+        int top = EXACT_NLIMB - 1;
+        while (top >= 0 && limbs[top] == 0ull) --top;
+        float r = 0.0f;                                          // exact zero: +0
+        if (top >= 0) {
+            const int hb = 31 - __clz((unsigned int)limbs[top]);
+            const int P = top * 32 + hb;                         // leading bit; value = magnitude * 2^-298
+            const int lsb = P - 23 > 149 ? P - 23 : 149;         // fp32 quantum: 24 significant bits, never below 2^-149
+            const int a0 = lsb >> 5, s0 = lsb & 31;
+            const unsigned long long win = limbs[a0] | ((a0 + 1 < EXACT_NLIMB ? limbs[a0 + 1] : 0ull) << 32);
+            unsigned long long mant = (win >> s0) & ((1ull << (P - lsb + 1)) - 1ull);
+            const int rb = lsb - 1;                              // >= 148
+            const unsigned long long rl = limbs[rb >> 5];
+            const bool rnd = (rl >> (rb & 31)) & 1ull;
+            bool sticky = (rl & ((1ull << (rb & 31)) - 1ull)) != 0ull;
+            for (int i = (rb >> 5) - 1; i >= 0 && !sticky; --i) sticky = limbs[i] != 0ull;
+            if (rnd && (sticky || (mant & 1ull))) ++mant;
+            r = ldexpf((float)mant, lsb - 298);                  // exact: mant <= 2^24; overflow -> inf; mant == 0 -> 0
+            if (neg) r = -r;
+        }
+        limbs[0] = (unsigned long long)__float_as_uint(r);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const float out = __uint_as_float((unsigned int)limbs[0]);
+    __builtin_amdgcn_wave_barrier();
+    return out;
 }
 
-// Same canonical score for TWO rows at once with the query chunks already in registers (qr[j] = q[lane*4 + j*256 .. +3], zero beyond d):
-// every global load of both rows is issued before the first use, so a wave pays one memory round trip per pair of rows instead of one
-// per 256-element step (the re-rank gathers one 4-KiB fp32 row per candidate from HBM).  NCH = number of 256-element steps (d <= 256 NCH).
-// The per-lane summation order is exactly canonical_dot_wave's (products with zero-filled tails add +0.0, which changes nothing).
+// S, A (wave-uniform: fp64 sum of the products and of their magnitudes, any order) -> canonical score
+__device__ __forceinline__ float canonical_finish(double S, double A, const float* __restrict__ q, const float* __restrict__ x, int d, int lane,
+                                                  unsigned long long* limbs, bool force_exact) {
+    if (!(A <= 1.7e308)) return (float)S;                        // inf / NaN inputs propagate as in IEEE arithmetic
+    const double E = (double)(d + 4) * 1.2e-16 * A;
+    const float lo = (float)(S - E), hi = (float)(S + E);
+    if (!force_exact && __float_as_uint(lo) == __float_as_uint(hi)) return lo;
+    return exact_dot_rn32_wave(q, x, d, lane, limbs);
+}
+
+// canonical scores of TWO rows at once with the query chunks already in registers (qr[j] = q[lane*4 + j*256 .. +3], zero beyond d): every global
+// load of both rows is issued before the first use, so a wave pays one memory round trip per pair of rows instead of one per 256-element step
+// (the re-rank gathers one 4-KiB fp32 row per candidate from HBM).  NCH = number of 256-element steps (d <= 256 NCH).  q points at the same
+// query in memory (exact path only).
 template <int NCH>
-__device__ __forceinline__ void canonical_dot_wave2(const float4 (&qr)[NCH], const float* __restrict__ x0, const float* __restrict__ x1, int d, int lane,
-                                                    double& e0, double& e1) {
+__device__ __forceinline__ void canonical_score_wave2(const float4 (&qr)[NCH], const float* __restrict__ q, const float* __restrict__ x0,
+                                                      const float* __restrict__ x1, int d, int lane, unsigned long long* limbs, bool force_exact,
+                                                      float& f0, float& f1) {
     float4 a[NCH], b[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -122,17 +206,27 @@ __device__ __forceinline__ void canonical_dot_wave2(const float4 (&qr)[NCH], con
         a[j] = make_float4(0.f, 0.f, 0.f, 0.f); b[j] = a[j];
         if (i < d) { a[j] = *reinterpret_cast<const float4*>(x0 + i); b[j] = *reinterpret_cast<const float4*>(x1 + i); }
     }
-    double s0 = 0.0, s1 = 0.0;
+    double s0 = 0.0, s1 = 0.0, m0 = 0.0, m1 = 0.0;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         if (lane * 4 + j * 256 < d) {
-            s0 += (double)qr[j].x * (double)a[j].x; s0 += (double)qr[j].y * (double)a[j].y; s0 += (double)qr[j].z * (double)a[j].z; s0 += (double)qr[j].w * (double)a[j].w;
-            s1 += (double)qr[j].x * (double)b[j].x; s1 += (double)qr[j].y * (double)b[j].y; s1 += (double)qr[j].z * (double)b[j].z; s1 += (double)qr[j].w * (double)b[j].w;
+            const float qv[4] = {qr[j].x, qr[j].y, qr[j].z, qr[j].w};
+            const float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w}, bv[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double p0 = (double)qv[c] * (double)av[c], p1 = (double)qv[c] * (double)bv[c];   // exact
+                s0 += p0; m0 += __builtin_fabs(p0);
+                s1 += p1; m1 += __builtin_fabs(p1);
+            }
         }
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { s0 += shfl_xor_f64(s0, m); s1 += shfl_xor_f64(s1, m); }
-    e0 = s0; e1 = s1;
+    for (int m = 32; m >= 1; m >>= 1) {
+        s0 += shfl_xor_f64(s0, m); s1 += shfl_xor_f64(s1, m);
+        m0 += shfl_xor_f64(m0, m); m1 += shfl_xor_f64(m1, m);
+    }
+    f0 = canonical_finish(s0, m0, q, x0, d, lane, limbs, force_exact);
+    f1 = canonical_finish(s1, m1, q, x1, d, lane, limbs, force_exact);
 }
 
 // in-LDS bitonic sort of n (power of two) uint64 keys, DESCENDING, by a block of nthreads threads

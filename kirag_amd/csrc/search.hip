@@ -22,6 +22,7 @@
 #include "gemm_nt.hpp"
 
 #include <algorithm>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <cmath>
@@ -45,6 +46,8 @@ struct Index {
     float* bounds = nullptr;   // [2] device: max_x ||x - c(x)||_2 , max_x ||c(x)||_2   (non-negative -> uint order)
     // search workspace (sized for QBLK queries)
     float* q_f = nullptr;      // [QBLK, d]
+    float* q_f2 = nullptr;     // [FINE_QMAX, d] compacted flagged queries of the high-precision pass
+    int force_exact = 0;       // test hook: every canonical score through the integer super-accumulator
     uint16_t* q_c = nullptr;   // [QBLK, dpad]
     float* thr = nullptr;      // [QBLK]
     float* eps = nullptr;      // [QBLK]
@@ -55,7 +58,7 @@ struct Index {
     float* out_s = nullptr;    // [QBLK, kmax]
     int64_t* out_r = nullptr;  // [QBLK, kmax]
     uint32_t* nrer = nullptr;  // [QBLK] re-ranked rows (stats)
-    uint32_t* h_status = nullptr;   // pinned host: [QBLK] flags | [QBLK] nrer | [1] list overflow
+    uint32_t* h_status = nullptr;   // pinned host: [QBLK] flags | [QBLK] nrer | [4] list overflow | pass 2: [QBLK] flags | [QBLK] nrer | [QBLK] group list overflow
     int out_k = 0;
     uint64_t* ex_a = nullptr; uint64_t* ex_b = nullptr; size_t ex_bytes = 0;  // exact-scan ping/pong
     int* ex_qidx = nullptr;    // [QBLK] flagged query list
@@ -151,6 +154,7 @@ struct CoarseArgs {
     uint4* blk_list; unsigned int* blk_cnt; unsigned int* list_overflow;
     int64_t tile_begin, tile_count;   // this round covers permuted tile slots [tile_begin, tile_begin + tile_count)
     int64_t ntiles, perm_mul;         // slot -> tile = (slot * perm_mul) % ntiles   (perm_mul coprime to ntiles)
+    const float* xf; const float* qf; int d;   // high-precision pass (k_fine): fp32 master rows, compacted fp32 queries
 };
 
 // persistent streaming coarse scan (gemm_nt_pingpong): grid = one block per CU, so nothing else on the CU hides an epilogue
@@ -409,6 +413,193 @@ __global__ __launch_bounds__(Q32_THREADS, 1) void k_coarse_q32(CoarseArgs a) {
     coarse_q32_body<T, DIRECT, KT>(a, a.xc, a.qc, smem);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// High-precision pass for the queries the 16-bit scan could not certify (dense clusters below the bf16 / f16 resolution, candidate-buffer
+// overflows): the SAME filter / select / certified re-rank pipeline, but the scan multiplies the fp32 MASTER rows by the fp32 queries with
+// fp64 products and fp64 accumulation (v_mfma_f64_16x16x4_f64: products of two fp32 values are exact in fp64), so its error bound is ~1e-11
+// instead of ~2.5e-3: the certificate then fails only on more than RERANK_MAX rows within a few fp32 ulps of the k-th score.  All flagged queries
+// of a group (up to FINE_QMAX = 32 at d <= 1024) share ONE pass over the corpus: 4 KiB per row once per group, instead of once per flagged query
+// as the exact scan does (round 1: 20 GB per flagged query at 5M rows).
+//   * the group's queries sit in LDS as fp32 (row stride dk * 4 + 16 B: the 16 queries of a B fragment fall on different banks);
+//   * every wave streams its own 32-row slots (two 16-row MFMA tiles) straight from HBM to registers, one 128-element chunk (16 float4 per lane)
+//     in flight behind the chunk being multiplied; A fragment: lane -> row l & 15, k = 32 j + 8 (l >> 4) + c; B fragment: query l & 15, same k;
+//     the k order inside the sum is irrelevant as long as A and B agree (step (j, c) pairs component c of both float4 pairs);
+//   * epilogue: D[row (l >> 4) + 4 r][query l & 15], fp64 -> fp32, then the same direct store / threshold filter as the 16-bit scans.
+// Tile slots are 32 rows (a.ntiles, a.tile_begin, a.tile_count, a.perm_mul in units of 32 rows), a.nq <= 16 NT queries.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) double f64x4;
+constexpr int FINE_THREADS = 512;
+constexpr int FINE_QMAX = 32;
+constexpr int FINE_DMAX = 2048;                       // 16 queries x 2048 x 4 B = 128 KiB of LDS
+static inline int fine_lds_bytes(int d, int gq) { const int dk = (int)round_up(d, 128); const int b = gq * (dk * 4 + 16) + 64; return b > 3 * QBLK * 4 ? b : 3 * QBLK * 4; }
+
+template <bool DIRECT, int NT>
+__global__ __launch_bounds__(FINE_THREADS, 2) void k_fine(CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int d = a.d;
+    const int dk = (d + 127) / 128 * 128;              // zero-filled tail: chunks of 128 elements
+    const int qstride = dk * 4 + 16;
+    for (int idx = threadIdx.x; idx < 16 * NT * (dk / 4); idx += FINE_THREADS) {
+        const int g = idx / (dk / 4), c4 = idx - g * (dk / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < a.nq && c4 * 4 < d) v = *reinterpret_cast<const float4*>(a.qf + (int64_t)g * d + c4 * 4);
+        *reinterpret_cast<float4*>(smem + g * qstride + c4 * 16) = v;
+    }
+    float thr[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) thr[nt] = DIRECT ? 0.f : a.thr[16 * nt + (lane & 15)];
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t wlist = __builtin_amdgcn_make_buffer_rsrc(
+        a.blk_list + ((int64_t)blockIdx.x * ShapeC::NWAVE + wave_id) * WLISTCAP, 0, WLISTCAP * 16, 0x00020000);
+    unsigned int wcnt = 0;
+    const int64_t W = (int64_t)gridDim.x * 8, w0 = (int64_t)blockIdx.x * 8 + wave_id;
+    const int64_t my = a.tile_count > w0 ? (a.tile_count - w0 + W - 1) / W : 0;
+    const int kq = 8 * (lane >> 4);                    // this lane's k offset inside a 32-element step
+    const char* qlds = smem + (lane & 15) * qstride + kq * 4;
+    const int nchunk = dk / 128;
+    for (int64_t i = 0; i < my; ++i) {
+        uint64_t qq; uint32_t tile;
+        fast_divmod64((uint64_t)(a.tile_begin + w0 + i * W) * (uint64_t)a.perm_mul, (uint32_t)a.ntiles, qq, tile);
+        const int64_t m0 = (int64_t)tile * 32;
+        const float* pa[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int64_t row = m0 + 16 * t + (lane & 15);
+            if (row >= a.n) row = a.n - 1;             // clamped rows are masked in the epilogue
+            pa[t] = a.xf + row * d + kq;
+        }
+        f64x4 acc[2][NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+        float4 cur[4][2][2], nxt[4][2][2];
+        auto load_chunk = [&](float4 (&buf)[4][2][2], int c) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int kk = c * 128 + u * 32 + kq + 4 * h;
+                        buf[u][t][h] = (kk < d) ? *reinterpret_cast<const float4*>(pa[t] + c * 128 + u * 32 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+        };
+        load_chunk(cur, 0);
+        for (int c = 0; c < nchunk; ++c) {
+            if (c + 1 < nchunk) load_chunk(nxt, c + 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float4 bq[NT][2];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        bq[nt][h] = *reinterpret_cast<const float4*>(qlds + nt * 16 * qstride + (c * 128 + u * 32 + 4 * h) * 4);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float av[2][4] = {{cur[u][0][h].x, cur[u][0][h].y, cur[u][0][h].z, cur[u][0][h].w},
+                                            {cur[u][1][h].x, cur[u][1][h].y, cur[u][1][h].z, cur[u][1][h].w}};
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const float bvv[4] = {bq[nt][h].x, bq[nt][h].y, bq[nt][h].z, bq[nt][h].w};
+                            const double b = (double)bvv[cc];
+#pragma unroll
+                            for (int t = 0; t < 2; ++t)
+                                acc[t][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[t][cc], b, acc[t][nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (c + 1 < nchunk) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) cur[u][t][h] = nxt[u][t][h];
+            }
+        }
+        // epilogue: register r of tile t, n-tile nt = row m0 + 16 t + (lane >> 4) + 4 r, query 16 nt + (lane & 15)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const uint32_t q = (uint32_t)(16 * nt + (lane & 15));
+            if constexpr (DIRECT) {
+                if (q < (uint32_t)a.nq) {
+                    uint64_t* cq = a.cand + (int64_t)q * a.cand_cap + (w0 + i * W) * 32;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ro = 16 * t + (lane >> 4) + 4 * r;
+                            const int64_t row = m0 + ro;
+                            cq[ro] = row < a.n ? make_key((float)acc[t][nt][r], (uint32_t)row) : 0ull;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = m0 + 16 * t + (lane >> 4) + 4 * r;
+                        const float sc = (float)acc[t][nt][r];
+                        const bool p = (sc >= thr[nt]) && row < a.n;          // thr = +inf for padded queries
+                        const unsigned long long mask = __ballot(p);
+                        if (mask) {
+                            if (p) {
+                                const unsigned int slot = wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                u32x4 e = {__float_as_uint(sc), (uint32_t)row, q, 0u};
+                                __builtin_amdgcn_raw_buffer_store_b128(e, wlist, slot * 16u, 0, 0);
+                            }
+                            wcnt += (unsigned)__popcll(mask);
+                        }
+                    }
+            }
+        }
+    }
+    if constexpr (!DIRECT) scatter_wave_lists(a, smem, wave_id, wcnt, FINE_THREADS);
+}
+
+// compacted copy of the flagged queries: dst[g] = src[qidx[g]]
+__global__ void k_gather_rows(const float* __restrict__ src, const int* __restrict__ qidx, float* __restrict__ dst, int d) {
+    const int g = blockIdx.x;
+    const float* s = src + (int64_t)qidx[g] * d;
+    for (int i = threadIdx.x * 4; i < d; i += blockDim.x * 4) *reinterpret_cast<float4*>(dst + (int64_t)g * d + i) = *reinterpret_cast<const float4*>(s + i);
+}
+
+// state reset + error bound of the high-precision pass for queries [0, nq) of the compacted list (blocks nq .. nq_pad-1: padding, thr = +inf).
+//   |canonical - stored fine score| <= |fine64 - exact| + two fp32 roundings
+//     fine64: fp64 accumulation of exact products in hardware order: <= 4 (d + 8) 2^-53 |q|.|x|  (a factor 4 over the round-to-nearest bound:
+//     the MFMA's internal rounding is not documented)
+template <int DUMMY = 0>
+__global__ __launch_bounds__(64) void k_prep_fine(const float* __restrict__ qf, int nq, int d, const float* __restrict__ bounds, float* __restrict__ eps,
+                                                  float* __restrict__ thr, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flags) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    float q2 = 0.f;
+    if (q < nq)
+        for (int i = lane * 4; i < d; i += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(qf + (int64_t)q * d + i);
+            q2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) q2 += __shfl_xor(q2, m, 64);
+    if (lane == 0) {
+        const float xn = bounds[0] + bounds[1];          // max |x| <= max |c(x)| + max |x - c(x)|
+        const float qn = sqrtf(q2) * 1.0001f;
+        float e = (2.4e-7f + 4.5e-16f * (float)(d + 8)) * qn * xn;
+        e = e * 1.001f + 1e-37f;
+        eps[q] = (q < nq) ? e : 0.f;
+        thr[q] = (q < nq) ? -INFINITY : INFINITY;
+        cnt[q] = 0u;
+        flags[q] = 0u;
+    }
+}
+
 // rows [n, round_up(n, 256)) of the 16-bit copy <- NaN
 __global__ void k_pad_nan(uint16_t* __restrict__ xc, int64_t n, int64_t n_pad, int dpad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -495,12 +686,15 @@ constexpr int RERANK_MAX = 2048;
 template <int NCH>   // NCH 256-element steps cover a row: d <= 256 NCH
 __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ cand, int cand_cap, const uint32_t* __restrict__ cnt,
                                                 uint32_t* __restrict__ flags, const float* __restrict__ thr, const float* __restrict__ eps,
-                                                const float* __restrict__ qf, const float* __restrict__ xf, int d, int k, int preset,
-                                                float* __restrict__ out_s, int64_t* __restrict__ out_r, uint32_t* __restrict__ nrer) {
+                                                const float* __restrict__ qf, const float* __restrict__ xf, int d, int k, int preset, int rmax,
+                                                float* __restrict__ out_s, int64_t* __restrict__ out_r, uint32_t* __restrict__ nrer,
+                                                const int* __restrict__ qmap, int force_exact) {
+    // qmap != nullptr: the blocks work on a compacted query list (the high-precision pass over flagged queries); results go to row qmap[q]
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned long long exact_limbs[4][EXACT_NLIMB];
     uint64_t* s = reinterpret_cast<uint64_t*>(smem);                                    // [cand_cap] copy of the buffer
-    uint64_t* sel = s + cand_cap;                                                       // [RERANK_MAX]
-    unsigned int* hist = reinterpret_cast<unsigned int*>(sel + RERANK_MAX);             // 256 + 4
+    uint64_t* sel = s + cand_cap;                                                       // [rmax]
+    unsigned int* hist = reinterpret_cast<unsigned int*>(sel + rmax);                   // 256 + 4
     unsigned int& rc = hist[259];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int m = preset > 0 ? preset : (int)cnt[q];
@@ -520,12 +714,12 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
     const bool certified = ok && (theta > thr[q]);
     for (int i = tid; i < m; i += 256) {
         const uint64_t key = s[i];
-        if (key_score(key) >= theta) { const unsigned p = atomicAdd(&rc, 1u); if (p < (unsigned)RERANK_MAX) sel[p] = key; }
+        if (key_score(key) >= theta) { const unsigned p = atomicAdd(&rc, 1u); if (p < (unsigned)rmax) sel[p] = key; }
     }
     __syncthreads();
     const int r_all = (int)rc;
-    const int r = r_all < RERANK_MAX ? r_all : RERANK_MAX;
-    if (tid == 0) { nrer[q] = (uint32_t)r; if (!certified || r_all > RERANK_MAX || r_all < k) flags[q] |= 2u; }
+    const int r = r_all < rmax ? r_all : rmax;
+    if (tid == 0) { nrer[q] = (uint32_t)r; if (!certified || r_all > rmax || r_all < k) flags[q] |= 2u; }
     int P = 1; while (P < r) P <<= 1;
     if (P < 1) P = 1;
     __syncthreads();
@@ -540,18 +734,19 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
         for (int i = wave; i < P; i += 8) {                    // two candidate rows per wave and step: i and i + 4
             const bool v0 = i < r, v1 = i + 4 < r;
             const uint32_t row0 = v0 ? key_row(sel[i]) : 0u, row1 = v1 ? key_row(sel[i + 4]) : row0;
-            double e0 = 0.0, e1 = 0.0;
-            if (v0) canonical_dot_wave2<NCH>(qr, xf + (int64_t)row0 * d, xf + (int64_t)row1 * d, d, lane, e0, e1);
+            float e0 = 0.f, e1 = 0.f;
+            if (v0) canonical_score_wave2<NCH>(qr, qv, xf + (int64_t)row0 * d, xf + (int64_t)row1 * d, d, lane, exact_limbs[wave], force_exact != 0, e0, e1);
             if (lane == 0) {
-                sel[i] = v0 ? make_key((float)e0, row0) : 0ull;
-                if (i + 4 < P) sel[i + 4] = v1 ? make_key((float)e1, row1) : 0ull;
+                sel[i] = v0 ? make_key(e0, row0) : 0ull;
+                if (i + 4 < P) sel[i + 4] = v1 ? make_key(e1, row1) : 0ull;
             }
         }
     }
     bitonic_sort_desc(sel, P, tid, 256);
+    const int64_t qo = qmap ? (int64_t)qmap[q] : (int64_t)q;
     for (int j = tid; j < k && j < P; j += 256) {
-        out_s[(int64_t)q * k + j] = key_score(sel[j]);
-        out_r[(int64_t)q * k + j] = (int64_t)key_row(sel[j]);
+        out_s[qo * k + j] = key_score(sel[j]);
+        out_r[qo * k + j] = (int64_t)key_row(sel[j]);
     }
 }
 
@@ -561,10 +756,11 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
 // grid (nchunks, nqf): canonical score of every row of the chunk for one query, chunk-local top-kk keys
 template <int NCH>   // NCH 256-element steps cover a row: d <= 256 NCH
 __global__ __launch_bounds__(256) void k_exact_scan(const float* __restrict__ qf, const int* __restrict__ qidx, const float* __restrict__ xf,
-                                                    int64_t n, int d, int kk, uint64_t* __restrict__ out, int nchunks, int rc) {
+                                                    int64_t n, int d, int kk, uint64_t* __restrict__ out, int nchunks, int rc, int force_exact) {
     // rc = rows per block (a power of two, kk <= rc <= EXACT_RC): 1024 for corpus-sized scans, as little as 64 for a transient candidate set of a
     // few hundred rows (kr_score_topk), so that the rows of ONE query are spread over several CUs instead of being a 128-step latency chain on one
     __shared__ uint64_t s[EXACT_RC];
+    __shared__ unsigned long long exact_limbs[4][EXACT_NLIMB];
     const int chunk = blockIdx.x, qi = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* qv = qf + (int64_t)qidx[qi] * d;
     const int64_t r0 = (int64_t)chunk * rc;
@@ -577,10 +773,10 @@ __global__ __launch_bounds__(256) void k_exact_scan(const float* __restrict__ qf
     for (int i = wave; i < rc; i += 8) {
         const int64_t row0 = r0 + i, row1 = r0 + i + 4;
         const bool v0 = row0 < n, v1 = row1 < n && i + 4 < rc;
-        double e0 = 0.0, e1 = 0.0;
-        if (v0) canonical_dot_wave2<NCH>(qr, xf + row0 * d, xf + (v1 ? row1 : row0) * d, d, lane, e0, e1);
+        float e0 = 0.f, e1 = 0.f;
+        if (v0) canonical_score_wave2<NCH>(qr, qv, xf + row0 * d, xf + (v1 ? row1 : row0) * d, d, lane, exact_limbs[wave], force_exact != 0, e0, e1);
         if (lane == 0) {
-            uint64_t k0 = v0 ? make_key((float)e0, (uint32_t)row0) : 0ull, k1 = v1 ? make_key((float)e1, (uint32_t)row1) : 0ull;
+            uint64_t k0 = v0 ? make_key(e0, (uint32_t)row0) : 0ull, k1 = v1 ? make_key(e1, (uint32_t)row1) : 0ull;
             if (v0 && k0 == 0ull) k0 = 1ull;   // cannot happen for row < 2^32-1; keeps "0 = padding" unambiguous
             if (v1 && k1 == 0ull) k1 = 1ull;
             s[i] = k0;
@@ -650,7 +846,8 @@ static int ensure_ws(Index* ix, int k, int cand_cap) {
         KR_HIP(hipMalloc(&ix->cnt, QBLK * sizeof(uint32_t)));
         KR_HIP(hipMalloc(&ix->flags, QBLK * sizeof(uint32_t)));
         KR_HIP(hipMalloc(&ix->nrer, QBLK * sizeof(uint32_t)));
-        KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->h_status), (2 * QBLK + 1) * sizeof(uint32_t), hipHostMallocDefault));
+        KR_HIP(hipMalloc(&ix->q_f2, (size_t)32 * ix->d * sizeof(float)));
+        KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->h_status), (5 * QBLK + 8) * sizeof(uint32_t), hipHostMallocDefault));
         KR_HIP(hipMalloc(&ix->ex_qidx, QBLK * sizeof(int)));
         KR_HIP(hipMalloc(&ix->blk_list, (size_t)ix->num_cu * ShapeC::NWAVE * WLISTCAP * sizeof(uint4)));
         KR_HIP(hipMalloc(&ix->blk_cnt, ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int)));
@@ -699,7 +896,7 @@ static int exact_scan(Index* ix, int nqf, int k, hipStream_t st) {
         const int g = std::min(group, nqf - g0);
         auto scan = ix->d <= 1024 ? &k_exact_scan<4> : ix->d <= 2048 ? &k_exact_scan<8> : &k_exact_scan<16>;
         hipLaunchKernelGGL(scan, dim3((unsigned)nchunks, g), dim3(256), 0, st, ix->q_f, ix->ex_qidx + g0, ix->xf, ix->n, ix->d, kk,
-                           ix->ex_a, (int)nchunks, rc);
+                           ix->ex_a, (int)nchunks, rc, ix->force_exact);
         uint64_t* cur = ix->ex_a; uint64_t* nxt = ix->ex_b;
         int64_t m = per_q;
         while (m > kk) {   // reduce until one sorted list of kk keys per query remains
@@ -716,15 +913,24 @@ static int exact_scan(Index* ix, int nqf, int k, hipStream_t st) {
     return 0;
 }
 
+// once per (process, device): hipFuncSetAttribute for the kernels that need more than 64 KiB of dynamic LDS.  Function attributes belong to
+// the device's code-object instance; std::call_once makes the guard safe when several host threads search on different handles.
+struct DevOnce { std::once_flag f[64]; int rc[64] = {}; };
+template <class F> static int once_per_device(DevOnce& o, int device, F&& fn) {
+    const int i = device & 63;
+    std::call_once(o.f[i], [&] { o.rc[i] = fn(); });
+    return o.rc[i];
+}
+
 template <class T, int KT>
 static int launch_q32_kt(const CoarseArgs& a, int num_cu, int device, hipStream_t st) {
     constexpr int lds = q32_lds<KT>();
-    static bool attr_set_dev[64] = {};
-    if (!attr_set_dev[device & 63]) {
+    static DevOnce once;
+    KR_TRY(once_per_device(once, device, [&]() -> int {
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse_q32<T, true, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse_q32<T, false, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set_dev[device & 63] = true;
-    }
+        return 0;
+    }));
     if (a.direct) hipLaunchKernelGGL((k_coarse_q32<T, true, KT>), dim3(num_cu), dim3(Q32_THREADS), lds, st, a);
     else hipLaunchKernelGGL((k_coarse_q32<T, false, KT>), dim3(num_cu), dim3(Q32_THREADS), lds, st, a);
     return 0;
@@ -740,102 +946,135 @@ static int launch_q32(const CoarseArgs& a, int kt64, int num_cu, int device, hip
     return fail(KR_EINVAL, "no k_coarse_q32 instance for dpad/64 = %d", kt64);
 }
 
+// over-fetch K1 and buffer capacity for top-k: K1 = pow2 >= 2.5 k while that is <= 512 (k <= 204), then pow2 >= 1.25 k (k <= 1638 > the k limit);
+// cap = min(16 K1, 8192) candidates per query (k_select / k_rerank keep the buffer in LDS).  The round growth factor follows from cap / K1.
+static void plan_buffers(int k, int& K1, int& cap, int& rmax) {
+    K1 = std::max(64, next_pow2((5 * k + 1) / 2));
+    if (K1 > 512) K1 = std::max(1024, next_pow2((5 * k + 3) / 4));
+    cap = std::min(16 * K1, 8192);
+    rmax = cap >= 8192 ? 8192 : RERANK_MAX;          // candidates the certified re-rank can take (LDS: cap + rmax keys)
+}
+
+// One filter / select pipeline over queries [0, nq) of the workspace arrays (thr, cnt, flags, cand): `launch(a)` runs one scan round over the
+// tile slots [a.tile_begin, a.tile_begin + a.tile_count) (slot = bm rows), k_select tightens the thresholds between rounds.
+// Round schedule (any thresholds are SAFE: the certificate in k_rerank decides exactness; the schedule only sets speed):
+//   round 0: cap rows, every score stored (direct slots);  growth rounds: g x the rows seen (g = cap / (2 K1) - 1: expected survivors cap / 2),
+//   thr = K1-th best; as soon as rows_seen * (cap / 64) >= rows_left the rest is ONE final round whose threshold is the r-th best seen with
+//   r = (cap/2) * seen / left  (expected cap/2 survivors), 32 <= r <= K1.
+template <class Launch>
+static int run_rounds(Index* ix, CoarseArgs& a, int nq, int bm, int K1, int cap, hipStream_t st, bool timed, Launch&& launch, int& final_preset, int& rounds) {
+    a.ntiles = (ix->n + bm - 1) / bm;
+    // interleaving permutation: multiplier near ntiles / golden ratio, coprime to ntiles
+    int64_t mul = std::max<int64_t>(1, (int64_t)((double)a.ntiles * 0.6180339887498949));
+    while (gcd64(mul, a.ntiles) != 1) ++mul;
+    a.perm_mul = mul % a.ntiles; if (a.perm_mul == 0) a.perm_mul = 1;
+    const size_t sel_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int);
+    const int64_t growth = std::max(1, cap / (2 * K1) - 1);
+    int64_t done = 0;
+    int64_t step = std::max<int64_t>(1, cap / bm);
+    int round = 0;
+    final_preset = 0;
+    a.direct = 1;
+    while (done < a.ntiles) {
+        const int64_t cnt_t = std::min<int64_t>(step, a.ntiles - done);
+        a.tile_begin = done; a.tile_count = cnt_t;
+        if (timed && round < 16) KR_HIP(hipEventRecord(ix->evc[2 * round], st));
+        KR_TRY(launch(a));
+        if (timed && round < 16) KR_HIP(hipEventRecord(ix->evc[2 * round + 1], st));
+        const int preset = a.direct ? (int)(cnt_t * bm) : 0;
+        ++round;
+        done += cnt_t;
+        a.direct = 0;
+        if (done >= a.ntiles) { final_preset = preset; break; }   // last round: k_rerank reads the buffer as it is; thr stays
+        const int64_t seen = done * bm, left = ix->n - seen;
+        int rank = K1;
+        // final round only once the rank it needs is >= 32 WITHOUT clamping: (cap/2) * seen / left >= 32.  (With a fixed "seen * 64 >= left" the
+        // small buffer of k <= 25 (cap = 1024) got rank 32 with up to 32 * 64 = 2048 expected survivors: overflow -> fallback.)
+        if (seen * std::max(1, cap / 64) >= left) {
+            step = a.ntiles - done;
+            rank = (int)std::min<int64_t>(K1, std::max<int64_t>(32, ((int64_t)(cap / 2) * seen + left - 1) / left));
+            rank = std::min(rank, K1);
+        } else {
+            step = done * growth;
+        }
+        hipLaunchKernelGGL(k_select, dim3(nq), dim3(256), sel_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, K1, rank, preset);
+    }
+    rounds = round;
+    return 0;
+}
+
+static int launch_rerank(Index* ix, int nq, int k, int rmax, int final_preset, const float* qf, const int* qmap, hipStream_t st) {
+    const size_t rer_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + (size_t)rmax * sizeof(uint64_t) + 264 * sizeof(unsigned int);
+    auto rerank = ix->d <= 1024 ? &k_rerank<4> : ix->d <= 2048 ? &k_rerank<8> : &k_rerank<16>;   // row steps held in registers
+    hipLaunchKernelGGL(rerank, dim3(nq), dim3(256), rer_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, ix->eps, qf, ix->xf, ix->d, k,
+                       final_preset, rmax, ix->out_s, ix->out_r, ix->nrer, qmap, ix->force_exact);
+    KR_HIP(hipGetLastError());
+    return 0;
+}
+
 template <class T>
 static int search_block(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int mode, hipStream_t st) {
     const bool smallq = nq <= ShapeSplit::BN;             // one 128-query tile: HBM-bound scan on the producer / consumer loop
     const int kt64 = ix->dpad / 64;
     const bool q32 = nq <= 32 && (kt64 == 16 || kt64 == 12 || kt64 == 8 || kt64 == 6) && !getenv("KIRAG_AMD_NO_Q32");   // register-resident queries, pure stream
     const int nq_pad = q32 ? 32 : (int)round_up(nq, smallq ? ShapeSplit::BN : ShapeC::BN);   // <= QBLK = 1024 = 4 x 256
-    // over-fetch K1 and buffer capacity: K1 = max(64, pow2 >= 2.5 k); cap = 16 K1; growth 8x per round
-    int K1 = std::max(64, next_pow2((5 * k + 1) / 2));
-    int cap = 16 * K1;
-    const bool fast_ok = (cap <= 8192) && mode == 0;
-    if (!fast_ok) { K1 = 64; cap = 1024; }
+    int K1, cap, rmax;
+    plan_buffers(k, K1, cap, rmax);
+    const bool coarse_pass = mode == 0;                   // mode 1: exact scan only; mode 2: high-precision pass only (test hooks)
+    const bool fine_ok = mode != 1 && ix->d <= FINE_DMAX && !getenv("KIRAG_AMD_NO_FINE");
     KR_TRY(ensure_ws(ix, k, cap));
+    static DevOnce sel_once;
+    KR_TRY(once_per_device(sel_once, ix->device, [&]() -> int {   // cap = 8192 needs 64 KiB + of dynamic LDS
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 8192 * 8 + 264 * 4));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 8192 * 8 + 264 * 4));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 8192 * 8 + 264 * 4));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        return 0;
+    }));
     KR_HIP(hipMemcpyAsync(ix->q_f, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyDefault, st));
     KR_HIP(hipEventRecord(ix->ev[0], st));
     std::vector<uint32_t> hflags(nq, 2u);
     double coarse_ms = 0.0;
-    if (fast_ok) {
+    CoarseArgs a{};
+    a.xc = ix->xc; a.n = ix->n; a.dpad = ix->dpad; a.qc = ix->q_c;
+    a.thr = ix->thr; a.cnt = ix->cnt; a.flags = ix->flags; a.cand = ix->cand; a.cand_cap = ix->cand_cap;
+    a.blk_list = ix->blk_list; a.blk_cnt = ix->blk_cnt; a.list_overflow = ix->blk_cnt + ix->num_cu * ShapeC::NWAVE;
+    a.xf = ix->xf; a.d = ix->d;
+    const size_t blk_cnt_bytes = ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int);
+    // ---- pass 1: 16-bit MFMA scan + certified re-rank, all queries -----------------------------------------------------------------------
+    if (coarse_pass) {
         hipLaunchKernelGGL(k_prep_queries<T>, dim3(nq_pad), dim3(64), 0, st, ix->q_f, ix->q_c, nq, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr,
                            ix->cnt, ix->flags);
-        CoarseArgs a;
-        a.xc = ix->xc; a.n = ix->n; a.dpad = ix->dpad; a.qc = ix->q_c; a.nq_pad = nq_pad; a.nq = nq;
-        a.thr = ix->thr; a.cnt = ix->cnt; a.flags = ix->flags; a.cand = ix->cand; a.cand_cap = ix->cand_cap;
-        a.blk_list = ix->blk_list; a.blk_cnt = ix->blk_cnt; a.list_overflow = ix->blk_cnt + ix->num_cu * ShapeC::NWAVE;
-        KR_HIP(hipMemsetAsync(ix->blk_cnt, 0, ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int), st));
+        a.nq_pad = nq_pad; a.nq = nq;
+        KR_HIP(hipMemsetAsync(ix->blk_cnt, 0, blk_cnt_bytes, st));
         const int bm = q32 ? 32 : smallq ? ShapeSplit::BM : ShapeC::BM;
-        a.ntiles = (ix->n + bm - 1) / bm;
-        // interleaving permutation: multiplier near ntiles / golden ratio, coprime to ntiles
-        int64_t mul = std::max<int64_t>(1, (int64_t)((double)a.ntiles * 0.6180339887498949));
-        while (gcd64(mul, a.ntiles) != 1) ++mul;
-        a.perm_mul = mul % a.ntiles; if (a.perm_mul == 0) a.perm_mul = 1;
         const int lds = smallq ? COARSE_LDS_SMALLQ : COARSE_LDS;
-        static bool attr_set_dev[64] = {};   // per device: function attributes belong to the device's code object instance
-        bool& attr_set = attr_set_dev[ix->device & 63];
-        if (!attr_set) {
+        static DevOnce coarse_once;
+        KR_TRY(once_per_device(coarse_once, ix->device, [&]() -> int {
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
-            attr_set = true;
-        }
-        const size_t sel_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int);
-        const size_t rer_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + (size_t)RERANK_MAX * sizeof(uint64_t) + 264 * sizeof(unsigned int);
-        static bool sel_attr_set_dev[64] = {};
-        bool& sel_attr_set = sel_attr_set_dev[ix->device & 63];
-        if (!sel_attr_set) {   // cap = 8192 needs 64 KiB + 16 B of dynamic LDS
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + RERANK_MAX * 8 + 264 * 4));
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + RERANK_MAX * 8 + 264 * 4));
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + RERANK_MAX * 8 + 264 * 4));
-            sel_attr_set = true;
-        }
-        // Round schedule (any thresholds are SAFE: the certificate in k_rerank decides exactness; the schedule only sets speed):
-        //   round 0: cap rows, every score stored (direct slots);  growth rounds: 7x the rows seen, thr = K1-th best;
-        //   as soon as rows_seen * (cap / 64) >= rows_left the rest is ONE final round whose threshold is the r-th best seen with
-        //   r = (cap/2) * seen / left  (expected cap/2 survivors), 32 <= r <= K1.
-        int64_t done = 0;
-        int64_t step = std::max<int64_t>(1, cap / bm);
-        int round = 0, final_preset = 0;
-        a.direct = 1;
-        while (done < a.ntiles) {
-            const int64_t cnt_t = std::min<int64_t>(step, a.ntiles - done);
-            a.tile_begin = done; a.tile_count = cnt_t;
-            if (round < 16) KR_HIP(hipEventRecord(ix->evc[2 * round], st));
-            if (q32) {
-                KR_TRY((launch_q32<T>(a, kt64, ix->num_cu, ix->device, st)));
-            } else if (smallq) {
-                if (a.direct) hipLaunchKernelGGL((k_coarse<T, true, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
-                else hipLaunchKernelGGL((k_coarse<T, false, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
-            } else if (a.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
-            else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, a);
-            if (round < 16) KR_HIP(hipEventRecord(ix->evc[2 * round + 1], st));
-            const int preset = a.direct ? (int)(cnt_t * bm) : 0;
-            ++round;
-            done += cnt_t;
-            a.direct = 0;
-            ix->st.coarse_rounds++;
-            if (done >= a.ntiles) { final_preset = preset; break; }   // last round: k_rerank reads the buffer as it is; thr stays
-            const int64_t seen = done * bm, left = ix->n - seen;
-            int rank = K1;
-            // final round only once the rank it needs is >= 32 WITHOUT clamping: (cap/2) * seen / left >= 32.  (With a fixed "seen * 64 >= left" the
-            // small buffer of k <= 25 (cap = 1024) got rank 32 with up to 32 * 64 = 2048 expected survivors: overflow -> exact-scan fallback.)
-            if (seen * std::max(1, cap / 64) >= left) {
-                step = a.ntiles - done;
-                rank = (int)std::min<int64_t>(K1, std::max<int64_t>(32, ((int64_t)(cap / 2) * seen + left - 1) / left));
-                rank = std::min(rank, K1);
-            } else {
-                step = done * 7;
-            }
-            hipLaunchKernelGGL(k_select, dim3(nq), dim3(256), sel_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, K1, rank, preset);
-        }
-        auto rerank = ix->d <= 1024 ? &k_rerank<4> : ix->d <= 2048 ? &k_rerank<8> : &k_rerank<16>;   // row steps held in registers
-        hipLaunchKernelGGL(rerank, dim3(nq), dim3(256), rer_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags,
-                           ix->thr, ix->eps, ix->q_f, ix->xf, ix->d, k, final_preset, ix->out_s, ix->out_r, ix->nrer);
-        KR_HIP(hipGetLastError());
+            return 0;
+        }));
+        int final_preset = 0, rounds = 0;
+        KR_TRY(run_rounds(ix, a, nq, bm, K1, cap, st, true, [&](const CoarseArgs& ca) -> int {
+            if (q32) return launch_q32<T>(ca, kt64, ix->num_cu, ix->device, st);
+            if (smallq) {
+                if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+                else hipLaunchKernelGGL((k_coarse<T, false, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+            } else if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+            else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+            return 0;
+        }, final_preset, rounds));
+        ix->st.coarse_rounds += rounds;
+        KR_TRY(launch_rerank(ix, nq, k, rmax, final_preset, ix->q_f, nullptr, st));
         // one round trip: status words into pinned memory and (optimistically) the results into the caller's buffers, ONE stream sync;
-        // only if a query was flagged does the exact scan run and overwrite its rows
+        // only if a query was flagged do the further passes run and overwrite its rows
         KR_HIP(hipMemcpyAsync(ix->h_status, ix->flags, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         KR_HIP(hipMemcpyAsync(ix->h_status + QBLK, ix->nrer, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         KR_HIP(hipMemcpyAsync(ix->h_status + 2 * QBLK, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
@@ -843,20 +1082,73 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
         KR_HIP(hipEventRecord(ix->ev[3], st));
         KR_HIP(hipStreamSynchronize(st));
-        const bool list_ovf = ix->h_status[2 * QBLK] != 0u;   // a block list overflowed (sticky for the call): every query goes to the exact scan
+        const bool list_ovf = ix->h_status[2 * QBLK] != 0u;   // a block list overflowed (sticky for the call): every query goes on to the next pass
         for (int i = 0; i < nq; ++i) { hflags[i] = ix->h_status[i] | (list_ovf ? 1u : 0u); ix->st.reranked_rows += ix->h_status[QBLK + i]; }
-        for (int r = 0; r < round && r < 16; ++r) {
+        for (int r = 0; r < rounds && r < 16; ++r) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ix->evc[2 * r], ix->evc[2 * r + 1]) == hipSuccess) coarse_ms += ms;
         }
     }
     std::vector<int> fl;
     for (int i = 0; i < nq; ++i) {
-        if (hflags[i]) { fl.push_back(i); if (hflags[i] & 1u) ix->st.overflow++; }
+        if (hflags[i]) { fl.push_back(i); if (coarse_pass && (hflags[i] & 1u)) ix->st.overflow++; }
     }
-    if (!fl.empty() || !fast_ok) {
+    const int64_t n_flagged = (int64_t)fl.size();
+    // ---- pass 2: fp64 MFMA scan of the fp32 master rows for the flagged queries, in groups that share one pass over the corpus -------------------
+    std::vector<int> fl3;
+    if (!fl.empty() && fine_ok) {
+        const int gmax = ix->d <= 1024 ? FINE_QMAX : 16;
         KR_HIP(hipMemcpyAsync(ix->ex_qidx, fl.data(), fl.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        KR_TRY(exact_scan(ix, (int)fl.size(), k, st));
+        KR_HIP(hipEventRecord(ix->ev[1], st));
+        int ngroups = 0;
+        for (size_t g0 = 0; g0 < fl.size(); g0 += gmax, ++ngroups) {
+            const int g = (int)std::min<size_t>(gmax, fl.size() - g0);
+            const int nt = g <= 16 ? 1 : 2;
+            const int* qmap = ix->ex_qidx + g0;
+            hipLaunchKernelGGL(k_gather_rows, dim3(g), dim3(256), 0, st, ix->q_f, qmap, ix->q_f2, ix->d);
+            hipLaunchKernelGGL(k_prep_fine<0>, dim3(16 * nt), dim3(64), 0, st, ix->q_f2, g, ix->d, ix->bounds, ix->eps, ix->thr, ix->cnt, ix->flags);
+            KR_HIP(hipMemsetAsync(ix->blk_cnt, 0, blk_cnt_bytes, st));
+            a.nq_pad = 16 * nt; a.nq = g; a.qf = ix->q_f2;
+            const int lds = fine_lds_bytes(ix->d, 16 * nt);
+            int final_preset = 0, rounds = 0;
+            KR_TRY(run_rounds(ix, a, g, 32, K1, cap, st, false, [&](const CoarseArgs& ca) -> int {
+                if (nt == 1) {
+                    if (ca.direct) hipLaunchKernelGGL((k_fine<true, 1>), dim3(ix->num_cu), dim3(FINE_THREADS), lds, st, ca);
+                    else hipLaunchKernelGGL((k_fine<false, 1>), dim3(ix->num_cu), dim3(FINE_THREADS), lds, st, ca);
+                } else {
+                    if (ca.direct) hipLaunchKernelGGL((k_fine<true, 2>), dim3(ix->num_cu), dim3(FINE_THREADS), lds, st, ca);
+                    else hipLaunchKernelGGL((k_fine<false, 2>), dim3(ix->num_cu), dim3(FINE_THREADS), lds, st, ca);
+                }
+                return 0;
+            }, final_preset, rounds));
+            ix->st.fine_rounds += rounds;
+            KR_TRY(launch_rerank(ix, g, k, rmax, final_preset, ix->q_f2, qmap, st));
+            uint32_t* hs = ix->h_status + 2 * QBLK + 4;
+            KR_HIP(hipMemcpyAsync(hs + g0, ix->flags, g * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            KR_HIP(hipMemcpyAsync(hs + QBLK + g0, ix->nrer, g * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            KR_HIP(hipMemcpyAsync(hs + 2 * QBLK + ngroups, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        }
+        KR_HIP(hipEventRecord(ix->ev[2], st));
+        KR_HIP(hipStreamSynchronize(st));
+        const uint32_t* hs = ix->h_status + 2 * QBLK + 4;
+        for (size_t j = 0; j < fl.size(); ++j) {
+            const bool ovf = hs[2 * QBLK + j / gmax] != 0u;
+            ix->st.reranked_rows += hs[QBLK + j];
+            if (hs[j] || ovf) fl3.push_back(fl[j]);
+        }
+        float fms = 0.f;
+        if (hipEventElapsedTime(&fms, ix->ev[1], ix->ev[2]) == hipSuccess) ix->st.last_fine_ms += fms;
+        ix->st.fine += (int64_t)fl.size() - (int64_t)fl3.size();
+    } else {
+        fl3 = fl;
+    }
+    // ---- pass 3: exact scan, one query at a time (mass ties beyond the re-rank capacity, NaN shortages, d > FINE_DMAX, mode 1) -----------------------
+    if (!fl3.empty()) {
+        KR_HIP(hipMemcpyAsync(ix->ex_qidx, fl3.data(), fl3.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        KR_TRY(exact_scan(ix, (int)fl3.size(), k, st));
+        ix->st.exact += (int64_t)fl3.size();
+    }
+    if (!fl.empty()) {
         KR_HIP(hipMemcpyAsync(scores, ix->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
         KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
         KR_HIP(hipEventRecord(ix->ev[3], st));
@@ -866,8 +1158,8 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
     if (hipEventElapsedTime(&tot, ix->ev[0], ix->ev[3]) == hipSuccess) ix->st.last_total_ms += tot;
     ix->st.last_coarse_ms += coarse_ms;
     ix->st.queries += nq;
-    ix->st.fallback += (int64_t)fl.size();
-    ix->st.certified += nq - (int64_t)fl.size();
+    ix->st.fallback += n_flagged;
+    ix->st.certified += nq - n_flagged;
     return 0;
 }
 
@@ -918,6 +1210,10 @@ __global__ __launch_bounds__(256) void k_merge_lists(const float* __restrict__ s
     for (int j = valid + tid; j < k; j += 256) { out_s[(int64_t)q * k + j] = -INFINITY; out_i[(int64_t)q * k + j] = -1; }
 }
 
+struct Scratch { Index* w = nullptr; size_t cap_x = 0, cap_q = 0, cap_i = 0, cap_s = 0, cap_r = 0; int iota_filled = 0; };
+static Scratch g_scratch[64];
+static std::mutex g_scratch_mu;
+
 }  // namespace kr
 
 using namespace kr;
@@ -945,7 +1241,7 @@ void kr_index_destroy(kr_index* h) {
     if (!h) return;
     Index* ix = reinterpret_cast<Index*>(h);
     (void)hipSetDevice(ix->device);
-    void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
+    void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_f2, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
                     ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ix->h_status) (void)hipHostFree(ix->h_status);
@@ -1010,11 +1306,12 @@ int kr_index_search(kr_index* h, const float* q, int nq, int k, float* scores, i
     if (nq < 0 || (nq > 0 && (!q || !scores || !rows))) return fail(KR_EINVAL, "bad query/output pointers");
     if (k <= 0 || (int64_t)k > ix->n) return fail(KR_EINVAL, "k=%d must satisfy 0 < k <= ntotal=%lld", k, (long long)ix->n);
     if (k > EXACT_RC) return fail(KR_EINVAL, "k=%d exceeds the supported maximum of %d", k, EXACT_RC);
-    if (mode != 0 && mode != 1) return fail(KR_EINVAL, "mode must be 0 (auto) or 1 (exact scan)");
+    if (mode < 0 || mode > 2) return fail(KR_EINVAL, "mode must be 0 (auto), 1 (exact scan only) or 2 (high-precision pass only)");
     if (nq == 0) return 0;
     KR_TRY(select_device(ix->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    ix->st.last_coarse_ms = 0.0; ix->st.last_total_ms = 0.0;
+    ix->force_exact = g_force_exact.load();
+    ix->st.last_coarse_ms = 0.0; ix->st.last_total_ms = 0.0; ix->st.last_fine_ms = 0.0;
     for (int b = 0; b < nq; b += QBLK) {
         const int nb = std::min(QBLK, nq - b);
         int rc;
@@ -1035,10 +1332,14 @@ int kr_score_topk(const float* q, int nq, const float* x, int64_t n, int d, int 
     if (k <= 0 || (int64_t)k > n || k > EXACT_RC) return fail(KR_EINVAL, "k=%d must satisfy 0 < k <= min(n=%lld, %d)", k, (long long)n, EXACT_RC);
     KR_TRY(select_device(device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static thread_local Index* scratch[64] = {};
     if (device < 0 || device >= 64) return fail(KR_EINVAL, "device %d out of range", device);
-    Index*& w = scratch[device];
-    if (!w) { w = new Index(); w->device = device; }
+    // per-device scratch shared by all host threads (calls are serialised by the mutex; the buffers persist between calls and are
+    // freed by kr_release_scratch())
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    Scratch& sc = g_scratch[device];
+    if (!sc.w) { sc.w = new Index(); sc.w->device = device; }
+    Index* w = sc.w;
+    w->force_exact = g_force_exact.load();
     auto regrow = [](auto*& p, size_t& have, size_t need) -> int {
         if (need <= have) return 0;
         if (p) (void)hipFree(p);
@@ -1047,29 +1348,41 @@ int kr_score_topk(const float* q, int nq, const float* x, int64_t n, int d, int 
         have = need;
         return 0;
     };
-    static thread_local size_t cap_x[64] = {}, cap_q[64] = {}, cap_i[64] = {}, cap_s[64] = {}, cap_r[64] = {};
-    KR_TRY(regrow(w->xf, cap_x[device], (size_t)n * d * sizeof(float)));
-    KR_TRY(regrow(w->q_f, cap_q[device], (size_t)nq * d * sizeof(float)));
-    KR_TRY(regrow(w->ex_qidx, cap_i[device], (size_t)nq * sizeof(int)));
-    KR_TRY(regrow(w->out_s, cap_s[device], (size_t)nq * k * sizeof(float)));
-    KR_TRY(regrow(w->out_r, cap_r[device], (size_t)nq * k * sizeof(int64_t)));
+    KR_TRY(regrow(w->xf, sc.cap_x, (size_t)n * d * sizeof(float)));
+    KR_TRY(regrow(w->q_f, sc.cap_q, (size_t)nq * d * sizeof(float)));
+    KR_TRY(regrow(w->ex_qidx, sc.cap_i, (size_t)nq * sizeof(int)));
+    KR_TRY(regrow(w->out_s, sc.cap_s, (size_t)nq * k * sizeof(float)));
+    KR_TRY(regrow(w->out_r, sc.cap_r, (size_t)nq * k * sizeof(int64_t)));
     w->d = d; w->n = n;
     KR_HIP(hipMemcpyAsync(w->xf, x, (size_t)n * d * sizeof(float), hipMemcpyDefault, st));
     KR_HIP(hipMemcpyAsync(w->q_f, q, (size_t)nq * d * sizeof(float), hipMemcpyDefault, st));
-    static thread_local int iota_filled[64] = {};      // ex_qidx[i] = i is written once per (re)allocation, not per call (it cost a stream sync)
-    if (cap_i[device] != (size_t)iota_filled[device] * sizeof(int) || iota_filled[device] < nq) {
-        const int cnt = (int)(cap_i[device] / sizeof(int));
+    if (sc.cap_i != (size_t)sc.iota_filled * sizeof(int) || sc.iota_filled < nq) {   // ex_qidx[i] = i is written once per (re)allocation, not per call
+        const int cnt = (int)(sc.cap_i / sizeof(int));
         std::vector<int> iota(cnt);
         for (int i = 0; i < cnt; ++i) iota[i] = i;
         KR_HIP(hipMemcpyAsync(w->ex_qidx, iota.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, st));
         KR_HIP(hipStreamSynchronize(st));   // iota is a heap host buffer
-        iota_filled[device] = cnt;
+        sc.iota_filled = cnt;
     }
     KR_TRY(exact_scan(w, nq, k, st));
     KR_HIP(hipMemcpyAsync(scores, w->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
     KR_HIP(hipMemcpyAsync(rows, w->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
     KR_HIP(hipStreamSynchronize(st));
     return 0;
+}
+
+void kr_release_scratch(void) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (int dev = 0; dev < 64; ++dev) {
+        Scratch& sc = g_scratch[dev];
+        if (!sc.w) continue;
+        if (hipSetDevice(dev) == hipSuccess) {
+            void* ptrs[] = {sc.w->xf, sc.w->q_f, sc.w->ex_qidx, sc.w->out_s, sc.w->out_r, sc.w->ex_a, sc.w->ex_b};
+            for (void* p : ptrs) if (p) (void)hipFree(p);
+        }
+        delete sc.w;
+        sc = Scratch{};
+    }
 }
 
 int kr_index_stats(kr_index* h, kr_search_stats* out, int reset) {
@@ -1121,11 +1434,11 @@ int kr_topk_merge_device(const float* scores, int64_t score_shard_stride, const 
     if (device < 0 || device >= 64) return fail(KR_EINVAL, "device %d out of range", device);
     if (nq == 0) return 0;
     KR_TRY(select_device(device));
-    static bool attr_set_dev[64] = {};
-    if (!attr_set_dev[device]) {
+    static DevOnce once;
+    KR_TRY(once_per_device(once, device, [&]() -> int {
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_lists), hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_MAX * 12));
-        attr_set_dev[device] = true;
-    }
+        return 0;
+    }));
     hipLaunchKernelGGL(k_merge_lists, dim3((unsigned)nq), dim3(256), (size_t)nshards * k * 12, reinterpret_cast<hipStream_t>(stream), scores, score_shard_stride,
                        ids, id_shard_stride, nshards, k, out_scores, out_ids);
     KR_HIP(hipGetLastError());

@@ -5,10 +5,12 @@ Restates ``retriever/index.py`` (``Indexer.index_data`` :26-34, ``search_knn`` :
 reference lives in faiss-cpu==1.8.0.post1 ``IndexFlatIP`` (not vendored, not installable here):
 **parity with faiss is unpinned**; semantics restated from its published behaviour.
 
-Three scorers:
-  * ``search_canonical``  — ctypes call into ``search_c.c``: the canonical, bit-reproducible score
-    (fp64 accumulation in a fixed order, rounded once to fp32) and the tie rule
-    (score desc, internal row asc).  This is what the HIP path must match bit for bit.
+Scorers:
+  * ``search_canonical``  — ctypes call into ``search_c.c``: the canonical score = the EXACT inner product of
+    the fp32 inputs rounded once to fp32 (round-to-nearest-even) — a definition that does not depend on any
+    summation order — and the tie rule (score desc, internal row asc).  This is what the HIP path must match
+    bit for bit.  ``dot_exact`` (super-accumulator) and ``dot_fraction`` (Python rationals) are the two
+    independent formulations the C fast path is pinned against.
   * ``search_f64``        — numpy fp64 GEMM, rounded to fp32, same tie rule.  Equal to the canonical
     result except when an fp64 sum lands within ~1e-13 relative of an fp32 rounding boundary; used
     for sizes where the scalar C loop is too slow.
@@ -39,8 +41,11 @@ def lib():
     global _LIB
     if _LIB is None:
         L = ctypes.CDLL(build())
-        L.kr_oracle_dot.restype = ctypes.c_double
-        L.kr_oracle_dot.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        for nm in ("kr_oracle_dot", "kr_oracle_dot_exact", "kr_oracle_dot_f32"):
+            getattr(L, nm).restype = ctypes.c_float
+            getattr(L, nm).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.kr_oracle_scores_all.restype = None
+        L.kr_oracle_scores_all.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.kr_oracle_search.restype = ctypes.c_int
         L.kr_oracle_search.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -63,9 +68,62 @@ def search_canonical(q: np.ndarray, x: np.ndarray, k: int) -> Tuple[np.ndarray, 
     n = x.shape[0]
     s = np.empty((nq, k), np.float32); i = np.empty((nq, k), np.int64)
     rc = lib().kr_oracle_search(q.ctypes.data, nq, x.ctypes.data, n, d, k, s.ctypes.data, i.ctypes.data)
+    if rc == -2:
+        raise ValueError(f"fewer than k={k} rows have a real (non-NaN) score")
     if rc != 0:
         raise ValueError(f"k={k} must satisfy 0 < k <= ntotal={n}")
     return s, i
+
+
+def dot(q: np.ndarray, x: np.ndarray, which: str = "canonical") -> float:
+    """One inner product by ``which`` in {"canonical" (sequential fp64 + certified rounding), "exact" (super-accumulator), "f32" (fp32 loop)}."""
+    q = _c(q, np.float32); x = _c(x, np.float32)
+    fn = {"canonical": lib().kr_oracle_dot, "exact": lib().kr_oracle_dot_exact, "f32": lib().kr_oracle_dot_f32}[which]
+    return float(np.float32(fn(q.ctypes.data, x.ctypes.data, int(q.shape[0]))))
+
+
+def scores_all(q: np.ndarray, x: np.ndarray, which: str = "canonical") -> np.ndarray:
+    """All-pairs scores [nq, n] by one of the three C formulations (see ``dot``)."""
+    q = _c(q, np.float32); x = _c(x, np.float32)
+    out = np.empty((q.shape[0], x.shape[0]), np.float32)
+    lib().kr_oracle_scores_all(q.ctypes.data, q.shape[0], x.ctypes.data, x.shape[0], q.shape[1],
+                               {"canonical": 0, "exact": 1, "f32": 2}[which], out.ctypes.data)
+    return out
+
+
+def dot_fraction(q: np.ndarray, x: np.ndarray) -> np.float32:
+    """Third, fully independent formulation: the inner product in Python rationals (exact), then ONE round-to-nearest-even
+    to fp32 done on integers.  Slow (pure Python): small cases and the golden vectors only."""
+    from fractions import Fraction
+    tot = Fraction(0)
+    for a, b in zip(np.asarray(q, np.float32).tolist(), np.asarray(x, np.float32).tolist()):
+        tot += Fraction(a) * Fraction(b)                 # Fraction(float) is exact
+    return round_fraction_to_f32(tot)
+
+
+def round_fraction_to_f32(v) -> np.float32:
+    """RN-even of a rational to fp32 (normal, subnormal, overflow to inf, signed zero for tiny non-zero values)."""
+    from fractions import Fraction
+    if v == 0:
+        return np.float32(0.0)
+    neg = v < 0
+    a = -v if neg else v
+    # exponent e with 2^e <= a < 2^(e+1)
+    e = a.numerator.bit_length() - a.denominator.bit_length()
+    if Fraction(2) ** e > a:
+        e -= 1
+    elif Fraction(2) ** (e + 1) <= a:
+        e += 1
+    qexp = max(e - 23, -149)                             # exponent of the fp32 quantum
+    scaled = a / (Fraction(2) ** qexp)
+    m = scaled.numerator // scaled.denominator
+    rem = scaled - m
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (m & 1)):
+        m += 1
+    val = np.float64(m) * np.float64(2.0) ** qexp if qexp > -1000 else 0.0     # m <= 2^24: exact in fp64
+    with np.errstate(over="ignore"):
+        f = np.float32(val)                              # exact (m * 2^qexp is representable) or inf on overflow
+    return np.float32(-f) if neg else f
 
 
 def scores_at(q: np.ndarray, x: np.ndarray, rows: np.ndarray) -> np.ndarray:

@@ -1,9 +1,16 @@
 """GPU parity tests of the index path (through the C ABI, via kirag_amd.retriever.index) against the oracle.
-Bar: internal rows identical and scores bit-identical to oracle.search_np.search_canonical."""
+Bar: internal rows identical and scores bit-identical to oracle.search_np.search_canonical (the exact inner product rounded once to fp32);
+at BASELINE sizes membership is checked against a kernel-independent fp32 sgemm + top-k (tests/indep_check.py)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 from oracle import search_np as S
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import indep_check as IC  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -135,7 +142,8 @@ def test_dense_cluster_forces_exact_fallback():
     s, i = ix.index.search(q, 50)
     so, io = S.search_canonical(q, x, 50)
     assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
-    assert ix.index.stats()["fallback"] > 0
+    st = ix.index.stats()
+    assert st["fallback"] > 0 and st["fine"] == st["fallback"] and st["exact"] == 0, st      # the fp64 pass certifies what bf16 cannot
 
 
 def test_nan_rows_are_never_returned():
@@ -221,45 +229,6 @@ def test_serialize_roundtrip(tmp_path):
     assert all(a[r][0] == b[r][0] and np.array_equal(a[r][1], b[r][1]) for r in range(3))
 
 
-def test_full_size_config2_properties():
-    """BASELINE config 2: 1M x 1024, 1000 queries, top-100 — size-independent properties + on-device exact cross-check."""
-    import torch
-    g = torch.Generator(device="cuda"); g.manual_seed(3)
-    n, d, nq, k = 1_000_000, 1024, 1000, 100
-    x = torch.randn(n, d, generator=g, device="cuda", dtype=torch.float32)
-    x = torch.nn.functional.normalize(x, dim=1)
-    pick = torch.randint(0, n, (nq,), generator=g, device="cuda")
-    q = torch.nn.functional.normalize(x[pick] + 0.05 * torch.randn(nq, d, generator=g, device="cuda"), dim=1)
-    from kirag_amd.retriever.index import FlatIPIndex
-    ix = FlatIPIndex(d); ix.reserve(n)
-    for s0 in range(0, n, 250_000):
-        ix.add(x[s0:s0 + 250_000])
-    s, i = ix.search(q, k)
-    assert np.array_equal(i[:, 0], pick.cpu().numpy())                 # planted neighbour first
-    assert (np.diff(s, axis=1) <= 0).all()                               # descending
-    assert all(len(set(r)) == k for r in i.tolist())                     # no duplicate rows
-    st = ix.stats()
-    assert st["certified"] >= 0.99 * nq, st
-    # exact full scan of a few queries on the device must agree bit for bit
-    s1, i1 = ix.search(q[:6], k, mode=1)
-    assert np.array_equal(i1, i[:6]) and np.array_equal(s1, s[:6])
-    # scores equal the canonical score of the returned rows (C oracle on gathered rows)
-    rows = torch.from_numpy(i[:4]).cuda()
-    xs = x[rows.reshape(-1)].cpu().numpy()
-    sc = S.scores_at(q[:4].cpu().numpy(), xs, (np.arange(4 * k).reshape(4, k)).astype(np.int64))
-    assert np.array_equal(sc, s[:4])
-    # shard-merge == unsharded (two 500k shards)
-    from kirag_amd import _lib
-    halves = []
-    for a, b in ((0, 500_000), (500_000, n)):
-        sh = FlatIPIndex(d); sh.reserve(b - a); sh.add(x[a:b])
-        s_, i_ = sh.search(q[:64], k); halves.append((s_, i_ + a)); del sh
-    sc2 = np.ascontiguousarray(np.stack([h[0] for h in halves])); ic2 = np.ascontiguousarray(np.stack([h[1] for h in halves]))
-    ms = np.empty((64, k), np.float32); mi = np.empty((64, k), np.int64)
-    _lib.check(_lib.load().kr_topk_merge(sc2.ctypes.data, ic2.ctypes.data, 2, 64, k, ms.ctypes.data, mi.ctypes.data))
-    assert np.array_equal(mi, i[:64]) and np.array_equal(ms, s[:64])
-
-
 def test_k_200_uses_large_candidate_buffers():
     """k > 102 switches to K1 = 512 / cap = 8192 (64 KiB + of dynamic LDS in k_select / k_rerank)."""
     rng = np.random.default_rng(21)
@@ -268,9 +237,14 @@ def test_k_200_uses_large_candidate_buffers():
     s, i = ix.index.search(q, 200)
     so, io = S.search_f64(q, x, 200)
     assert np.array_equal(i, io) and np.array_equal(s, so)
-    s, i = ix.index.search(q, 600)            # beyond the fast path: exact scan
-    so, io = S.search_f64(q, x, 600)
-    assert np.array_equal(i, io) and np.array_equal(s, so)
+    s, i = ix.index.search(q, 600)            # K1 = 1024, cap = 8192, doubling rounds
+    so, io = S.search_canonical(q, x, 600)
+    assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    s, i = ix.index.search(q, 1024)           # the largest k: K1 = 2048
+    so, io = S.search_canonical(q, x, 1024)
+    assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    st = ix.index.stats()
+    assert st["exact"] == 0, st               # round 1 sent every k > 204 to the per-query exact scan
 
 
 def test_seeded_random_shape_sweep_vs_canonical():
@@ -323,3 +297,241 @@ def test_many_rows_small_dim_tile_permutation_64bit():
     assert np.array_equal(s.view(np.uint32), so.view(np.uint32))
     assert np.array_equal(np.sort(i, axis=1), np.sort(pos, axis=1))
     assert st["certified"] == nq and st["fallback"] == 0 and st["coarse_rounds"] == 5
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# canonical score = exact inner product rounded once: known answers from Python rationals, and the rare exact path forced
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _score_topk1(q, x):
+    """one (q, x) pair through kr_score_topk (k_exact_scan): the canonical score as the library computes it"""
+    import ctypes as C
+    from kirag_amd import _lib
+    d = len(q); dp = max(4, (d + 3) // 4 * 4)
+    qq = np.zeros((1, dp), np.float32); xx = np.zeros((1, dp), np.float32)
+    qq[0, :d] = q; xx[0, :d] = x
+    sc = np.empty((1, 1), np.float32); rows = np.empty((1, 1), np.int64)
+    _lib.check(_lib.load().kr_score_topk(qq.ctypes.data, 1, xx.ctypes.data, 1, dp, 1, sc.ctypes.data, rows.ctypes.data, 0, None))
+    return sc[0, 0]
+
+
+@pytest.mark.parametrize("force", [0, 1])
+def test_canonical_score_golden_vectors_on_gpu(golden, force):
+    """tests/golden/g9_exact_dot.npz (351 known answers from Python rationals: exact midpoints, sticky bits, subnormal and vanishing results,
+    overflow to inf, cancellation, 120-bit exponent spreads) through the library's scoring kernel, with the certified fp64 fast path (force = 0)
+    and with every score sent through the integer super-accumulator (force = 1): every bit must match."""
+    from kirag_amd import _lib
+    lib = _lib.load()
+    g = golden("g9_exact_dot.npz")
+    off = g["offsets"]
+    _lib.check(lib.kr_set_option(b"force_exact_scores", force))
+    try:
+        for c in range(len(off) - 1):
+            q = g["q_bits"][off[c]:off[c + 1]].view(np.float32); x = g["x_bits"][off[c]:off[c + 1]].view(np.float32)
+            got = np.float32(_score_topk1(q, x)).view(np.uint32)
+            assert got == g["expected_bits"][c], (c, len(q), hex(int(got)), hex(int(g["expected_bits"][c])))
+    finally:
+        _lib.check(lib.kr_set_option(b"force_exact_scores", 0))
+    with pytest.raises(_lib.KiragAmdError):
+        _lib.check(lib.kr_set_option(b"no_such_option", 1))
+
+
+def test_forced_exact_path_equals_fast_path_in_search():
+    """Every re-rank / exact-scan score through the super-accumulator: same rows, same score bits as the fast path and as the oracle."""
+    from kirag_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(31)
+    x = _unit(rng, 6000, 1024); q, _ = _queries_near(rng, x, 20)
+    x2 = (_unit(rng, 3000, 100) * np.float32(37.5)).astype(np.float32); q2 = (_unit(rng, 7, 100) * np.float32(1e-3)).astype(np.float32)
+    for xx, qq, d, k in ((x, q, 1024, 100), (x2, q2, 100, 10)):
+        ix = _mk(d, xx)
+        s0, i0 = ix.index.search(qq, k)
+        so, io = S.search_canonical(qq, xx, k)
+        _lib.check(lib.kr_set_option(b"force_exact_scores", 1))
+        try:
+            s1, i1 = ix.index.search(qq, k)
+            s2, i2 = ix.index.search(qq[:3], k, mode=1)
+        finally:
+            _lib.check(lib.kr_set_option(b"force_exact_scores", 0))
+        for s_, i_ in ((s0, i0), (s1, i1)):
+            assert np.array_equal(i_, io) and np.array_equal(s_.view(np.uint32), so.view(np.uint32))
+        assert np.array_equal(i2, io[:3]) and np.array_equal(s2.view(np.uint32), so[:3].view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# pass 2 (fp64 MFMA scan of the fp32 rows for queries the 16-bit scan cannot certify) and pass 3 (exact scan)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,nq,k", [(1000, 64, 5, 10), (4097, 256, 17, 100), (20000, 1024, 33, 100), (70000, 1024, 16, 20), (9000, 100, 40, 204),
+                                      (50000, 2048, 9, 10), (33, 4, 3, 33), (30000, 768, 70, 300)])
+def test_fine_pass_only_vs_canonical(n, d, nq, k):
+    """mode = 2: no 16-bit scan, every query through the fp64 MFMA pass (groups of 32 / 16 queries, one and two 16-query tiles, several rounds,
+    a partial last 32-row slot, d not a multiple of 128), bit-exact vs the C oracle; nothing may need the per-query exact scan."""
+    rng = np.random.default_rng(n + d + nq)
+    x = _unit(rng, n, d)
+    if n > 100:
+        x[n - 3] = x[5]                                                # a duplicate row: tie broken by row number
+    q, _ = _queries_near(rng, x, nq)
+    ix = _mk(d, x)
+    s, i = ix.index.search(q, k, mode=2)
+    so, io = S.search_canonical(q, x, k)
+    assert np.array_equal(i, io), (n, d, nq, k)
+    assert np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    st = ix.index.stats()
+    assert st["fine"] == nq and st["exact"] == 0 and st["certified"] == 0, st
+
+
+def test_near_duplicate_corpus_all_queries_through_the_fine_pass():
+    """A corpus of near-duplicates (pairwise score differences ~1e-5, far below the bf16 bound but above the fp64 pass's): every query fails the
+    16-bit certificate; 300 flagged queries = 10 groups of 32 sharing one pass over the rows each; bit-exact vs the oracle."""
+    rng = np.random.default_rng(41)
+    base = _unit(rng, 1, 512)
+    x = base + 3e-5 * rng.standard_normal((40000, 512)).astype(np.float32)
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    q = (_unit(rng, 300, 512) * 0.3 + base)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    ix = _mk(512, x)
+    s, i = ix.index.search(q, 100)
+    so, io = S.search_canonical(q, x, 100)
+    assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    st = ix.index.stats()
+    print(f"[near-duplicates] {st}")
+    assert st["fallback"] >= 290 and st["fine"] == st["fallback"] and st["exact"] == 0, st
+
+
+def test_mass_exact_ties_reach_the_exact_scan():
+    """5000 identical rows: more exact ties at the k-th score than the certified re-rank can hold, for both passes -> pass 3 (exact scan);
+    ties come back in row order."""
+    rng = np.random.default_rng(42)
+    x = _unit(rng, 8000, 128)
+    x[1000:6000] = x[999]
+    q = x[[999, 7000]]
+    ix = _mk(128, x)
+    s, i = ix.index.search(q, 50)
+    so, io = S.search_canonical(q, x, 50)
+    assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    assert list(i[0]) == list(range(999, 1049))
+    st = ix.index.stats()
+    assert st["exact"] >= 1 and st["fine"] + st["exact"] == st["fallback"], st
+
+
+def test_fine_pass_top_1024_of_4096():
+    """k = 1024 (K1 = 2048, 8192-entry buffers, doubling rounds) through the fp64 MFMA pass: a quarter of the corpus returned in exact order."""
+    rng = np.random.default_rng(43)
+    x = _unit(rng, 4096, 1024); q = _unit(rng, 32, 1024)
+    ix = _mk(1024, x)
+    s, i = ix.index.search(q, 1024, mode=2)
+    so, io = S.search_canonical(q, x, 1024)
+    assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# BASELINE sizes: kernel-independent membership check (fp32 sgemm + torch.topk), Gaussian and e5like corpora
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _build_resident(n, d, kind, keep_chunks, chunk=250_000):
+    import torch
+    from kirag_amd.bench_support import CorpusDist
+    from kirag_amd.retriever.index import FlatIPIndex
+    dev = torch.device("cuda:0")
+    cd = CorpusDist(kind, d, dev)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    ix = FlatIPIndex(d, device=0); ix.reserve(n)
+    chunks, head = [], None
+    for s0 in range(0, n, chunk):
+        m = min(chunk, n - s0)
+        x = cd.rows(m, g); ix.add(x)
+        if head is None:
+            head = x[:1000].clone()
+        if keep_chunks:
+            chunks.append((s0, x))
+        del x
+    return ix, cd, chunks, head
+
+
+def _regen_chunks(n, d, kind, chunk=250_000):
+    """the same corpus again, chunk by chunk (rows are a pure function of the generator state): for sizes where a second resident copy is too much"""
+    import torch
+    from kirag_amd.bench_support import CorpusDist
+    dev = torch.device("cuda:0")
+    cd = CorpusDist(kind, d, dev)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    for s0 in range(0, n, chunk):
+        yield s0, cd.rows(min(chunk, n - s0), g)
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "e5like"])
+def test_config2_1M_all_queries_vs_independent_topk_and_oracle(kind):
+    """BASELINE config 2 (1M x 1024, 1000 queries, top-100) on the Gaussian corpus and on the e5like one (scores in a narrow band around 0.75,
+    rank-100 gaps ~5e-5): ALL 1000 queries against torch's fp32 sgemm + topk (no missed row, no wrong row, scores within 2e-6), 32 queries bit-exact
+    against the C oracle over the full corpus, planted neighbour first, certified fraction reported."""
+    import torch
+    n, d, nq, k = 1_000_000, 1024, 1000, 100
+    ix, cd, chunks, head = _build_resident(n, d, kind, keep_chunks=True)
+    gq = torch.Generator(device="cuda"); gq.manual_seed(2)
+    q = cd.queries_near(head[:nq], gq)
+    s, i = ix.search(q, k)
+    st = ix.stats()
+    print(f"[1M {kind}] certified {st['certified']}/{nq}, fine {st['fine']}, exact {st['exact']}, reranked/query {st['reranked_rows'] / nq:.0f}")
+    assert np.array_equal(i[:, 0], np.arange(nq))                                 # planted neighbour first
+    assert (np.diff(s, axis=1) <= 0).all()
+    rs, ri = IC.torch_topk_fp32(q, chunks, k + 32)
+    out = IC.check_membership(s, i, rs.cpu().numpy(), ri.cpu().numpy(), k)
+    assert out["queries"] == nq
+    assert st["certified"] >= 0.95 * nq and st["exact"] == 0, st
+    xh = torch.cat([c[1] for c in chunks]).cpu().numpy()
+    so, io = S.search_canonical(q[:32].cpu().numpy(), xh, k)
+    assert np.array_equal(i[:32], io) and np.array_equal(s[:32].view(np.uint32), so.view(np.uint32))
+    # shard-merge == unsharded (two 500k shards), through the host merge
+    from kirag_amd import _lib
+    from kirag_amd.retriever.index import FlatIPIndex
+    halves = []
+    for a, b in ((0, 500_000), (500_000, n)):
+        sh = FlatIPIndex(d); sh.reserve(b - a)
+        for r0, xc in chunks:
+            if a <= r0 < b:
+                sh.add(xc)
+        s_, i_ = sh.search(q[:64], k); halves.append((s_, i_ + a)); del sh
+    sc2 = np.ascontiguousarray(np.stack([h[0] for h in halves])); ic2 = np.ascontiguousarray(np.stack([h[1] for h in halves]))
+    ms = np.empty((64, k), np.float32); mi = np.empty((64, k), np.int64)
+    _lib.check(_lib.load().kr_topk_merge(sc2.ctypes.data, ic2.ctypes.data, 2, 64, k, ms.ctypes.data, mi.ctypes.data))
+    assert np.array_equal(mi, i[:64]) and np.array_equal(ms, s[:64])
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "e5like"])
+def test_metric_size_5M_all_queries_vs_independent_topk(kind):
+    """The metric's own size (5M x 1024 on one GPU, 1000 queries, top-100; BASELINE config 3's corpus): all 1000 queries against the
+    kernel-independent fp32 sgemm + topk (the corpus is regenerated chunk by chunk for the reference), 8 queries bit-exact against the C oracle
+    on the rows of the reference's top-132 lists plus 200k further rows."""
+    import torch
+    n, d, nq, k = 5_000_000, 1024, 1000, 100
+    ix, cd, _, head = _build_resident(n, d, kind, keep_chunks=False)
+    gq = torch.Generator(device="cuda"); gq.manual_seed(2)
+    q = cd.queries_near(head[:nq], gq)
+    s, i = ix.search(q, k)
+    st = ix.stats()
+    print(f"[5M {kind}] certified {st['certified']}/{nq}, fine {st['fine']}, exact {st['exact']}, reranked/query {st['reranked_rows'] / nq:.0f}, "
+          f"coarse {st['last_coarse_ms']:.2f} ms, total {st['last_total_ms']:.2f} ms")
+    assert np.array_equal(i[:, 0], np.arange(nq)) and (np.diff(s, axis=1) <= 0).all()
+    rs, ri = IC.torch_topk_fp32(q, _regen_chunks(n, d, kind), k + 32)
+    out = IC.check_membership(s, i, rs.cpu().numpy(), ri.cpu().numpy(), k)
+    assert out["queries"] == nq and st["certified"] >= 0.95 * nq and st["exact"] == 0, (out, st)
+    # canonical score bits of the returned rows (C oracle on the gathered rows)
+    rows = i[:8].reshape(-1)
+    xs = ix.reconstruct_rows(rows) if hasattr(ix, "reconstruct_rows") else np.stack([ix.reconstruct_n(int(r), 1)[0] for r in rows])
+    sc = S.scores_at(q[:8].cpu().numpy(), xs, np.arange(8 * k).reshape(8, k).astype(np.int64))
+    assert np.array_equal(sc.view(np.uint32), s[:8].view(np.uint32))
+
+
+def test_config4_size_21M_search_only_vs_independent_topk():
+    """BASELINE config 4's corpus size on ONE GPU: 21,015,324 x 1024 (43 GB bf16 + 86 GB fp32 resident), 256 queries, top-100, search only;
+    every query against the kernel-independent fp32 sgemm + topk over the regenerated corpus."""
+    import torch
+    n, d, nq, k = 21_015_324, 1024, 256, 100
+    ix, cd, _, head = _build_resident(n, d, "gaussian", keep_chunks=False, chunk=500_000)
+    gq = torch.Generator(device="cuda"); gq.manual_seed(2)
+    q = cd.queries_near(head[:nq], gq)
+    s, i = ix.search(q, k)
+    st = ix.stats()
+    print(f"[21M] certified {st['certified']}/{nq}, fine {st['fine']}, exact {st['exact']}, coarse {st['last_coarse_ms']:.2f} ms, total {st['last_total_ms']:.2f} ms")
+    assert np.array_equal(i[:, 0], np.arange(nq)) and (np.diff(s, axis=1) <= 0).all()
+    rs, ri = IC.torch_topk_fp32(q, _regen_chunks(n, d, "gaussian", chunk=500_000), k + 32)
+    out = IC.check_membership(s, i, rs.cpu().numpy(), ri.cpu().numpy(), k)
+    assert out["queries"] == nq and st["exact"] == 0, (out, st)

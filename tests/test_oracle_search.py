@@ -1,7 +1,9 @@
 """Known-answer tests for the search oracle.  faiss is not available: these pin the oracle's OWN stated
-semantics (exact IP, (score desc, row asc) tie rule, canonical fp64-ordered score), cross-check the three
-scorers against each other and against plain fp32 sgemm (what IndexFlatIP computes), and cover the edge
-cases of retriever/index.py (1024-query block boundary, id mapping, duplicate rows, k == n, k > n)."""
+semantics (exact IP, (score desc, row asc) tie rule, canonical score = the exact inner product rounded once
+to fp32), check its formulations against each other, against Python rationals and the committed vectors
+(tests/golden/g9_exact_dot.npz), measure the distance from plain fp32 arithmetic / sgemm (what IndexFlatIP
+computes), and cover the edge cases of retriever/index.py (1024-query block boundary, id mapping, duplicate
+rows, k == n, k > n)."""
 import numpy as np
 import pytest
 
@@ -13,13 +15,53 @@ def _unit(rng, n, d):
     return x / np.linalg.norm(x, axis=1, keepdims=True)
 
 
-def test_canonical_dot_is_fp64_exactish():
+def _g9(golden):
+    g = golden("g9_exact_dot.npz")
+    off = g["offsets"]
+    for c in range(len(off) - 1):
+        yield (g["q_bits"][off[c]:off[c + 1]].view(np.float32), g["x_bits"][off[c]:off[c + 1]].view(np.float32), g["expected_bits"][c])
+
+
+def test_canonical_score_golden_vectors(golden):
+    """351 known answers computed with Python rationals (tests/golden/make_exact_dot_golden.py): exact midpoints, sticky bits, subnormal
+    and vanishing results, overflow, cancellation, 120-bit exponent spreads.  Both C formulations must reproduce every bit."""
+    n = 0
+    for q, x, want in _g9(golden):
+        for which in ("canonical", "exact"):
+            got = np.float32(S.dot(q, x, which)).view(np.uint32)
+            assert got == want, (n, which, len(q), hex(int(got)), hex(int(want)))
+        n += 1
+    assert n == 351
+
+
+def test_canonical_equals_rationals_on_fresh_random_cases():
     rng = np.random.default_rng(0)
-    for d in (1, 3, 64, 257, 1024):
+    for t in range(200):
+        d = int(rng.choice([1, 2, 3, 5, 64, 257, 1024]))
         q = rng.standard_normal(d).astype(np.float32); x = rng.standard_normal(d).astype(np.float32)
-        got = S.lib().kr_oracle_dot(q.ctypes.data, x.ctypes.data, d)
-        ref = float(np.dot(q.astype(np.float64), x.astype(np.float64)))
-        assert abs(got - ref) <= 1e-12 * max(1.0, np.abs(q.astype(np.float64) * x).sum())
+        if t % 3 == 0:
+            q *= np.float32(2.0) ** rng.integers(-50, 50, d).astype(np.float32)
+        want = S.dot_fraction(q, x).view(np.uint32)
+        assert np.float32(S.dot(q, x)).view(np.uint32) == want and np.float32(S.dot(q, x, "exact")).view(np.uint32) == want
+
+
+def test_sequential_fp64_path_equals_super_accumulator_and_distance_from_fp32():
+    """The plain sequential-fp64 formulation (with its certified rounding) against the integer super-accumulator on 1.2M unit-vector pairs
+    at the metric's dimension, and the distance of the canonical score from fp32 arithmetic: an fp32 accumulation in index order and numpy's
+    sgemm (the BLAS formulation faiss.IndexFlatIP uses) stay within a few fp32 ulps of it — the oracle is not an artefact of one summation order."""
+    rng = np.random.default_rng(123)
+    x = _unit(rng, 30000, 1024); q = _unit(rng, 40, 1024)
+    can = S.scores_all(q, x, "canonical"); exa = S.scores_all(q, x, "exact")
+    assert np.array_equal(can.view(np.uint32), exa.view(np.uint32))
+    f32 = S.scores_all(q, x, "f32").astype(np.float64)
+    sg = (q @ x.T).astype(np.float64)
+    d_loop = np.abs(f32 - can).max(); d_sgemm = np.abs(sg - can).max()
+    absd = max(d_loop, d_sgemm)
+    ulp1 = 2.0 ** -24                                     # fp32 spacing just below 1.0 (cosine scores of real neighbours sit in [0.5, 1))
+    print(f"canonical vs fp32 loop: max |diff| {d_loop:.2e} = {d_loop / ulp1:.1f} ulp(1-); vs sgemm: {d_sgemm:.2e} = {d_sgemm / ulp1:.1f} ulp(1-)")
+    assert absd < 2e-6                                    # d * 2^-24 * sum|q_i x_i| ~ 1024 * 6e-8 * 0.03
+    f64 = (q.astype(np.float64) @ x.astype(np.float64).T).astype(np.float32)
+    assert (f64.view(np.uint32) != can.view(np.uint32)).mean() < 1e-4      # an unordered fp64 sum rounds the same except at fp32 boundaries
 
 
 def test_three_scorers_agree_and_match_sgemm():
