@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     BIND(kr_index_create) BIND(kr_index_destroy) BIND(kr_index_reserve) BIND(kr_index_add) BIND(kr_index_ntotal) BIND(kr_index_dim)
     BIND(kr_index_get_rows) BIND(kr_index_search) BIND(kr_index_stats) BIND(kr_score_topk) BIND(kr_topk_merge)
     BIND(kr_encoder_create) BIND(kr_encoder_destroy) BIND(kr_encoder_load_weight) BIND(kr_encoder_finalize) BIND(kr_encoder_forward)
-    BIND(kr_encoder_last_hidden)
+    BIND(kr_encoder_last_hidden) BIND(kr_set_option) BIND(kr_release_scratch) BIND(kr_topk_merge_device)
     if (p_kr_abi_version() != KR_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }
 
     /* argument validation happens before any device work */
@@ -33,6 +33,8 @@ int main(int argc, char** argv) {
     if (p_kr_index_ntotal(NULL) != 0 || p_kr_index_dim(NULL) != 0) return 1;
     p_kr_index_destroy(NULL);
     p_kr_encoder_destroy(NULL);
+    if (p_kr_set_option("no_such_option", 1) != KR_EINVAL || p_kr_set_option("force_exact_scores", 0) != KR_OK) { printf("kr_set_option\n"); return 1; }
+    p_kr_release_scratch();   /* nothing allocated yet: must be a no-op */
 
     /* host-side k-way merge of two shards (score desc, id asc), with a tie across shards and a short shard (-1 padding) */
     const float s[2][1][3] = {{{0.9f, 0.5f, 0.1f}}, {{0.9f, 0.7f, -INFINITY}}};
