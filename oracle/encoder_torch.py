@@ -27,16 +27,21 @@ def encode(model, ids, mask):
     return torch.nn.functional.normalize(emb, p=2, dim=1)
 
 
-def time_encode(n_seq: int, S: int, batch: int = 8):
-    """-> (sequences per second, seconds measured) for n_seq sequences of S tokens in batches of `batch` (reference: no no_grad in
-    cal_doc_embeddings, but autograd bookkeeping is not the arithmetic being compared: timed under no_grad, i.e. in the CPU's favour)."""
+def time_encode(n_seq: int, S: int, batch: int = 8, repeats: int = 5):
+    """-> (sequences per second, median seconds of one pass, all pass times) for n_seq sequences of S tokens in batches of `batch`.
+    BASELINE.md section 3 protocol: one warm-up pass, then the MEDIAN of `repeats` timed passes over the same sample.  (Reference: no no_grad
+    in cal_doc_embeddings, but autograd bookkeeping is not the arithmetic being compared: timed under no_grad, i.e. in the CPU's favour.)"""
     model = build_cpu_e5_large()
     g = torch.Generator().manual_seed(2)
     ids = torch.randint(1000, 30000, (n_seq, S), generator=g); mask = torch.ones(n_seq, S, dtype=torch.long)
+    times = []
     with torch.no_grad():
-        encode(model, ids[:batch], mask[:batch])          # warm-up
-        t0 = time.perf_counter()
-        for s in range(0, n_seq, batch):
-            encode(model, ids[s:s + batch], mask[s:s + batch]).detach().cpu()
-        dt = time.perf_counter() - t0
-    return n_seq / dt, dt
+        for rep in range(repeats + 1):
+            t0 = time.perf_counter()
+            for s in range(0, n_seq, batch):
+                encode(model, ids[s:s + batch], mask[s:s + batch]).detach().cpu()
+            if rep:                                          # pass 0 = warm-up
+                times.append(time.perf_counter() - t0)
+    times.sort()
+    dt = times[len(times) // 2]
+    return n_seq / dt, dt, times

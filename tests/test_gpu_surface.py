@@ -160,3 +160,55 @@ def test_setup_retriever_model_wiring(golden, tmp_path):
         for r in range(2):
             assert [d["id"] for d in out[r]] == [str(7 * j + 1) for j in io[r]]
             assert all(isinstance(d["score"], float) for d in out[r]) and out[r][0]["text"] == corpus.p[io[r][0]]
+
+
+def test_g4_g5_g6_on_the_gpu(golden):
+    """SURVEY 8a rows a11-a13 on the GPU box against the reference-generated goldens:
+    G4  BaseRetriever.compute_logits / score (retrievers.py:71-91), four rank cases + temperature 0.01 / "sqrt" + the ValueError, on device tensors;
+    G5  rank-3 input_ids through get_encoder_output / encoder_embed / doc (retrievers.py:93-122) on the HIP encoder (eval mode);
+    G6  InBatchRetriever.forward (retrievers.py:133-150): in train mode (PyTorch autograd on the GPU, loss.backward() reaches the weights) and in
+        eval mode (HIP encoder) - loss / scores / query embeddings against the reference's."""
+    from kirag_amd.retriever.retrievers import InBatchRetriever
+    with tempfile.TemporaryDirectory() as td:
+        g, tok, w, heads = _setup(td, golden)
+        ret = InBatchRetriever("E5Retriever", td, temperature=0.01).cuda()
+        assert ret.device.type == "cuda"
+        T = lambda k: torch.from_numpy(g[k]).cuda()
+        q1, d1, q2, d2, d3 = (T(f"g4.{k}") for k in ("q1", "d1", "q2", "d2", "d3"))
+        for got, want, tol in ((ret.compute_logits(q1, d1), "g4.l11", 1e-6), (ret.compute_logits(q1, d2), "g4.l12", 1e-6),
+                               (ret.compute_logits(q2, d3), "g4.l23", 1e-6), (ret.compute_logits(q2, d2), "g4.l22", 1e-6), (ret.score(q2, d2), "g4.s22_t001", 2e-4)):
+            assert got.is_cuda
+            np.testing.assert_allclose(got.cpu().numpy(), g[want], rtol=2e-6, atol=tol)
+        ret.temperature = "sqrt"
+        np.testing.assert_allclose(ret.score(q2, d2).cpu().numpy(), g["g4.s22_sqrt"], rtol=2e-6, atol=1e-6)
+        ret.temperature = 0.01
+        with pytest.raises(ValueError) as ei:
+            ret.compute_logits(d3, d3)
+        assert str(ei.value) == str(g["g4.err"])
+        # G5: rank-3 ids through the HIP encoder
+        ret.eval()
+        a3 = {"input_ids": T("g5.ids"), "attention_mask": T("g5.mask")}
+        out3 = ret.doc(a3)
+        assert out3.is_cuda and tuple(out3.shape) == tuple(g["g5.out"].shape)
+        assert np.abs(out3.cpu().numpy() - g["g5.out"]).max() <= 4e-3
+        # G6 eval mode (HIP forward) and train mode (autograd)
+        qa = {"input_ids": T("g7.e5.q.ids"), "attention_mask": T("g7.e5.q.mask")}
+        da = {"input_ids": T("g7.e5.d.ids"), "attention_mask": T("g7.e5.d.mask")}
+        labels = torch.tensor([0, 1, 2], device="cuda")
+        with torch.no_grad():
+            loss_e, scores_e, gq_e, gd_e = ret(qa, da, labels)
+        assert np.abs(gq_e.cpu().numpy() - g["g6.q"]).max() <= 4e-3
+        np.testing.assert_allclose(scores_e.cpu().numpy(), g["g6.scores"], atol=0.1)          # scores / 0.01: 1e-3 on a cosine = 0.1 here
+        assert abs(float(loss_e) - float(g["g6.loss"])) < 5e-2
+        ret.train()
+        for mod in ret.modules():                       # the golden was taken without dropout (config dropout 0 in make_golden.py)
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        loss, scores, gq, gd = ret(qa, da, labels)
+        assert loss.requires_grad and loss.is_cuda
+        np.testing.assert_allclose(gq.detach().cpu().numpy(), g["g6.q"], atol=5e-5)
+        np.testing.assert_allclose(scores.detach().cpu().numpy(), g["g6.scores"], atol=2e-2)
+        assert abs(float(loss) - float(g["g6.loss"])) < 5e-3
+        loss.backward()
+        gw = ret.encoder.encoder.layer[0].attention.self.query.weight.grad
+        assert gw is not None and torch.isfinite(gw).all() and float(gw.abs().sum()) > 0
