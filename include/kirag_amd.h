@@ -144,6 +144,11 @@ int kr_encoder_finalize(kr_encoder* enc);
  *   A sequence whose mask is all zero yields NaN (mean pool) exactly like the reference. */
 int kr_encoder_forward(kr_encoder* enc, const int64_t* input_ids, const int64_t* attention_mask, int B, int S,
                        int pool, float* out, void* stream);
+/* kr_encoder_forward with a DEVICE `out` pointer only enqueues work on `stream` and returns (no host synchronisation); with a host `out`
+ * it returns when the result is in the caller's buffer.  The one thing a forward can get wrong at run time - a token id outside [0, vocab)
+ * - is recorded by the kernels (the offending token is read as id 0) and reported as KR_EINVAL by the host-output call itself, or, for
+ * device-output calls, by the NEXT call on the handle once that forward has finished, or by kr_encoder_check(), which waits for it. */
+int kr_encoder_check(kr_encoder* enc);
 /* debugging / parity: last_hidden_state of the previous forward, fp32 [B*S_packed...] see DESIGN.md */
 int kr_encoder_last_hidden(kr_encoder* enc, float* out /* [B,S,hidden] */, int B, int S);
 

@@ -58,6 +58,7 @@ SIGNATURES = {
     "kr_encoder_finalize": (C.c_int, [C.c_void_p]),
     "kr_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "kr_encoder_last_hidden": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "kr_encoder_check": (C.c_int, [C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

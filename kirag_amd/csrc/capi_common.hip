@@ -23,6 +23,12 @@ int fail(int code, const char* fmt, ...) {
 
 std::atomic<int> g_force_exact{0};
 
+bool is_device_pointer(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // unregistered (pageable) host memory
+    return at.type == hipMemoryTypeDevice;
+}
+
 int select_device(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

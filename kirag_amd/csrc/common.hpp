@@ -35,6 +35,7 @@ int fail(int code, const char* fmt, ...);
     } while (0)
 
 int select_device(int device);  // hipSetDevice + arch check (gfx950)
+bool is_device_pointer(const void* p);   // hipMalloc memory (as opposed to pageable / pinned host memory)
 extern std::atomic<int> g_force_exact;   // kr_set_option("force_exact_scores")
 
 // ---- 16-bit element tags ------------------------------------------------------------------------------------

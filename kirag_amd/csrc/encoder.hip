@@ -70,6 +70,10 @@ struct Encoder {
     bool use_lo = false;       // KIRAG_AMD_RESIDUAL_LO=1 at kr_encoder_create
     uint16_t *y = nullptr, *xb = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *ctx = nullptr, *h = nullptr;
     int lastB = 0, lastS = 0;
+    int* h_err = nullptr;            // pinned: copy of d_err taken at the end of the last asynchronous forward
+    hipEvent_t ev_done = nullptr;    // recorded after that copy
+    bool pending = false;            // an asynchronous forward's error word has not been looked at yet
+    hipStream_t last_stream = nullptr;
     int num_cu = 256;
 };
 
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(64) void k_seq_scan(const int* __restrict__ nk, con
         if (b < B) off[b] = carry + incl - padded;
         carry += __shfl(incl, 63, 64);
     }
-    if (lane == 0) { *T = carry; *err = 0; }
+    if (lane == 0) { *T = carry; }   // *err is sticky: set by k_fill_tokens, cleared by the host once it has been reported
 }
 
 // one wave per sequence: packed token list (attended positions in order; the optional query-only row for position 0 last)
@@ -795,7 +799,13 @@ static void free_ws(Encoder* e) {
 static int ensure_ws(Encoder* e, int B, int S) {
     const int64_t maxT = (int64_t)B * (S + 4);
     const int H = e->cfg.hidden, FF = e->cfg.intermediate;
-    if (!e->d_T) { KR_TRY(dmalloc(&e->d_T, sizeof(int))); KR_TRY(dmalloc(&e->d_err, sizeof(int))); }
+    if (!e->d_T) {
+        KR_TRY(dmalloc(&e->d_T, sizeof(int))); KR_TRY(dmalloc(&e->d_err, sizeof(int)));
+        KR_HIP(hipMemset(e->d_err, 0, sizeof(int)));
+        KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_err), sizeof(int), hipHostMallocDefault));
+        *e->h_err = 0;
+        KR_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+    }
     if (maxT <= e->capT && B <= e->capB && (int64_t)B * S <= e->capBS) return 0;
     free_ws(e);
     const int64_t capT = round_up(maxT, 256), capB = B, capBS = (int64_t)B * S;   // multiple of the 256-token tile: see k_proj
@@ -983,6 +993,8 @@ void kr_encoder_destroy(kr_encoder* h) {
     Encoder* e = reinterpret_cast<Encoder*>(h);
     (void)hipSetDevice(e->device);
     free_ws(e);
+    if (e->h_err) (void)hipHostFree(e->h_err);
+    if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     void* ptrs[] = {e->word, e->pos, e->type, e->elng, e->elnb, e->stage, e->d_T, e->d_err};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& l : e->L) {
@@ -1059,6 +1071,14 @@ int kr_encoder_finalize(kr_encoder* h) {
     return 0;
 }
 
+// the sticky device error word has been copied to e->h_err and that copy has completed
+static int report_token_error(Encoder* e, hipStream_t st) {
+    if (*e->h_err == 0) return 0;
+    *e->h_err = 0;
+    KR_HIP(hipMemsetAsync(e->d_err, 0, sizeof(int), st));
+    return fail(KR_EINVAL, "input_ids contain a token id outside [0, %d)", e->cfg.vocab);
+}
+
 int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* attention_mask, int B, int S, int pool, float* out, void* stream) {
     if (!h) return fail(KR_EINVAL, "encoder is NULL");
     Encoder* e = reinterpret_cast<Encoder*>(h);
@@ -1070,6 +1090,13 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
     if (B > 65535) return fail(KR_EINVAL, "at most 65535 sequences per call");
     KR_TRY(select_device(e->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (e->pending) {
+        if (st != e->last_stream) KR_HIP(hipEventSynchronize(e->ev_done));      // the workspace is shared: a forward on another stream waits for the previous one
+        if (hipEventQuery(e->ev_done) == hipSuccess) {                          // finished: report its token-id error now (never blocks)
+            e->pending = false;
+            KR_TRY(report_token_error(e, st));
+        }
+    }
     KR_TRY(ensure_ws(e, B, S));
     const int H = e->cfg.hidden, FF = e->cfg.intermediate;
     const float eps = e->cfg.ln_eps;
@@ -1116,12 +1143,28 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
     hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);
     KR_HIP(hipGetLastError());
     KR_HIP(hipMemcpyAsync(out, e->out, (size_t)B * H * 4, hipMemcpyDefault, st));
-    int err = 0;
-    KR_HIP(hipMemcpyAsync(&err, e->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-    KR_HIP(hipStreamSynchronize(st));
-    e->lastB = B; e->lastS = S;
-    if (err) return fail(KR_EINVAL, "input_ids contain a token id outside [0, %d)", e->cfg.vocab);
-    return 0;
+    e->lastB = B; e->lastS = S; e->last_stream = st;
+    KR_HIP(hipMemcpyAsync(e->h_err, e->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (is_device_pointer(out)) {
+        // device output: nothing here waits for the GPU.  The token-id error word (the only thing the host would need) travels to pinned memory
+        // behind the forward; it is looked at by the next call on this handle or by kr_encoder_check().
+        KR_HIP(hipEventRecord(e->ev_done, st));
+        e->pending = true;
+        return 0;
+    }
+    KR_HIP(hipStreamSynchronize(st));   // a host pointer is returned: the caller reads it as soon as we return
+    e->pending = false;
+    return report_token_error(e, st);
+}
+
+int kr_encoder_check(kr_encoder* h) {
+    if (!h) return fail(KR_EINVAL, "encoder is NULL");
+    Encoder* e = reinterpret_cast<Encoder*>(h);
+    if (!e->pending) return 0;
+    KR_TRY(select_device(e->device));
+    KR_HIP(hipEventSynchronize(e->ev_done));
+    e->pending = false;
+    return report_token_error(e, e->last_stream);
 }
 
 // last_hidden_state of the previous forward, un-packed to [B,S,H]; rows of non-attended positions are zero
@@ -1130,6 +1173,7 @@ int kr_encoder_last_hidden(kr_encoder* h, float* out, int B, int S) {
     Encoder* e = reinterpret_cast<Encoder*>(h);
     if (B != e->lastB || S != e->lastS || B == 0) return fail(KR_ESTATE, "no forward of shape [%d,%d] to read back", B, S);
     KR_TRY(select_device(e->device));
+    KR_HIP(hipStreamSynchronize(e->last_stream));
     const int H = e->cfg.hidden;
     std::vector<int> off(B), nq(B);
     int T = 0;

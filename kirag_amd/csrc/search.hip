@@ -65,6 +65,7 @@ struct Index {
     uint4* blk_list = nullptr; unsigned int* blk_cnt = nullptr;   // [num_cu*8, WLISTCAP] per-wave survivor lists, [num_cu*8 + 1] counts (+ overflow word)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evc[2 * 16] = {};   // begin/end pairs around each coarse round (roofline timing)
+    hipEvent_t ev_add = nullptr;   // recorded behind the last (asynchronous) add: searches on another stream wait for it
     kr_search_stats st{};
     int num_cu = 256;
 };
@@ -1247,6 +1248,7 @@ void kr_index_destroy(kr_index* h) {
     if (ix->h_status) (void)hipHostFree(ix->h_status);
     for (auto& e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ix->evc) if (e) (void)hipEventDestroy(e);
+    if (ix->ev_add) (void)hipEventDestroy(ix->ev_add);
     delete ix;
 }
 
@@ -1279,7 +1281,13 @@ int kr_index_add(kr_index* h, const float* x, int64_t n, void* stream) {
         if (n_pad > nn) hipLaunchKernelGGL(k_pad_nan, dim3((unsigned)(((n_pad - nn) * ix->dpad + 255) / 256)), dim3(256), 0, st, ix->xc, nn, n_pad, ix->dpad);
     }
     KR_HIP(hipGetLastError());
-    KR_HIP(hipStreamSynchronize(st));   // x may be a pageable host buffer the caller frees on return
+    // a host source must have been consumed when we return (the caller may free it); a device source is only read in stream order, and the
+    // searches that follow are enqueued behind this add on the caller's stream
+    if (!is_device_pointer(x)) KR_HIP(hipStreamSynchronize(st));
+    else {
+        if (!ix->ev_add) KR_HIP(hipEventCreateWithFlags(&ix->ev_add, hipEventDisableTiming));
+        KR_HIP(hipEventRecord(ix->ev_add, st));
+    }
     ix->n += n;
     return 0;
 }
@@ -1310,6 +1318,7 @@ int kr_index_search(kr_index* h, const float* q, int nq, int k, float* scores, i
     if (nq == 0) return 0;
     KR_TRY(select_device(ix->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (ix->ev_add) KR_HIP(hipStreamWaitEvent(st, ix->ev_add, 0));   // rows added asynchronously on another stream
     ix->force_exact = g_force_exact.load();
     ix->st.last_coarse_ms = 0.0; ix->st.last_total_ms = 0.0; ix->st.last_fine_ms = 0.0;
     for (int b = 0; b < nq; b += QBLK) {

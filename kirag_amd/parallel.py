@@ -40,16 +40,22 @@ class ShardedSearcher:
         self.world = int(world) if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
 
     def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:
-        """-> (scores float32 [nq,k], GLOBAL rows int64 [nq,k]) on every rank.  A shard with fewer than k rows
-        contributes what it has (padded with id -1)."""
+        """-> (scores float32 [nq,k], GLOBAL rows int64 [nq,k]) on every rank, ONE contract for every world size: always k columns; a corpus
+        (all shards together) with fewer than k rows pads the tail with (-inf, -1).  A shard with fewer than k rows contributes what it has."""
         import torch
         import torch.distributed as dist
         k = int(k)
         kl = min(k, int(self.index.ntotal))
         nq = int(q.shape[0])
         if self.world == 1:
-            s, i = self.index.search(q, kl)
-            return s, i + self.row_offset
+            if kl == k:
+                s, i = self.index.search(q, k)
+                return s, i + self.row_offset
+            s = np.full((nq, k), -np.inf, np.float32); i = np.full((nq, k), -1, np.int64)
+            if kl > 0:
+                s_, i_ = self.index.search(q, kl)
+                s[:, :kl] = s_; i[:, :kl] = i_ + self.row_offset
+            return s, i
         on_gpu = torch.is_tensor(q) and q.is_cuda
         dev = q.device if on_gpu else torch.device("cpu")
         if not on_gpu and dist.get_backend(self.group) == "nccl":
@@ -99,6 +105,12 @@ class ShardedSearcher:
         if self.row_offset and kl > 0:
             (ids if kl == k else ids[:, :kl]).add_(self.row_offset)
         dist.all_gather_into_tensor(self._all, self._mine, group=self.group)
+        if W * k > 8192:
+            # beyond the device merge's LDS capacity (kr_topk_merge_device: nshards * k <= 8192, e.g. 16 shards x k = 1024): merge on the host
+            host = self._all.cpu().numpy().reshape(W, block)
+            ids_h = np.ascontiguousarray(host[:, :nq * k * 8]).view(np.int64).reshape(W, nq, k)
+            sc_h = np.ascontiguousarray(host[:, nq * k * 8:nq * k * 12]).view(np.float32).reshape(W, nq, k)
+            return merge_topk(sc_h, ids_h, k)
         base = self._all.data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(_lib.load().kr_topk_merge_device(base + nq * k * 8, block // 4, base, block // 8, W, nq, k,

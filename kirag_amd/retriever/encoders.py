@@ -61,6 +61,13 @@ class HipBertForward:
                 pass
             self._h = None
 
+    def invalidate(self) -> None:
+        """Forget the weight fingerprint: the next eval forward re-reads every parameter.  The fingerprint is (data_ptr, tensor version), which
+        in-place updates THROUGH ``.data`` do not bump (``p.data.copy_()``, HF ``_init_weights``, optimizers doing ``p.data.add_``): code that
+        mutates ``.data`` while the model stays in eval mode must call ``model.invalidate_hip_weights()``; ``train()`` / ``eval()`` transitions and
+        ``load_state_dict`` do it automatically."""
+        self.fingerprint = None
+
     def sync(self, module: torch.nn.Module) -> None:
         params = [(n, p) for n, p in module.named_parameters() if not n.startswith("pooler.")]
         fp = tuple((p.data_ptr(), p._version) for _, p in params)
@@ -106,6 +113,10 @@ class HipBertForward:
                                                 _lib.current_stream_ptr() if ids.is_cuda else None))
         return out
 
+    def check(self) -> None:
+        """Wait for the last device-output forward and raise if it saw a token id outside the vocabulary (``kr_encoder_check``)."""
+        _lib.check(self._lib.kr_encoder_check(self._h))
+
     def last_hidden(self, B: int, S: int) -> Tensor:
         out = torch.empty((B, S, self.hidden), dtype=torch.float32)
         _lib.check(self._lib.kr_encoder_last_hidden(self._h, out.data_ptr(), B, S))
@@ -136,6 +147,22 @@ class _HipSentenceEncoder(BertModel):
         self._hip.sync(self)
         with torch.cuda.device(idx):
             return self._hip.forward(input_ids.to(p.device), attention_mask, self._pool)
+
+    def invalidate_hip_weights(self) -> None:
+        if self._hip is not None:
+            self._hip.invalidate()
+
+    def train(self, mode: bool = True):
+        # every train <-> eval transition re-syncs the bf16 weight copies on the next eval forward (training steps may have updated the
+        # parameters through .data, which the (data_ptr, version) fingerprint cannot see)
+        if getattr(self, "_hip", None) is not None and bool(mode) != self.training:
+            self._hip.invalidate()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_hip_weights()
+        return out
 
     def _torch_pooled(self, input_ids, attention_mask, token_type_ids):
         out = BertModel.forward(self, input_ids=input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, return_dict=True)

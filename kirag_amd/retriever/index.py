@@ -74,6 +74,15 @@ class FlatIPIndex:
             return a.ctypes.data, a
         return int(a.data_ptr()), a  # torch.Tensor
 
+    def _stream(self, *tensors):
+        """hipStream_t for a call: torch's CURRENT stream on this index's device when any operand is a CUDA tensor (work the caller queued on a
+        side stream — a cast, a gather — is then ordered before the library's kernels, and the outputs after them), else the default stream."""
+        for t in tensors:
+            if not isinstance(t, np.ndarray) and getattr(t, "is_cuda", False):
+                import torch
+                return int(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
     def add(self, x) -> None:
         if isinstance(x, np.ndarray):
             x = np.ascontiguousarray(x, dtype=np.float32)
@@ -82,7 +91,7 @@ class FlatIPIndex:
         if x.ndim != 2 or x.shape[1] != self.d:
             raise ValueError(f"expected [n,{self.d}] embeddings, got {tuple(x.shape)}")
         p, keep = self._ptr(x)
-        _lib.check(self._lib.kr_index_add(self._h, p, int(x.shape[0]), None))
+        _lib.check(self._lib.kr_index_add(self._h, p, int(x.shape[0]), self._stream(x)))
 
     def search(self, q, k: int, mode: int = 0) -> Tuple[np.ndarray, np.ndarray]:
         """(scores float32 [nq,k] descending, internal rows int64 [nq,k]) — faiss's (D, I)."""
@@ -99,7 +108,7 @@ class FlatIPIndex:
         scores = np.empty((nq, k), np.float32)
         rows = np.empty((nq, k), np.int64)
         p, keep = self._ptr(q)
-        _lib.check(self._lib.kr_index_search(self._h, p, nq, k, scores.ctypes.data, rows.ctypes.data, int(mode), None))
+        _lib.check(self._lib.kr_index_search(self._h, p, nq, k, scores.ctypes.data, rows.ctypes.data, int(mode), self._stream(q)))
         return scores, rows
 
     def search_into(self, q, k: int, scores_out, rows_out, mode: int = 0) -> None:
@@ -112,7 +121,8 @@ class FlatIPIndex:
         assert tuple(scores_out.shape) == (nq, k) and tuple(rows_out.shape) == (nq, k)
         assert scores_out.is_contiguous() and rows_out.is_contiguous()
         p, keep = self._ptr(q)
-        _lib.check(self._lib.kr_index_search(self._h, p, nq, k, int(scores_out.data_ptr()), int(rows_out.data_ptr()), int(mode), None))
+        _lib.check(self._lib.kr_index_search(self._h, p, nq, k, int(scores_out.data_ptr()), int(rows_out.data_ptr()), int(mode),
+                                             self._stream(q, scores_out, rows_out)))
 
     def reconstruct_n(self, start: int, n: int) -> np.ndarray:
         out = np.empty((n, self.d), np.float32)

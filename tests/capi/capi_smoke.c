@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     BIND(kr_index_create) BIND(kr_index_destroy) BIND(kr_index_reserve) BIND(kr_index_add) BIND(kr_index_ntotal) BIND(kr_index_dim)
     BIND(kr_index_get_rows) BIND(kr_index_search) BIND(kr_index_stats) BIND(kr_score_topk) BIND(kr_topk_merge)
     BIND(kr_encoder_create) BIND(kr_encoder_destroy) BIND(kr_encoder_load_weight) BIND(kr_encoder_finalize) BIND(kr_encoder_forward)
-    BIND(kr_encoder_last_hidden) BIND(kr_set_option) BIND(kr_release_scratch) BIND(kr_topk_merge_device)
+    BIND(kr_encoder_last_hidden) BIND(kr_encoder_check) BIND(kr_set_option) BIND(kr_release_scratch) BIND(kr_topk_merge_device)
     if (p_kr_abi_version() != KR_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }
 
     /* argument validation happens before any device work */

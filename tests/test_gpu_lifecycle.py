@@ -64,3 +64,45 @@ def test_encoder_create_use_destroy_does_not_leak():
         assert np.abs(h.forward_np(ids, mask, 0) - ref).max() < 4e-3
         del h
     assert base - _free_bytes() < (8 << 20), f"leaked {(base - _free_bytes()) >> 20} MiB over 8 encoder life cycles"
+
+
+def test_async_boundary_device_pointers_streams_and_deferred_errors():
+    """Device-pointer calls do not synchronise the host: kr_encoder_forward returns with the work enqueued on the caller's stream and reports a
+    bad token id at the NEXT call / kr_encoder_check; kr_index_add from a device source and searches under a torch side stream (with a cast and a
+    non-contiguous query produced on that stream) are ordered by the stream, not by hidden syncs."""
+    from kirag_amd import _lib
+    from kirag_amd.retriever.encoders import HipBertForward
+    from kirag_amd.retriever.index import FlatIPIndex
+    cfg = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
+                          max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    w = E.synth_weights(128, 2, 512, 1000, 512, seed=5)
+    ids, mask = E.synth_tokens(64, 40, seed=1, ragged=True, vocab_lo=5, vocab_hi=1000, min_len=3)
+    ref = E.e5_encode(w, ids, mask, 2)
+    h = HipBertForward(cfg, 0); h.load_state(w)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        tid = torch.from_numpy(ids).cuda(); tm = torch.from_numpy(mask).cuda()
+        emb = h.forward(tid, tm, 0)                                   # enqueued on `side`
+        h.check()
+        assert np.abs(emb.cpu().numpy() - ref).max() < 4e-3
+        bad = tid.clone(); bad[3, 1] = 5000
+        out_bad = h.forward(bad, tm, 0)                               # returns: the error is deferred
+        with pytest.raises(_lib.KiragAmdError):
+            h.check()
+        emb2 = h.forward(tid, tm, 0); h.check()                       # the handle is usable again and the flag was cleared
+        assert np.abs(emb2.cpu().numpy() - ref).max() < 4e-3
+        out_bad2 = h.forward(bad, tm, 0)
+        side.synchronize()
+        with pytest.raises(_lib.KiragAmdError):                       # ... or the NEXT call reports it
+            h.forward(tid, tm, 0)
+        # index: device source on the side stream, queries cast + strided on the same stream
+        x = torch.nn.functional.normalize(torch.randn(5000, 128, device="cuda"), dim=1)
+        ix = FlatIPIndex(128); ix.add(x[:2500].double()); ix.add(x[2500:])
+        q16 = (x[:40] + 0.01).half()
+        qs = torch.stack([q16, q16], dim=1)[:, 1]                     # non-contiguous view, fp16: .float().contiguous() runs on `side`
+        sc = torch.empty((40, 10), dtype=torch.float32, device="cuda"); rows = torch.empty((40, 10), dtype=torch.int64, device="cuda")
+        ix.search_into(qs, 10, sc, rows)
+        s_np, i_np = ix.search(qs, 10)
+        side.synchronize()
+    so, io = S.search_canonical(q16.float().cpu().numpy(), x.cpu().numpy(), 10)
+    assert np.array_equal(rows.cpu().numpy(), io) and np.array_equal(i_np, io) and np.array_equal(sc.cpu().numpy().view(np.uint32), so.view(np.uint32))
