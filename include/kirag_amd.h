@@ -66,6 +66,15 @@ int kr_index_dim(const kr_index* ix);
 /* read back fp32 rows [start, start+n) (serialisation: index.py:55-64 writes the flat storage) */
 int kr_index_get_rows(kr_index* ix, int64_t start, int64_t n, float* out, void* stream);
 
+/* Native shard files (SURVEY 8f-1 "native sharded bf16 format"; kirag_amd/retriever/index.py ShardedIndexer.serialize /
+ * deserialize_from, next to the reference's index.py:55-79 formats): the stored state of rows, exactly — fp32 master, 16-bit
+ * scan copy [n, coarse_dim] and the two quantisation bounds — so that a saved shard reloads without re-quantising. */
+int kr_index_coarse_dim(const kr_index* ix);      /* row length of the 16-bit copy (d rounded up to 64) */
+int kr_index_coarse_dtype(const kr_index* ix);    /* KR_COARSE_BF16 / KR_COARSE_F16 */
+int kr_index_get_coarse(kr_index* ix, int64_t start, int64_t n, uint16_t* out, void* stream);
+int kr_index_get_bounds(kr_index* ix, float* out2 /* max |x - c(x)|, max |c(x)| over the stored rows */);
+int kr_index_add_raw(kr_index* ix, const float* xf, const uint16_t* xc, int64_t n, const float* bounds2, void* stream);
+
 /* Indexer.search_knn -> index.search(q, top_docs) (index.py:47): exact inner-product top-k.
  *   q       [nq,d] fp32;  scores [nq,k] fp32 (descending);  rows [nq,k] int64 = internal row numbers
  *   (the caller maps them through index_id_to_db_id exactly as index.py:49 does).

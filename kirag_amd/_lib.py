@@ -47,6 +47,11 @@ SIGNATURES = {
     "kr_index_ntotal": (C.c_int64, [C.c_void_p]),
     "kr_index_dim": (C.c_int, [C.c_void_p]),
     "kr_index_get_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "kr_index_coarse_dim": (C.c_int, [C.c_void_p]),
+    "kr_index_coarse_dtype": (C.c_int, [C.c_void_p]),
+    "kr_index_get_coarse": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "kr_index_get_bounds": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kr_index_add_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "kr_index_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kr_index_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "kr_score_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

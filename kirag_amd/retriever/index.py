@@ -129,6 +129,40 @@ class FlatIPIndex:
         _lib.check(self._lib.kr_index_get_rows(self._h, int(start), int(n), out.ctypes.data, None))
         return out
 
+    def reconstruct_rows(self, rows) -> np.ndarray:
+        """fp32 master rows of arbitrary row numbers (runs of consecutive rows are read together)."""
+        rows = np.asarray(rows, np.int64).reshape(-1)
+        out = np.empty((len(rows), self.d), np.float32)
+        j = 0
+        while j < len(rows):
+            e = j + 1
+            while e < len(rows) and rows[e] == rows[e - 1] + 1:
+                e += 1
+            out[j:e] = self.reconstruct_n(int(rows[j]), e - j)
+            j = e
+        return out
+
+    # ---- stored state, exactly (native shard files) ------------------------------------------------------------------------
+    @property
+    def coarse_dim(self) -> int:
+        return int(self._lib.kr_index_coarse_dim(self._h))
+
+    def coarse_rows(self, start: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.coarse_dim), np.uint16)
+        _lib.check(self._lib.kr_index_get_coarse(self._h, int(start), int(n), out.ctypes.data, None))
+        return out
+
+    def bounds(self) -> np.ndarray:
+        out = np.empty(2, np.float32)
+        _lib.check(self._lib.kr_index_get_bounds(self._h, out.ctypes.data))
+        return out
+
+    def add_raw(self, xf: np.ndarray, xc: np.ndarray, bounds: np.ndarray) -> None:
+        xf = np.ascontiguousarray(xf, np.float32); xc = np.ascontiguousarray(xc, np.uint16); bounds = np.ascontiguousarray(bounds, np.float32)
+        if xf.ndim != 2 or xf.shape[1] != self.d or xc.shape != (xf.shape[0], self.coarse_dim) or bounds.shape != (2,):
+            raise ValueError("add_raw: expected xf [n,d] float32, xc [n,coarse_dim] uint16, bounds [2]")
+        _lib.check(self._lib.kr_index_add_raw(self._h, xf.ctypes.data, xc.ctypes.data, int(xf.shape[0]), bounds.ctypes.data, None))
+
     def stats(self, reset: bool = False) -> dict:
         st = _lib.SearchStats()
         _lib.check(self._lib.kr_index_stats(self._h, C.byref(st), int(reset)))
@@ -213,7 +247,7 @@ class ShardedIndexer(Indexer):
         self.ntotal_global = 0
 
     def index_data(self, ids, embeddings):
-        raise NotImplementedError("ShardedIndexer is filled by deserialize_from() (this rank's share of index.faiss) or by set_local_shard()")
+        raise NotImplementedError("ShardedIndexer is filled by deserialize_from() (this rank's share of the native shards / of index.faiss) or by set_local_shard()")
 
     def set_local_shard(self, local_ids, embeddings):
         """Resident-shard build path (``compute_corpus_embeddings.cal_doc_embeddings(..., indexer=...)`` on every rank): this rank contributes
@@ -233,17 +267,47 @@ class ShardedIndexer(Indexer):
         self.ntotal_global = len(self.index_id_to_db_id)
 
     def deserialize_from(self, dir_path):
-        index_file = os.path.join(dir_path, "index.faiss")
+        """Loads this rank's contiguous share of the rows.  Preferred source: the native shard files written by ``serialize`` (fp32 rows + the 16-bit
+        scan copy + its error bounds: no re-quantisation; any saved world size can be loaded into any other).  Otherwise the reference's
+        ``index.faiss`` (``index.py:66-79``), of which each rank reads only its byte range."""
         meta_file = os.path.join(dir_path, "index_meta.faiss")
-        logger.info(f'Loading rank {self.rank}/{self.world} share of {index_file}, meta data from {meta_file}')
-        self.index = read_faiss_flat_ip(index_file, device=self.index.device, coarse_dtype=self.index.coarse_dtype, row_range=(self.rank, self.world))
+        manifest = os.path.join(dir_path, SHARD_MANIFEST)
+        if os.path.exists(manifest):
+            logger.info(f'Loading rank {self.rank}/{self.world} share of the native shards in {dir_path}')
+            self.index = read_native_shards(dir_path, device=self.index.device, coarse_dtype=self.index.coarse_dtype, row_range=(self.rank, self.world))
+        else:
+            index_file = os.path.join(dir_path, "index.faiss")
+            logger.info(f'Loading rank {self.rank}/{self.world} share of {index_file}, meta data from {meta_file}')
+            self.index = read_faiss_flat_ip(index_file, device=self.index.device, coarse_dtype=self.index.coarse_dtype, row_range=(self.rank, self.world))
         with open(meta_file, "rb") as reader:
             self.index_id_to_db_id = pickle.load(reader)
         self.row_offset, self.ntotal_global = self.index.row_offset, self.index.file_ntotal
         assert len(self.index_id_to_db_id) == self.ntotal_global, 'Deserialized index_id_to_db_id should match faiss index size'
 
     def serialize(self, dir_path):
-        raise NotImplementedError("serialize() a ShardedIndexer from rank-local shards is not implemented; build the files with faiss_index_corpus")
+        """Collective.  Every rank writes its resident rows as one native shard file (``index_shard_RRRR_of_WWWW.krshard``); rank 0 also writes the
+        manifest (``kirag_shards.json``) and ``index_meta.faiss`` — the reference's pickled int64 id map (``index.py:63-64``), so the meta file is
+        the one every other tool of the reference expects.  ``index.faiss`` itself is NOT written (a 5M x 1024 index is 20 GB that would have to
+        funnel through one rank); ``faiss_index_corpus`` / ``Indexer.serialize`` produce it when a single-host index is wanted."""
+        import torch.distributed as dist
+        os.makedirs(dir_path, exist_ok=True)
+        n_local = self.index.ntotal
+        write_native_shard(self.index, os.path.join(dir_path, shard_file_name(self.rank, self.world)), self.row_offset, self.ntotal_global)
+        info = [None] * self.world
+        mine = {"rank": self.rank, "row0": int(self.row_offset), "rows": int(n_local), "file": shard_file_name(self.rank, self.world)}
+        if self.world > 1:
+            dist.all_gather_object(info, mine, group=self.group)
+        else:
+            info = [mine]
+        if self.rank == 0:
+            import json
+            with open(os.path.join(dir_path, SHARD_MANIFEST), "w") as f:
+                json.dump({"format": "krshard-1", "d": self.index.d, "coarse_dim": self.index.coarse_dim, "coarse_dtype": self.index.coarse_dtype,
+                           "ntotal": int(self.ntotal_global), "world": self.world, "shards": sorted(info, key=lambda e: e["row0"])}, f, indent=1)
+            with open(os.path.join(dir_path, "index_meta.faiss"), mode='wb') as f:
+                pickle.dump(self.index_id_to_db_id, f)
+        if self.world > 1:
+            dist.barrier(group=self.group)
 
     def search_knn(self, query_vectors, top_docs: int, index_batch_size=1024, verbose: bool = True):
         from ..parallel import ShardedSearcher
@@ -266,7 +330,9 @@ class ShardedIndexer(Indexer):
 # faiss flat-index file layout.  faiss is a third-party dependency of the reference (requirements.txt:10) and
 # its source is not on disk here: the layout below restates faiss 1.8 `write_index` for IndexFlat from its
 # published io code (impl/index_write.cpp: fourcc, write_index_header, WRITEXBVECTOR) and is UNVERIFIED
-# against a real faiss build in this environment.
+# against a real faiss build in this environment: tests/test_capi_and_host.py pins the writer to a hand-assembled
+# byte string of that field list (header 4+4+8+8+8+1+4 = 37 bytes, then the WRITEXBVECTOR count = payload bytes / 4),
+# which guards the layout against regressions but is NOT a round trip through faiss.
 #   u32  fourcc "IxFI"
 #   i32  d ; i64 ntotal ; i64 dummy (1<<20) ; i64 dummy (1<<20) ; u8 is_trained ; i32 metric_type (0 = IP)
 #   u64  number of float32 values (= ntotal * d) ; float32[ntotal * d] row-major
@@ -311,4 +377,81 @@ def read_faiss_flat_ip(path: str, device: Optional[int] = None, coarse_dtype: st
             buf = np.frombuffer(f.read(m * d * 4), dtype=np.float32).reshape(m, d)
             index.add(buf)
         index.file_ntotal, index.row_offset = n, a
+    return index
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Native shard files: what one rank's FlatIPIndex holds, byte for byte, so that a reload does not re-quantise.
+#   bytes 0..7    magic  b"KRSHARD1"
+#   i32 d ; i32 coarse_dim ; i32 coarse_dtype (0 bf16, 1 f16) ; i32 reserved = 0
+#   i64 row0 (first global row) ; i64 rows ; i64 ntotal (rows of the whole corpus)
+#   f32 bounds[2]   max |x - c(x)|_2 , max |c(x)|_2 over the rows of the index that wrote the file
+#   f32 [rows, d]   master rows ; u16 [rows, coarse_dim]  scan copy
+# ---------------------------------------------------------------------------------------------------------
+SHARD_MANIFEST = "kirag_shards.json"
+_SHARD_MAGIC = b"KRSHARD1"
+_SHARD_HEADER = struct.Struct("<8siiiiqqqff")
+
+
+def shard_file_name(rank: int, world: int) -> str:
+    return f"index_shard_{rank:04d}_of_{world:04d}.krshard"
+
+
+def write_native_shard(index: FlatIPIndex, path: str, row0: int, ntotal: int) -> None:
+    n, d, dc = index.ntotal, index.d, index.coarse_dim
+    b = index.bounds() if n else np.zeros(2, np.float32)
+    with open(path, "wb") as f:
+        f.write(_SHARD_HEADER.pack(_SHARD_MAGIC, d, dc, {"bf16": 0, "f16": 1}[index.coarse_dtype], 0, int(row0), n, int(ntotal), float(b[0]), float(b[1])))
+        for s in range(0, n, _IO_CHUNK_ROWS):
+            f.write(index.reconstruct_n(s, min(_IO_CHUNK_ROWS, n - s)).tobytes())
+        for s in range(0, n, _IO_CHUNK_ROWS):
+            f.write(index.coarse_rows(s, min(_IO_CHUNK_ROWS, n - s)).tobytes())
+
+
+def read_native_shards(dir_path: str, device: Optional[int] = None, coarse_dtype: str = "bf16", row_range=None) -> FlatIPIndex:
+    """Rows [a, b) of the corpus (``row_range = (rank, world)``: that rank's contiguous share; None: everything) from whichever shard files hold
+    them — the loading world size need not be the saving one.  The 16-bit copy is taken from the files when their dtype matches ``coarse_dtype``
+    (bounds = the maximum over the files read, which is valid for any subset of their rows), otherwise the rows are re-quantised."""
+    import json
+    with open(os.path.join(dir_path, SHARD_MANIFEST)) as f:
+        man = json.load(f)
+    if man.get("format") != "krshard-1":
+        raise ValueError(f"{dir_path}: unknown shard format {man.get('format')!r}")
+    n, d = int(man["ntotal"]), int(man["d"])
+    a, b = 0, n
+    if row_range is not None:
+        rank, world = row_range
+        per = (n + world - 1) // world
+        a, b = min(rank * per, n), min((rank + 1) * per, n)
+    index = FlatIPIndex(d, device=device, coarse_dtype=coarse_dtype)
+    index.reserve(b - a)
+    raw = man["coarse_dtype"] == coarse_dtype
+    covered = a
+    for sh in man["shards"]:
+        r0, rows = int(sh["row0"]), int(sh["rows"])
+        lo, hi = max(a, r0), min(b, r0 + rows)
+        if lo >= hi:
+            continue
+        if lo != covered:
+            raise ValueError(f"{dir_path}: rows [{covered}, {lo}) are in no shard file")
+        with open(os.path.join(dir_path, sh["file"]), "rb") as f:
+            magic, fd, fdc, fct, _, fr0, frows, fnt, b0, b1 = _SHARD_HEADER.unpack(f.read(_SHARD_HEADER.size))
+            if magic != _SHARD_MAGIC or fd != d or fr0 != r0 or frows != rows or fnt != n:
+                raise ValueError(f"{sh['file']}: header does not match the manifest")
+            base_f = _SHARD_HEADER.size
+            base_c = base_f + rows * d * 4
+            for s0 in range(lo, hi, _IO_CHUNK_ROWS):
+                m = min(_IO_CHUNK_ROWS, hi - s0)
+                f.seek(base_f + (s0 - r0) * d * 4)
+                xf = np.frombuffer(f.read(m * d * 4), dtype=np.float32).reshape(m, d)
+                if raw and fdc == index.coarse_dim:
+                    f.seek(base_c + (s0 - r0) * fdc * 2)
+                    xc = np.frombuffer(f.read(m * fdc * 2), dtype=np.uint16).reshape(m, fdc)
+                    index.add_raw(xf, xc, np.array([b0, b1], np.float32))
+                else:
+                    index.add(xf)
+        covered = hi
+    if covered != b:
+        raise ValueError(f"{dir_path}: rows [{covered}, {b}) are in no shard file")
+    index.file_ntotal, index.row_offset = n, a
     return index

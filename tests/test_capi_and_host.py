@@ -264,3 +264,32 @@ def test_corpus_embedding_shard_files_and_index_builder(tmp_path):
     assert ids == [str(7 * i + 1) for i in range(53)]
     ref = ret.doc(col.encode_doc([corpus[i]["passage"] for i in range(53)]))
     torch.testing.assert_close(full, ref.detach())
+
+
+def test_faiss_flat_file_layout_byte_for_byte(tmp_path):
+    """index.faiss as faiss 1.8 writes an IndexFlatIP (impl/index_write.cpp: fourcc "IxFI"; write_index_header = int d, idx_t ntotal, two idx_t
+    dummies of 1 << 20, bool is_trained, int metric_type (0 = METRIC_INNER_PRODUCT, no metric_arg); then WRITEXBVECTOR(codes): size_t count =
+    bytes / 4, then the raw float32 rows).  The expected bytes are assembled by hand from that field list — this pins our writer / reader to the
+    published layout; it is NOT a round trip through faiss (not installable here), so interoperability stays unverified."""
+    import struct
+    from kirag_amd.retriever import index as I
+
+    class Rows:                                                   # the three members write_faiss_flat_ip touches
+        d = 4; ntotal = 3
+        x = np.arange(12, dtype=np.float32).reshape(3, 4) / 8 - 0.5
+        def reconstruct_n(self, s, n): return self.x[s:s + n]
+    path = str(tmp_path / "index.faiss")
+    I.write_faiss_flat_ip(Rows(), path)
+    want = (b"IxFI" + struct.pack("<i", 4) + struct.pack("<q", 3) + struct.pack("<q", 1 << 20) * 2 + bytes([1]) + struct.pack("<i", 0)
+            + struct.pack("<Q", 12) + Rows.x.tobytes())
+    got = open(path, "rb").read()
+    assert len(want) == 4 + (4 + 8 + 8 + 8 + 1 + 4) + 8 + 48 and got == want
+    # the reader's header parse (device-free part): wrong fourcc / metric / payload count are rejected before any allocation
+    for bad, msg in ((b"IxF2" + want[4:], "not a faiss IndexFlatIP"), (want[:33] + struct.pack("<i", 1) + want[37:], "metric_type"),
+                     (want[:37] + struct.pack("<Q", 11) + want[45:], "payload")):
+        with open(path, "wb") as f:
+            f.write(bad)
+        with pytest.raises(ValueError) as ei:
+            I.read_faiss_flat_ip(path)
+        assert msg in str(ei.value)
+    assert I._SHARD_HEADER.size == 8 + 16 + 24 + 8 and I.shard_file_name(3, 8) == "index_shard_0003_of_0008.krshard"

@@ -87,6 +87,28 @@ def _worker_indexer(rank, world, port, folder, ret):
             assert ids == eids and np.array_equal(np.asarray(sc).view(np.uint32), np.asarray(esc).view(np.uint32))
         with pytest.raises(ValueError):
             sh.search_knn(q, 4000, verbose=False)
+        # native shard files: collective serialize of the resident shards, reload WITHOUT re-quantising (same world size), bit-equal state and results
+        nat = os.path.join(folder, "native")
+        sh2.serialize(nat)
+        sh3 = ShardedIndexer(64); sh3.deserialize_from(nat)
+        assert sh3.row_offset == a and sh3.ntotal_global == 3001 and sh3.index.ntotal == b - a
+        assert np.array_equal(sh3.index.reconstruct_n(0, b - a), x[a:b])
+        assert np.array_equal(sh3.index.coarse_rows(0, b - a), sh2.index.coarse_rows(0, b - a))
+        assert np.array_equal(sh3.index.bounds(), sh2.index.bounds()) and np.array_equal(sh3.index_id_to_db_id, full.index_id_to_db_id)
+        got3 = sh3.search_knn(q, 25, verbose=False)
+        for (ids, sc), (eids, esc) in zip(got3, expected):
+            assert ids == eids and np.array_equal(np.asarray(sc).view(np.uint32), np.asarray(esc).view(np.uint32))
+        if rank == 0:
+            # a different world size at load time: everything into one index (rows from both files), and an f16 index (re-quantised from the fp32 rows)
+            from kirag_amd.retriever.index import read_native_shards
+            for dt in ("bf16", "f16"):
+                one = read_native_shards(nat, device=0, coarse_dtype=dt)
+                assert one.ntotal == 3001 and np.array_equal(one.reconstruct_n(0, 3001), x)
+                s1, i1 = one.search(q, 25)
+                for r, (eids, esc) in enumerate(expected):
+                    assert [str(full.index_id_to_db_id[j]) for j in i1[r]] == eids and np.array_equal(s1[r].view(np.uint32), np.asarray(esc).view(np.uint32))
+            third = read_native_shards(nat, device=0, row_range=(1, 3))            # rank 1 of 3: rows [1001, 2002) straddle the two files
+            assert third.row_offset == 1001 and third.ntotal == 1001 and np.array_equal(third.reconstruct_n(0, 1001), x[1001:2002])
         ret[rank] = "ok"
     except Exception:
         import traceback
