@@ -43,6 +43,11 @@ def setup_parser(argv=None):
     # MI355X path: passages per encoder launch (rows are batch-invariant, so this changes speed only)
     parser.add_argument("--encode_batch_size", type=int, default=512)
     parser.add_argument("--prefetch_batches", type=int, default=2, help="batches tokenised ahead of the GPU on a background thread")
+    parser.add_argument("--tokenizer_workers", type=int, default=0,
+                        help="> 0: tokenise in that many worker PROCESSES (each with its own tokenizer; batches come back in order) instead of "
+                             "one background thread - for hosts where one tokenizer cannot keep the encoder fed")
+    parser.add_argument("--no_embedding_files", action="store_true",
+                        help="do not write corpus_embeddings_*.pkl / passage_id_list_*.pkl (streamed encode straight into a resident index shard)")
     return parser.parse_args(argv)
 
 
@@ -78,26 +83,88 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
             pickle.dump(buf_ids, f)
         buf, buf_ids, file_start = [], [], upto
 
-    def collate(s):                                          # runs on the prefetch thread: dataset access + tokenisation of batch i+1, i+2
+    def collate(s):                                          # runs on the prefetch thread (or in a worker process): dataset access + tokenisation
         items = [corpus_dataset[i] for i in range(s, min(s + bs, end))]
         return collator.encode_doc([it["passage"] for it in items]), [corpus_dataset.index_to_passage_id[it["index"]] for it in items]
 
-    for cpu_inputs, ids in prefetch_map(collate, range(start, end, bs), depth=int(getattr(args, "prefetch_batches", 2))):
-        inputs = to_device(cpu_inputs, device)
-        emb = model.doc(inputs).detach()                     # HIP path (eval mode), stays on the GPU
+    write_files = not bool(getattr(args, "no_embedding_files", False))
+    depth = int(getattr(args, "prefetch_batches", 2))
+    workers = int(getattr(args, "tokenizer_workers", 0))
+    batches = range(start, end, bs)
+    source = pool_map(collate, batches, workers, depth) if workers > 0 else prefetch_map(collate, batches, depth=depth)
+    # The GPU side never waits for the host inside the loop: inputs go up from pinned memory, the forward (device output: asynchronous,
+    # kr_encoder_forward) and the append to the resident shard are enqueued on the current stream, the embeddings come down into a small ring of
+    # pinned buffers behind an event; the host consumes batch i - 2 (file buffers) while batch i is being encoded.
+    ring, pending = [], []
+
+    def drain(keep):
+        nonlocal buf, buf_ids, file_start
+        while len(pending) > keep:
+            ev, host, n_rows, ids = pending.pop(0)
+            ev.synchronize()
+            emb = host[:n_rows].clone()
+            ring.append(host)
+            while len(buf_ids) + len(ids) > cap:             # respect the per-file row cap
+                take = cap - len(buf_ids)
+                buf.append(emb[:take]); buf_ids.extend(ids[:take])
+                flush(file_start + cap)
+                emb, ids = emb[take:], ids[take:]
+            buf.append(emb); buf_ids.extend(ids)
+            if len(buf_ids) == cap:
+                flush(file_start + cap)
+
+    hidden = None
+    for cpu_inputs, ids in source:
+        inputs = {k: (v.pin_memory().to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in cpu_inputs.items()}
+        emb = model.doc(inputs).detach()                     # HIP path (eval mode), stays on the GPU; no host synchronisation
         if indexer is not None:
-            indexer.index_data(ids, emb)                     # device-to-device append into the resident shard
-        emb = emb.cpu()
-        while len(buf_ids) + len(ids) > cap:                 # respect the per-file row cap
-            take = cap - len(buf_ids)
-            buf.append(emb[:take]); buf_ids.extend(ids[:take])
-            flush(file_start + cap)
-            emb, ids = emb[take:], ids[take:]
-        buf.append(emb); buf_ids.extend(ids)
-        if len(buf_ids) == cap:
-            flush(file_start + cap)
+            indexer.index_data(ids, emb)                     # device-to-device append into the resident shard (stream-ordered)
+        if write_files:
+            hidden = emb.shape[1]
+            host = ring.pop() if ring and ring[-1].shape[0] >= emb.shape[0] else torch.empty((bs, hidden), dtype=torch.float32, pin_memory=True)
+            host[:emb.shape[0]].copy_(emb, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+            pending.append((ev, host, emb.shape[0], ids))
+            drain(2)
+    drain(0)
     flush(end)
+    enc = getattr(getattr(model, "encoder", None), "_hip", None)
+    if enc is not None:
+        enc.check()                                          # token ids outside the vocabulary surface here at the latest
     return start, end
+
+
+def pool_map(fn, items, workers: int, depth: int):
+    """Ordered ``map(fn, items)`` over ``workers`` forked processes, at most ``workers + depth`` batches ahead of the consumer.  The closure
+    (dataset, collator, tokenizer) is inherited by fork, only the small integer items and the tokenised batches cross the pipes.
+    HF fast tokenizers already use a Rust thread pool inside one call; separate processes help when the Python side of the collate
+    (dataset access, string building) or a slow tokenizer is the limit.  Call before the parent has created threads that hold locks."""
+    import multiprocessing as mp
+    os.environ.setdefault("TOKENIZERS_PARALLELISM", "false")   # one tokenizer thread per worker process: no oversubscription
+    global _POOL_FN
+    _POOL_FN = fn
+    ctx = mp.get_context("fork")
+    with ctx.Pool(processes=workers) as pool:
+        it = iter(items)
+        inflight = []
+        for _ in range(workers + max(1, depth)):
+            x = next(it, None)
+            if x is None:
+                break
+            inflight.append(pool.apply_async(_pool_call, (x,)))
+        while inflight:
+            res = inflight.pop(0).get()
+            x = next(it, None)
+            if x is not None:
+                inflight.append(pool.apply_async(_pool_call, (x,)))
+            yield res
+
+
+_POOL_FN = None
+
+
+def _pool_call(x):
+    return _POOL_FN(x)
 
 
 def main(argv=None):

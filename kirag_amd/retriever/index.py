@@ -245,9 +245,35 @@ class ShardedIndexer(Indexer):
         super().__init__(vector_sz, metric=metric, n_subquantizers=n_subquantizers, n_bits=n_bits, device=device, coarse_dtype=coarse_dtype)
         self.row_offset = 0
         self.ntotal_global = 0
+        self._local_ids = []
+        self._dirty = False
 
     def index_data(self, ids, embeddings):
-        raise NotImplementedError("ShardedIndexer is filled by deserialize_from() (this rank's share of the native shards / of index.faiss) or by set_local_shard()")
+        """Streamed build (``cal_doc_embeddings(..., indexer=this)`` on every rank, BASELINE config 4: "streamed encode + search"): appends this
+        rank's rows to its resident shard — device tensors go in device-to-device, stream-ordered — and remembers their ids.  Not collective;
+        the global id map and the row offsets are exchanged by ``sync_shards()``, which ``search_knn`` / ``serialize`` call when needed."""
+        if isinstance(embeddings, np.ndarray):
+            embeddings = embeddings.astype('float32')
+        self.index.add(embeddings)
+        self._local_ids.append(np.array(ids, dtype=np.int64))
+        self._dirty = True
+
+    def sync_shards(self):
+        """Collective: assemble ``index_id_to_db_id`` (all ranks' ids in rank order), ``row_offset`` and ``ntotal_global`` after ``index_data`` calls."""
+        import torch.distributed as dist
+        if not self._dirty:
+            return
+        local = np.concatenate(self._local_ids, axis=0) if self._local_ids else np.empty((0), dtype=np.int64)
+        parts = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(parts, local, group=self.group)
+        else:
+            parts = [local]
+        self.row_offset = int(sum(len(p) for p in parts[: self.rank]))
+        self.index_id_to_db_id = np.concatenate(parts, axis=0)
+        self.ntotal_global = len(self.index_id_to_db_id)
+        self._local_ids = [local]
+        self._dirty = False
 
     def set_local_shard(self, local_ids, embeddings):
         """Resident-shard build path (``compute_corpus_embeddings.cal_doc_embeddings(..., indexer=...)`` on every rank): this rank contributes
@@ -265,6 +291,7 @@ class ShardedIndexer(Indexer):
         self.row_offset = int(sum(len(p) for p in parts[: self.rank]))
         self.index_id_to_db_id = np.concatenate(parts, axis=0)
         self.ntotal_global = len(self.index_id_to_db_id)
+        self._local_ids, self._dirty = [local], False
 
     def deserialize_from(self, dir_path):
         """Loads this rank's contiguous share of the rows.  Preferred source: the native shard files written by ``serialize`` (fp32 rows + the 16-bit
@@ -290,6 +317,7 @@ class ShardedIndexer(Indexer):
         the one every other tool of the reference expects.  ``index.faiss`` itself is NOT written (a 5M x 1024 index is 20 GB that would have to
         funnel through one rank); ``faiss_index_corpus`` / ``Indexer.serialize`` produce it when a single-host index is wanted."""
         import torch.distributed as dist
+        self.sync_shards()
         os.makedirs(dir_path, exist_ok=True)
         n_local = self.index.ntotal
         write_native_shard(self.index, os.path.join(dir_path, shard_file_name(self.rank, self.world)), self.row_offset, self.ntotal_global)
@@ -311,6 +339,7 @@ class ShardedIndexer(Indexer):
 
     def search_knn(self, query_vectors, top_docs: int, index_batch_size=1024, verbose: bool = True):
         from ..parallel import ShardedSearcher
+        self.sync_shards()
         if isinstance(query_vectors, np.ndarray):
             query_vectors = query_vectors.astype('float32')
         if top_docs > self.ntotal_global:

@@ -212,3 +212,80 @@ def test_g4_g5_g6_on_the_gpu(golden):
         loss.backward()
         gw = ret.encoder.encoder.layer[0].attention.self.query.weight.grad
         assert gw is not None and torch.isfinite(gw).all() and float(gw.abs().sum()) > 0
+
+
+def test_config4_flow_streamed_bge_encode_into_resident_shard_then_search(golden, tmp_path):
+    """BASELINE config 4's flow (bge-large 'streamed encode + search') at test size: 200k synthetic passages through BGECollator (no passage
+    prefix) -> BGE encoder (CLS pooling) on the HIP path -> straight into a resident ShardedIndexer shard (no embedding files, no host round trip
+    per batch: compute_corpus_embeddings.py:77-125 without the gather / torch.cat), then queries through BGECollator.encode_query
+    (instruction prefix) -> search_knn.  Checks: every passage indexed exactly once and in corpus order, stored rows == a direct batch of the
+    same passages (batch invariance) == the numpy oracle's BGE forward (<= 4e-3), search results == the C oracle on the stored rows, native
+    shard round trip; both tokenisation feeds (prefetch thread, worker processes) give identical rows."""
+    import time
+    from transformers import BertConfig, BertTokenizerFast
+    from kirag_amd import compute_corpus_embeddings as CC
+    from kirag_amd.collators import BGECollator
+    from kirag_amd.retriever.encoders import BGEEncoder
+    from kirag_amd.retriever.index import ShardedIndexer
+    from kirag_amd.retriever.retrievers import InBatchRetriever
+    with tempfile.TemporaryDirectory() as td:
+        g = golden("g4_g8_retriever.npz")
+        H, L, heads, FF, vocab, max_pos = [int(v) for v in g["cfg"]]
+        cfg = BertConfig(vocab_size=vocab, hidden_size=H, num_hidden_layers=L, num_attention_heads=heads, intermediate_size=FF, max_position_embeddings=max_pos)
+        m = BGEEncoder(cfg, add_pooling_layer=False)
+        w = E.synth_weights(H, L, FF, vocab, max_pos, seed=int(g["weight_seed"]))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+        m.save_pretrained(td)
+        with open(os.path.join(td, "vocab.txt"), "w") as f:
+            f.write("\n".join(str(v) for v in g["vocab"]) + "\n")
+        tok = BertTokenizerFast(vocab_file=os.path.join(td, "vocab.txt"), do_lower_case=True)
+        ret = InBatchRetriever("BGERetriever", td, temperature=0.01)
+        col = BGECollator(tokenizer=tok, query_maxlength=32, doc_maxlength=32)
+        rng = np.random.default_rng(5)
+        words = np.array([str(v) for v in g["vocab"] if str(v).isalpha() and len(str(v)) > 1])
+        n = 200_000
+        lens = rng.integers(4, 26, n)
+        flat = rng.choice(words, int(lens.sum()))
+        cuts = np.concatenate([[0], np.cumsum(lens)])
+
+        class Corpus:
+            index_to_passage_id = {i: str(2 * i + 7) for i in range(n)}
+            def __len__(self): return n
+            def passage(self, i): return "title:  " + flat[cuts[i]] + ", text:  " + " ".join(flat[cuts[i] + 1:cuts[i + 1]])
+            def __getitem__(self, i): return {"index": i, "passage": self.passage(i)}
+        corpus = Corpus()
+        args = SimpleNamespace(local_rank=-1, save_dir=str(tmp_path), name="bge", index_folder="c", per_gpu_batch_size=8, num_passage_per_index_file=1_000_000,
+                               encode_batch_size=2048, prefetch_batches=4, tokenizer_workers=0, no_embedding_files=True)
+        resident = ShardedIndexer(H)
+        t0 = time.perf_counter()
+        CC.cal_doc_embeddings(args, ret, corpus, col, indexer=resident)
+        dt = time.perf_counter() - t0
+        print(f"[config-4 flow] {n} passages streamed into the resident shard in {dt:.1f} s = {n / dt:.0f} passages/s (tiny encoder: the tokenizer feed is the limit)")
+        assert resident.index.ntotal == n and not [f for f in os.listdir(os.path.join(str(tmp_path), "bge", "c")) if f.endswith(".pkl")]
+        qtexts = [" ".join(flat[cuts[i] + 1:cuts[i + 1]]) for i in (5, 70_000, 199_999)] + ["capital of france"]
+        qa = col.encode_query(qtexts)
+        qv = ret.query({k: v.cuda() for k, v in qa.items()}).cpu().numpy()
+        res = resident.search_knn(qv, 10, verbose=False)
+        assert resident.ntotal_global == n and resident.index_id_to_db_id[:3].tolist() == [7, 9, 11] and resident.index_id_to_db_id[-1] == 2 * (n - 1) + 7
+        x = resident.index.reconstruct_n(0, n)
+        so, io = S.search_canonical(qv, x, 10)
+        for r in range(4):
+            assert res[r][0] == [str(2 * j + 7) for j in io[r]] and np.array_equal(res[r][1].view(np.uint32), so[r].view(np.uint32))
+        assert res[0][0][0] == str(2 * 5 + 7) and res[2][0][0] == str(2 * 199_999 + 7)              # a passage's own text retrieves it
+        pick = rng.choice(n, 64, replace=False)
+        a = col.encode_doc([corpus.passage(int(i)) for i in pick])
+        direct = ret.doc({k: v.cuda() for k, v in a.items()}).cpu().numpy()
+        assert np.array_equal(direct, x[pick])                                                        # batch invariance: bit-equal rows
+        ref = E.bge_encode(w, a["input_ids"].numpy(), a["attention_mask"].numpy(), heads)
+        assert np.abs(direct - ref).max() <= 4e-3
+        # the same stream tokenised by worker processes, a smaller slice: identical rows
+        args2 = SimpleNamespace(**{**vars(args), "tokenizer_workers": 4})
+        small = type("C2", (), {"index_to_passage_id": corpus.index_to_passage_id, "__len__": lambda s: 20_000, "__getitem__": lambda s, i: corpus[i]})()
+        res2 = ShardedIndexer(H)
+        CC.cal_doc_embeddings(args2, ret, small, col, indexer=res2)
+        assert res2.index.ntotal == 20_000 and np.array_equal(res2.index.reconstruct_n(0, 20_000), x[:20_000])
+        nat = os.path.join(str(tmp_path), "native")
+        resident.serialize(nat)
+        back = ShardedIndexer(H); back.deserialize_from(nat)
+        res3 = back.search_knn(qv, 10, verbose=False)
+        assert all(res3[r][0] == res[r][0] and np.array_equal(res3[r][1], res[r][1]) for r in range(4))

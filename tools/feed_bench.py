@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""can the host keep the encoder fed?  Measures, on the GPU box,
+  (a) the tokenizer alone (HF BertTokenizerFast, synthetic 30522-entry WordPiece vocab, ~110-token passages, batches of 512): one Rust thread,
+      the tokenizer's own thread pool, N worker processes;
+  (b) compute_corpus_embeddings.cal_doc_embeddings end to end at the e5-large shape (synthetic weights), prefetch_batches in {2, 8} and
+      tokenizer_workers in {0, 8}, against the encoder's rate on pre-tokenised, device-resident batches.
+Usage: python tools/feed_bench.py [passages]"""
+import os, sys, tempfile, time
+from types import SimpleNamespace
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40_000
+rng = np.random.default_rng(0)
+letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
+def rand_words(k, lo, hi):
+    out = set()
+    while len(out) < k:
+        out.add("".join(rng.choice(letters, int(rng.integers(lo, hi)))))
+    return sorted(out)
+words = rand_words(20000, 3, 9); pieces = ["##" + w for w in rand_words(10517, 2, 5)]
+td = tempfile.mkdtemp()
+with open(os.path.join(td, "vocab.txt"), "w") as f:
+    f.write("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words + pieces) + "\n")
+wa = np.array(words); pa = np.array([p[2:] for p in pieces])
+def passage():
+    k = int(rng.integers(60, 100))
+    ws = rng.choice(wa, k)
+    glue = rng.random(k) < 0.3                                   # 30 % of the words carry a suffix piece -> real WordPiece work
+    return "title:  " + ws[0] + ", text:  " + " ".join(w + (s if g else "") for w, s, g in zip(ws[1:], rng.choice(pa, k - 1), glue[1:]))
+texts = [passage() for _ in range(n)]
+
+def tok_rate(parallel, label):
+    os.environ["TOKENIZERS_PARALLELISM"] = "true" if parallel else "false"
+    from transformers import BertTokenizerFast
+    tok = BertTokenizerFast(vocab_file=os.path.join(td, "vocab.txt"), do_lower_case=True)
+    tok(["passage: " + t for t in texts[:512]], max_length=128, padding=True, truncation=True, return_tensors="pt")
+    t0 = time.perf_counter(); ntok = 0
+    for s in range(0, n, 512):
+        e = tok(["passage: " + t for t in texts[s:s + 512]], max_length=128, padding=True, truncation=True, return_tensors="pt")
+        ntok += int(e["attention_mask"].sum())
+    dt = time.perf_counter() - t0
+    print(f"[tokenizer] {label}: {n / dt:.0f} passages/s ({ntok / n:.0f} tokens per passage)", flush=True)
+    return tok
+
+import subprocess
+if os.environ.get("FEED_BENCH_CHILD") == "single":
+    tok_rate(False, "one Rust thread (TOKENIZERS_PARALLELISM=false)"); sys.exit(0)
+subprocess.run([sys.executable, __file__, str(n)], env={**os.environ, "FEED_BENCH_CHILD": "single"})     # the setting is read once per process
+tok = tok_rate(True, f"tokenizer's own thread pool ({os.cpu_count()} cpus visible)")
+
+import torch
+from kirag_amd import bench_support as BS
+from kirag_amd import compute_corpus_embeddings as CC
+from kirag_amd.collators import E5Collator
+dev = torch.device("cuda:0")
+hip = BS.make_hip_encoder(dev)
+class Model:
+    encoder = SimpleNamespace(_hip=hip)
+    def to(self, d): return self
+    def eval(self): return self
+    def doc(self, a): return hip.forward(a["input_ids"], a["attention_mask"], 0)
+class Corpus:
+    index_to_passage_id = {i: str(i) for i in range(n)}
+    def __len__(self): return n
+    def __getitem__(self, i): return {"index": i, "passage": texts[i]}
+col = E5Collator(tokenizer=tok, query_maxlength=128, doc_maxlength=128)
+# encoder alone on pre-tokenised resident batches
+a = col.encode_doc(texts[:512]); ids = a["input_ids"].to(dev); mask = a["attention_mask"].to(dev)
+hip.forward(ids, mask, 0); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    hip.forward(ids, mask, 0)
+torch.cuda.synchronize()
+enc_rate = 20 * 512 / (time.perf_counter() - t0)
+print(f"[encoder] pre-tokenised resident batches of 512: {enc_rate:.0f} passages/s", flush=True)
+for depth, workers in ((2, 0), (8, 0), (2, 8), (8, 8)):
+    args = SimpleNamespace(local_rank=-1, save_dir=td, name="f", index_folder=f"d{depth}w{workers}", per_gpu_batch_size=8, num_passage_per_index_file=10**9,
+                           encode_batch_size=512, prefetch_batches=depth, tokenizer_workers=workers, no_embedding_files=True)
+    t0 = time.perf_counter()
+    CC.cal_doc_embeddings(args, Model(), Corpus(), col, device=dev)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"[end to end] prefetch_batches={depth} tokenizer_workers={workers}: {n / dt:.0f} passages/s = {n / dt / enc_rate * 100:.0f} % of the encoder-only rate", flush=True)
