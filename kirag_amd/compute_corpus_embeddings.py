@@ -91,7 +91,10 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
     depth = int(getattr(args, "prefetch_batches", 2))
     workers = int(getattr(args, "tokenizer_workers", 0))
     batches = range(start, end, bs)
-    source = pool_map(collate, batches, workers, depth) if workers > 0 else prefetch_map(collate, batches, depth=depth)
+    def make_texts(s):
+        items = [corpus_dataset[i] for i in range(s, min(s + bs, end))]
+        return [it["passage"] for it in items], [corpus_dataset.index_to_passage_id[it["index"]] for it in items]
+    source = pool_map(make_texts, collator, batches, workers, depth) if workers > 0 else prefetch_map(collate, batches, depth=depth)
     # The GPU side never waits for the host inside the loop: inputs go up from pinned memory, the forward (device output: asynchronous,
     # kr_encoder_forward) and the append to the resident shard are enqueued on the current stream, the embeddings come down into a small ring of
     # pinned buffers behind an event; the host consumes batch i - 2 (file buffers) while batch i is being encoded.
@@ -134,37 +137,83 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
     return start, end
 
 
-def pool_map(fn, items, workers: int, depth: int):
-    """Ordered ``map(fn, items)`` over ``workers`` forked processes, at most ``workers + depth`` batches ahead of the consumer.  The closure
-    (dataset, collator, tokenizer) is inherited by fork, only the small integer items and the tokenised batches cross the pipes.
-    HF fast tokenizers already use a Rust thread pool inside one call; separate processes help when the Python side of the collate
-    (dataset access, string building) or a slow tokenizer is the limit.  Call before the parent has created threads that hold locks."""
-    import multiprocessing as mp
-    os.environ.setdefault("TOKENIZERS_PARALLELISM", "false")   # one tokenizer thread per worker process: no oversubscription
-    global _POOL_FN
-    _POOL_FN = fn
-    ctx = mp.get_context("fork")
-    with ctx.Pool(processes=workers) as pool:
-        it = iter(items)
-        inflight = []
-        for _ in range(workers + max(1, depth)):
-            x = next(it, None)
-            if x is None:
-                break
-            inflight.append(pool.apply_async(_pool_call, (x,)))
-        while inflight:
-            res = inflight.pop(0).get()
-            x = next(it, None)
-            if x is not None:
-                inflight.append(pool.apply_async(_pool_call, (x,)))
-            yield res
+def pool_map(make_texts, collator, items, workers: int, depth: int):
+    """Ordered map over ``workers`` tokenizer PROCESSES (``python -m kirag_amd.tokenize_worker``, started as plain child processes: no fork of a
+    process that holds a GPU context and a tokenizer thread pool, no re-import of the caller's ``__main__``).  For every item the parent builds the
+    batch's strings (``make_texts(item) -> (texts, ids)``: dataset access stays in the parent), worker ``j % workers`` tokenises batch j with its own
+    copy of the collator (one Rust thread each), and the batches are yielded in order, at most ``workers + depth`` ahead of the consumer."""
+    import struct
+    import subprocess
+    import sys
+    import threading
+    import numpy as np
+    items = list(items)
+    env = dict(os.environ, TOKENIZERS_PARALLELISM="false", PYTHONPATH=os.pathsep.join(
+        [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p]))
+    procs = [subprocess.Popen([sys.executable, "-m", "kirag_amd.tokenize_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+             for _ in range(min(workers, max(1, len(items))))]
+    blob = pickle.dumps(collator)
 
+    def send(p, payload):
+        p.stdin.write(struct.pack("<Q", len(payload))); p.stdin.write(payload); p.stdin.flush()
 
-_POOL_FN = None
+    def recv(p):
+        head = p.stdout.read(8)
+        if len(head) != 8:
+            raise RuntimeError("tokenizer worker exited unexpectedly")
+        (n,) = struct.unpack("<Q", head)
+        return pickle.loads(p.stdout.read(n))
+    results, cond, failed = {}, threading.Condition(), []
+    window = len(procs) + max(1, depth)
+    consumed = [0]
 
-
-def _pool_call(x):
-    return _POOL_FN(x)
+    def serve(w):
+        p = procs[w]
+        try:
+            send(p, blob)
+            for j in range(w, len(items), len(procs)):
+                with cond:
+                    cond.wait_for(lambda: j < consumed[0] + window or failed)
+                    if failed:
+                        return
+                texts, ids = make_texts(items[j])
+                send(p, pickle.dumps(texts))
+                out = recv(p)
+                if isinstance(out, str):
+                    raise RuntimeError("tokenizer worker: " + out)
+                ii, mm = out
+                with cond:
+                    results[j] = ({"input_ids": torch.from_numpy(ii.astype(np.int64)), "attention_mask": torch.from_numpy(mm.astype(np.int64))}, ids)
+                    cond.notify_all()
+        except BaseException as e:   # noqa: BLE001 - forwarded to the consumer
+            with cond:
+                failed.append(e); cond.notify_all()
+    threads = [threading.Thread(target=serve, args=(w,), daemon=True) for w in range(len(procs))]
+    for t in threads:
+        t.start()
+    try:
+        for j in range(len(items)):
+            with cond:
+                cond.wait_for(lambda: j in results or failed)
+                if failed:
+                    raise failed[0]
+                out = results.pop(j)
+                consumed[0] = j + 1
+                cond.notify_all()
+            yield out
+    finally:
+        with cond:
+            failed.append(GeneratorExit()); cond.notify_all()
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
 
 
 def main(argv=None):

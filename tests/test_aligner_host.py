@@ -104,3 +104,31 @@ def test_prefetch_map_order_bound_and_errors():
     g = prefetch_map(fn, range(1000), depth=1); next(g); g.close()      # abandoning the generator stops the worker
     time.sleep(0.5)
     assert threading.active_count() <= n0 + 1
+
+
+def test_pool_map_tokenizer_worker_processes_keep_order_and_match_in_process_collate(tmp_path):
+    """SURVEY 8f-4 multi-process tokenisation: batches tokenised by `python -m kirag_amd.tokenize_worker` child processes come back in order and
+    equal the in-process collator output (dataset/collators.py:59-81,143-145 semantics); a worker-side failure surfaces at the consumer."""
+    import numpy as np
+    import pytest
+    import torch
+    from transformers import BertTokenizerFast
+    from kirag_amd import compute_corpus_embeddings as CC
+    from kirag_amd.collators import E5Collator
+    with open(tmp_path / "vocab.txt", "w") as f:
+        f.write("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "passage", ":", "hello", "world", "foo", "bar", "##s"]) + "\n")
+    tok = BertTokenizerFast(vocab_file=str(tmp_path / "vocab.txt"), do_lower_case=True)
+    col = E5Collator(tokenizer=tok, query_maxlength=16, doc_maxlength=12)
+    texts = [" ".join(np.random.default_rng(i).choice(["hello", "world", "foo", "bars", "bar"], 1 + i % 14)) for i in range(103)]
+
+    def mk(s):
+        return texts[s:s + 10], list(range(s, min(s + 10, 103)))
+    out = list(CC.pool_map(mk, col, range(0, 103, 10), 3, 2))
+    assert len(out) == 11
+    for (enc, ids), s in zip(out, range(0, 103, 10)):
+        ref = col.encode_doc(texts[s:s + 10])
+        assert torch.equal(enc["input_ids"], ref["input_ids"]) and torch.equal(enc["attention_mask"], ref["attention_mask"])
+        assert enc["input_ids"].dtype == torch.int64 and ids == list(range(s, min(s + 10, 103)))
+    with pytest.raises(RuntimeError) as ei:
+        list(CC.pool_map(lambda s: ([], [s]), col, range(3), 2, 1))          # an empty batch: the collator raises inside the worker
+    assert "text_list is None or an empty" in str(ei.value)
