@@ -25,6 +25,7 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <mutex>
 #include <vector>
 
 namespace kr {
@@ -318,6 +319,8 @@ struct ProjArgs {
     const uint16_t* W; const uint16_t* X; const int* Tp; int F; int K; int H;
     const float* bias;
     uint16_t* out0; uint16_t* out1; uint16_t* outT; int64_t ldT;   // QKV: q, k row-major [T,H]; vT [H, ldT].  Others: out0 [T, F]
+    int nt;   // epilogue stores non-temporal (large launches: the output is consumed from HBM by the next kernel, keep it out of L2) or plain
+              // (small launches: the whole output fits in L2 / Infinity Cache, the next kernel reads it from there)
 };
 
 enum { EPI_QKV = 0, EPI_DENSE = 1, EPI_GELU = 2 };
@@ -364,7 +367,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 // rows: for one mi the wave's 32 tokens x 64 features are staged as bf16 [32 tokens][128 B]; registers 4g .. 4g+3 of a lane are 4
 // consecutive features -> one packed ds_write_b64 (16-B chunk index XOR (token & 7): 2-way instead of 16-way conflicts), read back 16 B
 // per lane: every global store instruction writes eight whole 128-B rows.  f(v, ni, g) maps 4 features (bias / GELU) before packing.
-template <class Shape, class F>
+template <class Shape, bool NT, class F>
 __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ out, int64_t ld, int64_t row0, int col0, F&& f) {
     static_assert(Shape::TN == 2, "stage geometry assumes 64 features per wave");
     const int c = acc.lane & 31, h = acc.lane >> 5;
@@ -392,15 +395,18 @@ __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage
         }
         if (mi > 0) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p)   // rl & 7 == lane >> 3 for every p: one lane-dependent LDS / global base, the rest are wave-uniform steps (8 rows per store)
-                __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d[(mi - 1) & 1][p]), reinterpret_cast<u32x4_t*>(g_base + (int64_t)((mi - 1) * 32 + p * 8) * ld));
+            for (int p = 0; p < 4; ++p) {  // rl & 7 == lane >> 3 for every p: one lane-dependent LDS / global base, the rest are wave-uniform steps (8 rows per store)
+                u32x4_t* dst = reinterpret_cast<u32x4_t*>(g_base + (int64_t)((mi - 1) * 32 + p * 8) * ld);
+                if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d[(mi - 1) & 1][p]), dst);
+                else *dst = __builtin_bit_cast(u32x4_t, d[(mi - 1) & 1][p]);
+            }
         }
     }
 }
 
 // V^T[feature, token]: each 32x32 tile is staged as [32 features][32 tokens] (80-B rows), lanes = consecutive tokens of a feature row,
 // read back 16 B per lane: a store instruction writes 64-B runs of sixteen V^T rows.
-template <class Shape>
+template <class Shape, bool NT>
 __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ outT, int64_t ldT, int64_t t0, int f0) {
     const int c = acc.lane & 31, h = acc.lane >> 5;
 #pragma unroll
@@ -414,7 +420,9 @@ __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char*
             for (int p = 0; p < 2; ++p) {
                 const int fl = p * 16 + (acc.lane >> 2), ch = acc.lane & 3;
                 const uint4 d = *reinterpret_cast<const uint4*>(stage + fl * 80 + ch * 16);
-                __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d), reinterpret_cast<u32x4_t*>(outT + (int64_t)(f0 + ni * 32 + fl) * ldT + t0 + mi * 32 + ch * 8));
+                u32x4_t* dst = reinterpret_cast<u32x4_t*>(outT + (int64_t)(f0 + ni * 32 + fl) * ldT + t0 + mi * 32 + ch * 8);
+                if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d), dst);
+                else *dst = __builtin_bit_cast(u32x4_t, d);
             }
         }
 }
@@ -426,7 +434,7 @@ __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char*
 //   EPI_QKV:   F = 3H: features [0,H) -> q (bias, 1/8 folded into the weights), [H,2H) -> k, [2H,3H) -> V^T (its bias lives in bo_eff)
 //   EPI_DENSE: out0[T,F] = acc as bf16 (k_ln adds the bias and the residual in fp32)
 //   EPI_GELU:  out0[T,F] = gelu(acc + bias)
-template <int EPI, class ShapeE>
+template <int EPI, class ShapeE, bool NT>
 __device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>& acc, int64_t m0, int64_t n0, char* stage) {
     const int64_t t0 = m0 + acc.m_wave;
     const int f0 = (int)n0 + acc.n_wave;          // first feature of this wave's 64 columns; F % 64 == 0, so a wave is never partial
@@ -442,15 +450,15 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>
     if constexpr (EPI == EPI_QKV) {
         const int region = f0 / a.H;              // H % 64 == 0: a wave's columns never straddle q | k | v
         if (region == 2) {
-            store_transposed_bf16<ShapeE>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H);   // value bias lives in bo_eff
+            store_transposed_bf16<ShapeE, NT>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H);   // value bias lives in bo_eff
         } else {
-            store_rows_bf16<ShapeE>(acc, stage, region ? a.out1 : a.out0, a.H, t0, f0 - region * a.H,
+            store_rows_bf16<ShapeE, NT>(acc, stage, region ? a.out1 : a.out0, a.H, t0, f0 - region * a.H,
                                     [&](f32x4 v, int ni, int g) { return v + b[ni][g]; });
         }
     } else if constexpr (EPI == EPI_DENSE) {
-        store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int, int) { return v; });   // the bias is added in k_ln (fp32)
+        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int, int) { return v; });   // the bias is added in k_ln (fp32)
     } else {
-        store_rows_bf16<ShapeE>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int ni, int g) {
+        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int ni, int g) {
             const f32x4 x = v + b[ni][g];
             const f32x2 lo = gelu_erf_fast2(f32x2{x.x, x.y}), hi = gelu_erf_fast2(f32x2{x.z, x.w});
             return f32x4{lo.x, lo.y, hi.x, hi.y};
@@ -458,7 +466,7 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>
     }
 }
 
-template <int EPI, class ShapeE, int STAGES>
+template <int EPI, class ShapeE, int STAGES, bool NT>
 __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = *a.Tp;
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
             patch_coord(nat, tm_count, tn_count, tm, tn);
             m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
         },
-        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeE>(a, acc, m0, n0, stage); });
+        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeE, NT>(a, acc, m0, n0, stage); });
 }
 
 // the same projections on the producer / consumer 128x128 loop (gemm_nt_split): 4 multiplying + 4 staging waves, 4-slot ring + one 4-KiB epilogue
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_proj_split(ProjArgs a) {
             patch_coord(nat, tm_count, tn_count, tm, tn);
             m0 = tm * 128; n0 = tn * 128;
         },
-        [&](AccTile<ShapeSplit>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeSplit>(a, acc, m0, n0, stage); });
+        [&](AccTile<ShapeSplit>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeSplit, false>(a, acc, m0, n0, stage); });
 }
 
 // the same projections for a handful of token rows on the skinny loop (gemm_nt_skinny): one 32-token x 32-feature tile per block, grid = (F / 32, T / 32).
@@ -886,26 +894,40 @@ static int launch_attn(const Encoder* e, int B, int cap, int nqt, hipStream_t st
     return 0;
 }
 
+template <class Shape, int STAGES, bool NT>
+static int launch_proj_shape_nt(int epi, const ProjArgs& a, int blocks, int device, hipStream_t st) {
+    constexpr int lds = STAGES * Shape::STAGE_BYTES + Shape::NWAVE * EPI_STAGE_BYTES;   // 160 KiB for the 256x256 tile: the whole LDS of a CU
+    static std::once_flag once[64]; static int once_rc[64] = {};
+    std::call_once(once[device & 63], [&] {
+        once_rc[device & 63] = [&]() -> int {
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_QKV, Shape, STAGES, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_DENSE, Shape, STAGES, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_GELU, Shape, STAGES, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            return 0;
+        }();
+    });
+    KR_TRY(once_rc[device & 63]);
+#ifdef KR_STAMP
+    { const int slot = epi + (a.K > 1024 ? 2 : 0); (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(kr_stamp_slot), &slot, sizeof(int), 0, hipMemcpyHostToDevice, st); }
+#endif
+    if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj<EPI_QKV, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    else if (epi == EPI_DENSE) hipLaunchKernelGGL((k_proj<EPI_DENSE, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    else hipLaunchKernelGGL((k_proj<EPI_GELU, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    return 0;
+}
 template <class Shape, int STAGES>
 static int launch_proj_shape(int epi, const ProjArgs& a, int blocks, int device, hipStream_t st) {
-    constexpr int lds = STAGES * Shape::STAGE_BYTES + Shape::NWAVE * EPI_STAGE_BYTES;   // 160 KiB for the 256x256 tile: the whole LDS of a CU
-    static bool attr_set_dev[64] = {};
-    bool& attr_set = attr_set_dev[device & 63];
-    if (!attr_set) {
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_QKV, Shape, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_DENSE, Shape, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_GELU, Shape, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj<EPI_QKV, Shape, STAGES>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
-    else if (epi == EPI_DENSE) hipLaunchKernelGGL((k_proj<EPI_DENSE, Shape, STAGES>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
-    else hipLaunchKernelGGL((k_proj<EPI_GELU, Shape, STAGES>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
-    return 0;
+    return a.nt ? launch_proj_shape_nt<Shape, STAGES, true>(epi, a, blocks, device, st) : launch_proj_shape_nt<Shape, STAGES, false>(epi, a, blocks, device, st);
 }
 
 // tile shape per launch: when the 256x256 tiling has fewer tiles than ~5/8 of the CUs (small batches: the reference's per_gpu_batch_size 4-8, the KiRAG
 // loop's triple batches, a 1/8 slice of a query batch) the 128x128 tiling gives 4x the parallelism at a quarter of the per-tile latency
-static int launch_proj(int epi, const ProjArgs& a, int64_t max_tokens, int num_cu, int device, hipStream_t st) {
+static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int num_cu, int device, hipStream_t st) {
+    ProjArgs a = a_in;
+    {   // store policy by output size (see ProjArgs::nt); KIRAG_AMD_STORE_NT = 0 / 1 forces it (A/B measurements)
+        const char* se = getenv("KIRAG_AMD_STORE_NT");
+        a.nt = se ? atoi(se) : (max_tokens * (int64_t)a.F * 2 > ((int64_t)96 << 20) ? 1 : 0);
+    }
     const int64_t big_tiles = ((max_tokens + 255) / 256) * ((a.F + 255) / 256);
     const int64_t small_tiles = ((max_tokens + 127) / 128) * ((a.F + 127) / 128);
     const char* fe = getenv("KIRAG_AMD_PROJ_TILE");   // 128 / 256 force a path (tests run every parity case through both); read per call
@@ -1166,6 +1188,15 @@ int kr_encoder_check(kr_encoder* h) {
     e->pending = false;
     return report_token_error(e, e->last_stream);
 }
+
+#ifdef KR_STAMP
+// diagnostic build only: the projection kernels' copy of the stamp sums
+int kr_debug_read_stamps_enc(unsigned long long* out256) {
+    if (hipMemcpyFromSymbol(out256, HIP_SYMBOL(kr_stamp_buf), 256 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[256] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kr_stamp_buf), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // last_hidden_state of the previous forward, un-packed to [B,S,H]; rows of non-attended positions are zero
 int kr_encoder_last_hidden(kr_encoder* h, float* out, int B, int S) {

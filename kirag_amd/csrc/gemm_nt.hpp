@@ -100,6 +100,15 @@ __device__ __forceinline__ void patch_coord(int64_t n, int64_t tm_count, int64_t
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Diagnostic build only (-DKR_STAMP, tools/stamp_build.sh): per-wave cycle sums of the three parts of an output tile in gemm_nt_pingpong — [0] tile
+// set-up (coordinates, cursor), [1] the K loop (all intervals), [2] the epilogue, [3] tiles — accumulated into kr_stamp_buf[wave 0..7][4].  The
+// product build contains none of this.
+#ifdef KR_STAMP
+__device__ unsigned long long kr_stamp_buf[8 * 8 * 4];   // [slot][wave][part]
+__device__ int kr_stamp_slot;                              // set by the host (stream-ordered) before a launch
+#define KR_STAMP_NOW() __builtin_amdgcn_s_memtime()
+#endif
+
 template <class T, class Shape, int STAGES = 3, bool SWAP = false, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_nt_stream(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb,
                                                int64_t N, int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
@@ -548,10 +557,17 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
     const int b_row_byte = (wq * 64 + frow) * 128;
 
     int cur = 0;   // ring slot of the K-tile being multiplied
+#ifdef KR_STAMP
+    unsigned long long st_gap = 0, st_loop = 0, st_epi = 0, st_t0 = KR_STAMP_NOW();
+#endif
     for (int64_t i = 0; i < my; ++i) {
         int64_t m0, n0;
         const int64_t nat = xcd_chunk_map((int64_t)blockIdx.x + i * G, total_tiles);
         coord(nat, m0, n0);
+#ifdef KR_STAMP
+        const unsigned long long st_t1 = KR_STAMP_NOW();
+        st_gap += st_t1 - st_t0;
+#endif
         AccTile<Shape> acc;
         acc.m_wave = grp * 128;
         acc.n_wave = wq * 64;
@@ -612,9 +628,23 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
             interval(std::false_type{}, sa, sa + ABYTES, 0, false);
             interval(std::false_type{}, sa, sa + ABYTES, 1, kt == nk - 1);
         }
+#ifdef KR_STAMP
+        const unsigned long long st_t2 = KR_STAMP_NOW();
+        st_loop += st_t2 - st_t1;
+#endif
         epi(acc, m0, n0, nat);
+#ifdef KR_STAMP
+        st_t0 = KR_STAMP_NOW();
+        st_epi += st_t0 - st_t2;
+#endif
         if (grp) __builtin_amdgcn_s_barrier();
     }
+#ifdef KR_STAMP
+    if (lane == 0) {
+        unsigned long long* sb = kr_stamp_buf + (kr_stamp_slot & 7) * 32 + wave * 4;
+        atomicAdd(&sb[0], st_gap); atomicAdd(&sb[1], st_loop); atomicAdd(&sb[2], st_epi); atomicAdd(&sb[3], (unsigned long long)my);
+    }
+#endif
     if (!grp) __builtin_amdgcn_s_barrier();   // group 0 started one interval early: same number of barriers for every wave
     wait_vmcnt<0>();                            // dummy tail DMAs must not land after the caller re-uses the ring
     __builtin_amdgcn_s_barrier();

@@ -38,8 +38,65 @@ constexpr int QBLK = 1024;                   // queries per search block (refere
 constexpr int EXACT_RC = 1024;               // rows per block of the exact scan
 constexpr int SORT_CHUNK = 4096;             // keys per block of the merge tree
 
+// Growable device array without copies: a virtual address range reserved once (sized for the whole HBM: an index can never need more) into which
+// physical chunks are mapped as the row count grows (hipMemAddressReserve / hipMemCreate / hipMemMap).  The rows never move, so appending to a
+// 100-GB index needs neither a second allocation nor a device-to-device copy (round 1: grow() = hipMalloc of 1.5x + full copy, a transient 2.5x
+// footprint whenever the caller had not called reserve()).
+struct VBuf {
+    char* base = nullptr;
+    size_t reserved = 0, mapped = 0, chunk = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    int device = 0;
+
+    int init(int dev, size_t reserve_bytes) {
+        device = dev;
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) { (void)hipGetLastError(); return -1; }
+        chunk = ((size_t)(64u << 20) + gran - 1) / gran * gran;
+        reserved = (reserve_bytes + chunk - 1) / chunk * chunk;
+        void* p = nullptr;
+        if (hipMemAddressReserve(&p, reserved, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); reserved = 0; return -1; }
+        base = static_cast<char*>(p);
+        return 0;
+    }
+    // make [0, bytes) backed by memory; 0 on success, -1 = this mechanism is unavailable / out of range (nothing changed), KR_ENOMEM = out of memory
+    int ensure(size_t bytes) {
+        if (bytes <= mapped) return 0;
+        if (!base || bytes > reserved) return -1;
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        while (mapped < bytes) {
+            hipMemGenericAllocationHandle_t h;
+            hipError_t e = hipMemCreate(&h, chunk, &prop, 0);
+            if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? KR_ENOMEM : -1; }
+            if (hipMemMap(base + mapped, chunk, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return -1; }
+            if (hipMemSetAccess(base + mapped, chunk, &acc, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap(base + mapped, chunk); (void)hipMemRelease(h); return -1; }
+            handles.push_back(h);
+            mapped += chunk;
+        }
+        return 0;
+    }
+    void release() {
+        for (size_t i = 0; i < handles.size(); ++i) { (void)hipMemUnmap(base + i * chunk, chunk); (void)hipMemRelease(handles[i]); }
+        handles.clear(); mapped = 0;
+        if (base) (void)hipMemAddressFree(base, reserved);
+        base = nullptr; reserved = 0;
+    }
+};
+
 struct Index {
     int d = 0, dpad = 0, coarse = KR_COARSE_BF16, device = 0;
+    VBuf vf, vc;               // backing of xf / xc when the virtual-memory path is in use (vmm == 1)
+    int vmm = -1;              // -1 not decided yet, 0 hipMalloc + copy-on-grow, 1 mapped chunks
     int64_t n = 0, cap_rows = 0;
     float* xf = nullptr;       // [cap_rows, d] fp32 master
     uint16_t* xc = nullptr;    // [cap_rows, dpad] 16-bit coarse copy
@@ -210,7 +267,7 @@ __device__ __forceinline__ void scatter_wave_lists(const CoarseArgs& a, char* sm
 // SMALLQ (at most 128 queries in the block: the KiRAG loop's 1-2 queries per hop, single-question retrieval): 128-row x 128-query tiles on the
 // producer / consumer loop (gemm_nt_split) instead of 256 x 256 on the ping-pong loop.  With a 256-query tile a small batch pays the MFMA time of 256
 // queries (2.0 ms per 5M rows, above the 1.3-1.6 ms the corpus needs to cross HBM); with 128 the scan is HBM-bound.
-template <class T, bool DIRECT, bool SMALLQ = false>
+template <class T, bool DIRECT, bool SMALLQ = false, int EPIV = 0>
 __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
     using S = std::conditional_t<SMALLQ, ShapeSplit, ShapeC>;      // S::NWAVE = waves that own accumulators (4 of the 8 with SMALLQ)
     constexpr int RING_BYTES = SMALLQ ? SPLIT_RING * ShapeSplit::STAGE_BYTES : COARSE_STAGES * ShapeC::STAGE_BYTES;
@@ -265,6 +322,17 @@ __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
                     const float t = thr_s[q];
 #pragma unroll
                     for (int mi = 0; mi < S::TM; ++mi) {
+                        if constexpr (EPIV == 1) {
+                            // one test per 32 x 32 block: the largest of the lane's 16 scores against its query's threshold (8 v_max3 + 1 compare + ONE
+                            // branch); almost every block has no survivor (rate ~ cap / (2 rows)), so the 16 per-register tests and their 16 TAKEN
+                            // branches (the skip over the store path) are not executed at all.  NaN scores never win a max3 and fail the compare.
+                            const f32x16& v = acc.v[mi][ni];
+                            float m = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]);
+#pragma unroll
+                            for (int r = 3; r < 15; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, v[r]), v[r + 1]);
+                            m = __builtin_fmaxf(m, v[15]);
+                            if (!__ballot(m >= t)) continue;
+                        }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
@@ -817,6 +885,46 @@ __global__ void k_keys_to_out(const uint64_t* __restrict__ keys, int64_t stride,
 // ---------------------------------------------------------------------------------------------------------
 static int grow(Index* ix, int64_t want) {
     if (want <= ix->cap_rows) return 0;
+    const size_t row_f = (size_t)ix->d * sizeof(float), row_c = (size_t)ix->dpad * 2;
+    // small indexes (< 256 MiB of rows) live in plain hipMalloc memory and grow by copy; from 256 MiB on the rows move ONCE into mapped chunks
+    // (64 MiB each) and never again
+    if (ix->vmm < 0 && (size_t)want * (row_f + row_c) >= ((size_t)256 << 20)) {
+        ix->vmm = 0;
+        size_t free_b = 0, total_b = 0;
+        if (!getenv("KIRAG_AMD_NO_VMM") && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+            const size_t max_rows = total_b / (row_f + row_c) + 4096;          // more rows than the device could ever hold
+            if (ix->vf.init(ix->device, max_rows * row_f) == 0 && ix->vc.init(ix->device, max_rows * row_c) == 0) ix->vmm = 1;
+            else { ix->vf.release(); ix->vc.release(); }
+        }
+        if (ix->vmm == 1) {
+            const int64_t ncap = round_up(want, 256);
+            const int rf = ix->vf.ensure((size_t)ncap * row_f), rc = rf == 0 ? ix->vc.ensure((size_t)ncap * row_c) : rf;
+            if (rf != 0 || rc != 0) {
+                ix->vf.release(); ix->vc.release(); ix->vmm = 0;
+                if (rf == KR_ENOMEM || rc == KR_ENOMEM) return fail(KR_ENOMEM, "out of device memory growing the index to %lld rows", (long long)want);
+            } else {
+                float* nf = reinterpret_cast<float*>(ix->vf.base); uint16_t* nc = reinterpret_cast<uint16_t*>(ix->vc.base);
+                if (ix->n > 0) {   // the one migration copy (< 256 MiB); includes the NaN padding rows of the 16-bit copy
+                    KR_HIP(hipMemcpy(nf, ix->xf, (size_t)ix->n * row_f, hipMemcpyDeviceToDevice));
+                    KR_HIP(hipMemcpy(nc, ix->xc, (size_t)round_up(ix->n, 256) * row_c, hipMemcpyDeviceToDevice));
+                }
+                if (ix->xf) (void)hipFree(ix->xf);
+                if (ix->xc) (void)hipFree(ix->xc);
+                ix->xf = nf; ix->xc = nc;
+                ix->cap_rows = (int64_t)std::min(ix->vf.mapped / row_f, ix->vc.mapped / row_c) / 256 * 256;
+                return 0;
+            }
+        }
+    } else if (ix->vmm == 1) {
+        const int64_t ncap = round_up(want, 256);
+        const int rf = ix->vf.ensure((size_t)ncap * row_f), rc = rf == 0 ? ix->vc.ensure((size_t)ncap * row_c) : rf;
+        if (rf == 0 && rc == 0) {
+            ix->cap_rows = (int64_t)std::min(ix->vf.mapped / row_f, ix->vc.mapped / row_c) / 256 * 256;
+            return 0;                                                           // rows did not move; the NaN padding behind row n is still in place
+        }
+        if (rf == KR_ENOMEM || rc == KR_ENOMEM) return fail(KR_ENOMEM, "out of device memory growing the index to %lld rows", (long long)want);
+        return fail(KR_EHIP, "mapping more index memory failed");
+    }
     int64_t ncap = std::max<int64_t>(want, ix->cap_rows + ix->cap_rows / 2);
     ncap = round_up(ncap, 256);
     float* nf = nullptr; uint16_t* nc = nullptr;
@@ -1058,17 +1166,21 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         KR_TRY(once_per_device(coarse_once, ix->device, [&]() -> int {
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
+            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
             return 0;
         }));
         int final_preset = 0, rounds = 0;
+        const char* epiv_env = getenv("KIRAG_AMD_EPIV");
+        const int epiv = epiv_env ? atoi(epiv_env) : 0;
         KR_TRY(run_rounds(ix, a, nq, bm, K1, cap, st, true, [&](const CoarseArgs& ca) -> int {
             if (q32) return launch_q32<T>(ca, kt64, ix->num_cu, ix->device, st);
             if (smallq) {
                 if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
                 else hipLaunchKernelGGL((k_coarse<T, false, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
             } else if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+            else if (epiv == 1) hipLaunchKernelGGL((k_coarse<T, false, false, 1>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
             else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
             return 0;
         }, final_preset, rounds));
@@ -1242,6 +1354,7 @@ void kr_index_destroy(kr_index* h) {
     if (!h) return;
     Index* ix = reinterpret_cast<Index*>(h);
     (void)hipSetDevice(ix->device);
+    if (ix->vmm == 1) { (void)hipDeviceSynchronize(); ix->vf.release(); ix->vc.release(); ix->xf = nullptr; ix->xc = nullptr; }
     void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_f2, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
                     ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1433,6 +1546,15 @@ int kr_score_topk(const float* q, int nq, const float* x, int64_t n, int d, int 
     KR_HIP(hipStreamSynchronize(st));
     return 0;
 }
+
+#ifdef KR_STAMP
+// diagnostic build only: read and clear the per-wave stamp sums of gemm_nt_pingpong (this translation unit's copy: the coarse scan)
+int kr_debug_read_stamps(unsigned long long* out256) {
+    if (hipMemcpyFromSymbol(out256, HIP_SYMBOL(kr_stamp_buf), 256 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[256] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kr_stamp_buf), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 void kr_release_scratch(void) {
     std::lock_guard<std::mutex> lock(g_scratch_mu);

@@ -106,3 +106,37 @@ def test_async_boundary_device_pointers_streams_and_deferred_errors():
         side.synchronize()
     so, io = S.search_canonical(q16.float().cpu().numpy(), x.cpu().numpy(), 10)
     assert np.array_equal(rows.cpu().numpy(), io) and np.array_equal(i_np, io) and np.array_equal(sc.cpu().numpy().view(np.uint32), so.view(np.uint32))
+
+
+def test_large_index_grows_in_place_without_copies():
+    """An index that outgrows 256 MiB moves once into mapped 64-MiB chunks (hipMemAddressReserve / hipMemMap) and from then on grows in place:
+    50k-row appends WITHOUT reserve() (the reference's faiss_index_corpus loop, index.py:88-106 style) must not need a second copy of the rows —
+    peak device memory stays within one chunk pair of the final footprint — and every row must survive the growth steps bit for bit."""
+    from kirag_amd.retriever.index import FlatIPIndex
+    torch.cuda.empty_cache()
+    d, step, steps = 1024, 50_000, 12                                       # 600k rows x 6 KiB = 3.7 GB
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    base = _free_bytes()
+    ix = FlatIPIndex(d)
+    low = base
+    keep = []
+    for it in range(steps):
+        x = torch.nn.functional.normalize(torch.randn(step, d, generator=g, device="cuda"), dim=1)
+        if it in (0, 5, 11):
+            keep.append((it * step, x[:300].cpu().numpy()))
+        ix.add(x)
+        del x
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        low = min(low, torch.cuda.mem_get_info()[0])
+    final_bytes = steps * step * (d * 4 + d * 2)
+    peak = base - low
+    print(f"[grow] final footprint {final_bytes / 2**30:.2f} GiB, peak extra device memory during the appends {peak / 2**30:.2f} GiB")
+    assert peak < final_bytes + (450 << 20), (peak, final_bytes)              # round 1: 2.5x the footprint at every regrowth
+    for r0, rows in keep:
+        assert np.array_equal(ix.reconstruct_n(r0, 300), rows)
+    q = torch.from_numpy(keep[1][1][:16]).cuda()
+    s, i = ix.search(q, 5)
+    assert np.array_equal(i[:, 0], np.arange(keep[1][0], keep[1][0] + 16))
+    del ix
+    torch.cuda.synchronize()
+    assert base - _free_bytes() < (64 << 20)

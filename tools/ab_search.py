@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""A/B of search-kernel variants selected by environment variables, interleaved rounds in ONE process on one device (guide rule 24).
+Usage: python tools/ab_search.py VAR=a,b [rows] [queries]   e.g. KIRAG_AMD_EPIV=0,1"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from kirag_amd.bench_support import CorpusDist
+from kirag_amd.retriever.index import FlatIPIndex
+var, vals = sys.argv[1].split("=")
+vals = vals.split(",")
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000
+nq = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+d, k = 1024, 100
+dev = torch.device("cuda:0")
+cd = CorpusDist("gaussian", d, dev)
+g = torch.Generator(device=dev); g.manual_seed(3)
+ix = FlatIPIndex(d, device=0); ix.reserve(n)
+head = None
+for s0 in range(0, n, 250_000):
+    x = cd.rows(min(250_000, n - s0), g); ix.add(x)
+    head = x[:nq].clone() if head is None else head
+q = cd.queries_near(head, torch.Generator(device=dev).manual_seed(2))
+sc = torch.empty((nq, k), dtype=torch.float32, device=dev); rows = torch.empty((nq, k), dtype=torch.int64, device=dev)
+res = {v: [] for v in vals}
+ref = None
+for rnd in range(8):
+    for v in vals:
+        os.environ[var] = v
+        for _ in range(3):
+            ix.search_into(q, k, sc, rows)
+        cs, ts = [], []
+        for _ in range(5):
+            ix.search_into(q, k, sc, rows)
+            st = ix.stats(); cs.append(st["last_coarse_ms"]); ts.append(st["last_total_ms"])
+        res[v].append((np.median(cs), np.median(ts)))
+        r = rows.cpu().numpy()
+        ref = r if ref is None else ref
+        assert np.array_equal(r, ref), "variants disagree"
+for v in vals:
+    a = np.array(res[v])
+    print(f"{var}={v}: coarse median {np.median(a[:, 0]):.3f} ms (min {a[:, 0].min():.3f}), total median {np.median(a[:, 1]):.3f} ms; per round {np.round(a[:, 0], 3).tolist()}")
