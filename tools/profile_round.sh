@@ -1,16 +1,26 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun -- 'bash tools/profile_round.sh r01'): kernel-trace stats of the default bench, kernel-trace of the search-only
+# Runs on the GPU box (gpurun -- 'bash tools/profile_round.sh r02'): kernel-trace stats of the default bench, kernel-trace of the search-only
 # bench, and two separate PMC passes (FETCH_SIZE, WRITE_SIZE) of the search-only bench.  Summaries -> gpurun_out/<tag>/ (copy into profiles/).
+# The program after `--` is python3 itself (never env / bash -c: the profiler's preloaded library has initialised the GPU).
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py --steps 20 --warmup 3 > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+echo "plain bench done" 
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+echo "kernel trace (full step) done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_search -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-encoder > $OUT/bench_search_under_rocprof.json 2> $OUT/kt_search.err
+echo "kernel trace (search only) done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-encoder --no-cpu-baseline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+echo "pmc fetch done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-encoder --no-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+echo "pmc write done"
 python3 $R/tools/pmc_summary.py $OUT > $OUT/search_pmc_fetch_write.json
 python3 $R/tools/pmc_summary.py $OUT --traffic 4 > $OUT/traffic.json
+python3 $R/tools/trace_breakdown.py $OUT/kt > $OUT/encoder_forward_breakdown.txt
+python3 $R/bench.py --steps 10 --warmup 2 --corpus-dist e5like --no-cpu-baseline > $OUT/bench_e5like.json 2> $OUT/bench_e5like.err
+python3 $R/bench.py --steps 10 --warmup 2 --total-rows 1000000 --no-cpu-baseline > $OUT/bench_config2_1M.json 2> $OUT/bench_1M.err
 echo "profile_round done: $OUT"
