@@ -71,6 +71,7 @@ struct Encoder {
     bool use_lo = false;       // KIRAG_AMD_RESIDUAL_LO=1 at kr_encoder_create
     uint16_t *y = nullptr, *xb = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *ctx = nullptr, *h = nullptr;
     int lastB = 0, lastS = 0;
+    int h_pad = 0;                   // extra elements per row of h (row pitch not a power of two: see ensure_ws)
     int* h_err = nullptr;            // pinned: copy of d_err taken at the end of the last asynchronous forward
     hipEvent_t ev_done = nullptr;    // recorded after that copy
     bool pending = false;            // an asynchronous forward's error word has not been looked at yet
@@ -319,6 +320,7 @@ struct ProjArgs {
     const uint16_t* W; const uint16_t* X; const int* Tp; int F; int K; int H;
     const float* bias;
     uint16_t* out0; uint16_t* out1; uint16_t* outT; int64_t ldT;   // QKV: q, k row-major [T,H]; vT [H, ldT].  Others: out0 [T, F]
+    int64_t ldx, ldo;   // row pitch (elements) of X and of out0 (EPI_DENSE / EPI_GELU); 0 = K / F
     int nt;   // epilogue stores non-temporal (large launches: the output is consumed from HBM by the next kernel, keep it out of L2) or plain
               // (small launches: the whole output fits in L2 / Infinity Cache, the next kernel reads it from there)
 };
@@ -380,6 +382,9 @@ __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage
     uint4 d[2][4];
 #pragma unroll
     for (int mi = 0; mi <= Shape::TM; ++mi) {
+#ifdef KR_STAMP
+        acc.stamp(mi);                      // [0] = everything before the first block (bias loads ...), [mi] = block mi-1
+#endif
         if (mi < Shape::TM) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
@@ -402,6 +407,9 @@ __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage
             }
         }
     }
+#ifdef KR_STAMP
+    acc.stamp(Shape::TM + 1);
+#endif
 }
 
 // V^T[feature, token]: each 32x32 tile is staged as [32 features][32 tokens] (80-B rows), lanes = consecutive tokens of a feature row,
@@ -456,9 +464,9 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>
                                     [&](f32x4 v, int ni, int g) { return v + b[ni][g]; });
         }
     } else if constexpr (EPI == EPI_DENSE) {
-        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int, int) { return v; });   // the bias is added in k_ln (fp32)
+        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.ldo, t0, f0, [&](f32x4 v, int, int) { return v; });   // the bias is added in k_ln (fp32)
     } else {
-        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.F, t0, f0, [&](f32x4 v, int ni, int g) {
+        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.ldo, t0, f0, [&](f32x4 v, int ni, int g) {
             const f32x4 x = v + b[ni][g];
             const f32x2 lo = gelu_erf_fast2(f32x2{x.x, x.y}), hi = gelu_erf_fast2(f32x2{x.z, x.w});
             return f32x4{lo.x, lo.y, hi.x, hi.y};
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
     const int64_t tm_count = (T + ShapeE::BM - 1) / ShapeE::BM, tn_count = (a.F + ShapeE::BN - 1) / ShapeE::BN;
     char* stage = smem + STAGES * ShapeE::STAGE_BYTES + (threadIdx.x >> 6) * EPI_STAGE_BYTES;
     gemm_main<ShapeE, STAGES>(
-        a.X, a.K, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
+        a.X, a.ldx, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             int64_t tm, tn;
             patch_coord(nat, tm_count, tn_count, tm, tn);
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_proj_split(ProjArgs a) {
     const int64_t tm_count = (T + 127) / 128, tn_count = (a.F + 127) / 128;
     char* stage = smem + SPLIT_RING * ShapeSplit::STAGE_BYTES + ((threadIdx.x >> 6) & 3) * EPI_STAGE_BYTES;
     gemm_nt_split<BF16, true>(
-        a.X, a.K, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
+        a.X, a.ldx, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             int64_t tm, tn;
             patch_coord(nat, tm_count, tn_count, tm, tn);
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(SKINNY_THREADS) void k_proj_skinny(ProjArgs a) {
     const int T = *a.Tp;
     const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
     if (m0 >= T) return;                                  // block-uniform, before any barrier
-    gemm_nt_skinny<BF16, RING, true>(a.X, a.K, T, m0, a.W, a.K, a.F, n0, a.K, smem, [&](AccTile<ShapeSkinny>& acc, int64_t t0, int64_t f0) {
+    gemm_nt_skinny<BF16, RING, true>(a.X, a.ldx, T, m0, a.W, a.K, a.F, n0, a.K, smem, [&](AccTile<ShapeSkinny>& acc, int64_t t0, int64_t f0) {
         const int c = acc.lane & 31, h = acc.lane >> 5;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(SKINNY_THREADS) void k_proj_skinny(ProjArgs a) {
                     v = f32x4{lo.x, lo.y, hi.x, hi.y};
                 }
                 uint2 w; w.x = pack_bf16x2(v.x, v.y); w.y = pack_bf16x2(v.z, v.w);
-                *reinterpret_cast<uint2*>(a.out0 + (t0 + c) * a.F + f) = w;
+                *reinterpret_cast<uint2*>(a.out0 + (t0 + c) * a.ldo + f) = w;
             }
         }
     });
@@ -825,7 +833,7 @@ static int ensure_ws(Encoder* e, int B, int S) {
     e->ldv = capT + 64;   // slack: the last key tile of the last sequence may read up to 43 columns past T
     KR_TRY(dmalloc(&e->vT, (size_t)H * e->ldv * 2));
     KR_HIP(hipMemset(e->vT, 0, (size_t)H * e->ldv * 2));
-    KR_TRY(dmalloc(&e->ctx, capT * H * 2)); KR_TRY(dmalloc(&e->h, capT * FF * 2));
+    KR_TRY(dmalloc(&e->ctx, capT * H * 2)); KR_TRY(dmalloc(&e->h, capT * (FF + e->h_pad) * 2));
     e->capT = capT; e->capB = (int)capB; e->capBS = capBS;
     return 0;
 }
@@ -910,9 +918,15 @@ static int launch_proj_shape_nt(int epi, const ProjArgs& a, int blocks, int devi
 #ifdef KR_STAMP
     { const int slot = epi + (a.K > 1024 ? 2 : 0); (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(kr_stamp_slot), &slot, sizeof(int), 0, hipMemcpyHostToDevice, st); }
 #endif
-    if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj<EPI_QKV, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
-    else if (epi == EPI_DENSE) hipLaunchKernelGGL((k_proj<EPI_DENSE, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
-    else hipLaunchKernelGGL((k_proj<EPI_GELU, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    int repeat = 1;
+#ifdef KR_STAMP
+    { const char* r = getenv("KIRAG_AMD_DEBUG_REPEAT"); if (r) repeat = atoi(r); }   // diagnostic: the same launch again (warm instruction cache?)
+#endif
+    for (int rep = 0; rep < repeat; ++rep) {
+        if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj<EPI_QKV, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+        else if (epi == EPI_DENSE) hipLaunchKernelGGL((k_proj<EPI_DENSE, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+        else hipLaunchKernelGGL((k_proj<EPI_GELU, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+    }
     return 0;
 }
 template <class Shape, int STAGES>
@@ -924,6 +938,8 @@ static int launch_proj_shape(int epi, const ProjArgs& a, int blocks, int device,
 // loop's triple batches, a 1/8 slice of a query batch) the 128x128 tiling gives 4x the parallelism at a quarter of the per-tile latency
 static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int num_cu, int device, hipStream_t st) {
     ProjArgs a = a_in;
+    if (a.ldx == 0) a.ldx = a.K;
+    if (a.ldo == 0) a.ldo = a.F;
     {   // store policy by output size (see ProjArgs::nt); KIRAG_AMD_STORE_NT = 0 / 1 forces it (A/B measurements)
         const char* se = getenv("KIRAG_AMD_STORE_NT");
         a.nt = se ? atoi(se) : (max_tokens * (int64_t)a.F * 2 > ((int64_t)96 << 20) ? 1 : 0);
@@ -992,6 +1008,7 @@ int kr_encoder_create(const kr_bert_cfg* cfg, int device, kr_encoder** out) {
     Encoder* e = new Encoder();
     e->cfg = *cfg; e->device = device;
     { const char* v = getenv("KIRAG_AMD_RESIDUAL_LO"); e->use_lo = v && atoi(v) != 0; }
+    { const char* v = getenv("KIRAG_AMD_HPAD"); e->h_pad = v ? (atoi(v) / 8) * 8 : 0; }   // diagnostic (tools/stamp_hpad.py): a row pitch of h that is not a power of two made no difference
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) e->num_cu = (p.multiProcessorCount / 8) * 8; }
     e->L.resize(cfg->layers);
     e->got.assign(T_LAYER0 + (size_t)cfg->layers * L_COUNT, 0);
@@ -1140,7 +1157,7 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
         ProjArgs a{};
         a.Tp = e->d_T; a.H = H;
         // q | k | v^T in one GEMM (F = 3H)
-        a.W = l.wqkv; a.X = e->xb; a.F = 3 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k; a.outT = e->vT; a.ldT = e->ldv;
+        a.W = l.wqkv; a.X = e->xb; a.F = 3 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k; a.outT = e->vT; a.ldT = e->ldv; a.ldx = 0; a.ldo = 0;
         KR_TRY(launch_proj(EPI_QKV, a, maxT, e->num_cu, e->device, st));
         {
             const int cap = (int)round_up(S, 32);
@@ -1150,14 +1167,14 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
             else KR_TRY(launch_attn<4>(e, B, cap, nqt, st));
         }
         // attention.output.dense + residual -> LayerNorm
-        a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y;
+        a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y; a.ldx = 0; a.ldo = 0;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
         hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.bo_eff, e->d_T, l.ln1g, l.ln1b, eps, H, lo_rw, lo_rw, e->xb);
         // intermediate.dense + GELU
-        a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h;
+        a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h; a.ldx = 0; a.ldo = FF + e->h_pad;
         KR_TRY(launch_proj(EPI_GELU, a, maxT, e->num_cu, e->device, st));
         // output.dense + residual -> LayerNorm
-        a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->y;
+        a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->y; a.ldx = FF + e->h_pad; a.ldo = 0;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
         // the LAST LayerNorm always writes the low half: pooling and kr_encoder_last_hidden read the final hidden state with 16 mantissa bits
         hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.b2, e->d_T, l.ln2g, l.ln2b, eps, H, lo_rw, last ? e->xlo : lo_rw, e->xb);
@@ -1190,6 +1207,11 @@ int kr_encoder_check(kr_encoder* h) {
 }
 
 #ifdef KR_STAMP
+int kr_debug_read_fine_enc(unsigned long long* out128) {
+    if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(kr_stamp_fine), 128 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[128] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kr_stamp_fine), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
 // diagnostic build only: the projection kernels' copy of the stamp sums
 int kr_debug_read_stamps_enc(unsigned long long* out256) {
     if (hipMemcpyFromSymbol(out256, HIP_SYMBOL(kr_stamp_buf), 256 * sizeof(unsigned long long)) != hipSuccess) return -1;

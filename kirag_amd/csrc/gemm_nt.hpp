@@ -44,6 +44,10 @@ template <class Shape>
 struct AccTile {
     f32x16 v[Shape::TM][Shape::TN];
     int m_wave, n_wave, lane;
+#ifdef KR_STAMP
+    unsigned long long fine[6] = {0, 0, 0, 0, 0, 0}, fine_prev = 0;
+    __device__ __forceinline__ void stamp(int step) { const unsigned long long now = __builtin_amdgcn_s_memtime(); fine[step] += now - fine_prev; fine_prev = now; }
+#endif
     __device__ __forceinline__ int row(int mi, int r) const { return m_wave + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
     __device__ __forceinline__ int col(int ni) const { return n_wave + ni * 32 + (lane & 31); }
 };
@@ -106,6 +110,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 #ifdef KR_STAMP
 __device__ unsigned long long kr_stamp_buf[8 * 8 * 4];   // [slot][wave][part]
 __device__ int kr_stamp_slot;                              // set by the host (stream-ordered) before a launch
+__device__ unsigned long long kr_stamp_fine[8 * 2 * 8];    // [slot][group][step]: cycle sums at finer points inside an epilogue (kept in SGPRs per tile)
 #define KR_STAMP_NOW() __builtin_amdgcn_s_memtime()
 #endif
 
@@ -559,6 +564,7 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
     int cur = 0;   // ring slot of the K-tile being multiplied
 #ifdef KR_STAMP
     unsigned long long st_gap = 0, st_loop = 0, st_epi = 0, st_t0 = KR_STAMP_NOW();
+    unsigned long long st_fine[6] = {0, 0, 0, 0, 0, 0};
 #endif
     for (int64_t i = 0; i < my; ++i) {
         int64_t m0, n0;
@@ -631,11 +637,13 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
 #ifdef KR_STAMP
         const unsigned long long st_t2 = KR_STAMP_NOW();
         st_loop += st_t2 - st_t1;
+        acc.fine_prev = st_t2;
 #endif
         epi(acc, m0, n0, nat);
 #ifdef KR_STAMP
         st_t0 = KR_STAMP_NOW();
         st_epi += st_t0 - st_t2;
+        for (int z = 0; z < 6; ++z) st_fine[z] += acc.fine[z];
 #endif
         if (grp) __builtin_amdgcn_s_barrier();
     }
@@ -643,6 +651,7 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
     if (lane == 0) {
         unsigned long long* sb = kr_stamp_buf + (kr_stamp_slot & 7) * 32 + wave * 4;
         atomicAdd(&sb[0], st_gap); atomicAdd(&sb[1], st_loop); atomicAdd(&sb[2], st_epi); atomicAdd(&sb[3], (unsigned long long)my);
+        for (int z = 0; z < 6; ++z) atomicAdd(&kr_stamp_fine[((kr_stamp_slot & 7) * 2 + grp) * 8 + z], st_fine[z]);
     }
 #endif
     if (!grp) __builtin_amdgcn_s_barrier();   // group 0 started one interval early: same number of barriers for every wave
