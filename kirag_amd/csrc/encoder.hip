@@ -948,7 +948,9 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int nu
     const int64_t small_tiles = ((max_tokens + 127) / 128) * ((a.F + 127) / 128);
     const char* fe = getenv("KIRAG_AMD_PROJ_TILE");   // 128 / 256 force a path (tests run every parity case through both); read per call
     const int force = fe ? atoi(fe) : 0;
-    const bool small = force == 128 || (force != 256 && big_tiles * 8 < (int64_t)num_cu * 5);   // measured crossover: ~5/8 of the CUs busy with 256x256 tiles
+    const char* re = getenv("KIRAG_AMD_SMALL_RATIO");   // A/B knob (tools/ab_encoder.py): eighths of the CU count below which the 128x128 tiling is used
+    const int ratio8 = re ? atoi(re) : 5;
+    const bool small = force == 128 || (force != 256 && big_tiles * 8 < (int64_t)num_cu * ratio8);   // measured crossover: ~5/8 of the CUs busy with 256x256 tiles
     // a handful of token rows: 32x32 tiles, one per block (latency chain: the operand stream of the launch spread over as many CUs as it has tiles).
     // Used while the launch has at most 4 tiles per CU (measured crossover against the 128x128 producer / consumer loop); 32 forces it
     const int64_t skinny_tiles = ((max_tokens + 31) / 32) * (a.F / 32);

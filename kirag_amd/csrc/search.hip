@@ -267,7 +267,7 @@ __device__ __forceinline__ void scatter_wave_lists(const CoarseArgs& a, char* sm
 // SMALLQ (at most 128 queries in the block: the KiRAG loop's 1-2 queries per hop, single-question retrieval): 128-row x 128-query tiles on the
 // producer / consumer loop (gemm_nt_split) instead of 256 x 256 on the ping-pong loop.  With a 256-query tile a small batch pays the MFMA time of 256
 // queries (2.0 ms per 5M rows, above the 1.3-1.6 ms the corpus needs to cross HBM); with 128 the scan is HBM-bound.
-template <class T, bool DIRECT, bool SMALLQ = false, int EPIV = 0>
+template <class T, bool DIRECT, bool SMALLQ = false>
 __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
     using S = std::conditional_t<SMALLQ, ShapeSplit, ShapeC>;      // S::NWAVE = waves that own accumulators (4 of the 8 with SMALLQ)
     constexpr int RING_BYTES = SMALLQ ? SPLIT_RING * ShapeSplit::STAGE_BYTES : COARSE_STAGES * ShapeC::STAGE_BYTES;
@@ -322,17 +322,8 @@ __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
                     const float t = thr_s[q];
 #pragma unroll
                     for (int mi = 0; mi < S::TM; ++mi) {
-                        if constexpr (EPIV == 1) {
-                            // one test per 32 x 32 block: the largest of the lane's 16 scores against its query's threshold (8 v_max3 + 1 compare + ONE
-                            // branch); almost every block has no survivor (rate ~ cap / (2 rows)), so the 16 per-register tests and their 16 TAKEN
-                            // branches (the skip over the store path) are not executed at all.  NaN scores never win a max3 and fail the compare.
-                            const f32x16& v = acc.v[mi][ni];
-                            float m = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]);
-#pragma unroll
-                            for (int r = 3; r < 15; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, v[r]), v[r + 1]);
-                            m = __builtin_fmaxf(m, v[15]);
-                            if (!__ballot(m >= t)) continue;
-                        }
+                        // (a block-level pre-test — the max of the lane's 16 scores against the threshold, ONE branch per 32 x 32 block instead of 16
+                        // taken ones — was measured 7 % SLOWER in an interleaved A/B on one device, profiles/r02/ab_coarse_blockmax_epilogue.txt)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
@@ -1166,21 +1157,17 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         KR_TRY(once_per_device(coarse_once, ix->device, [&]() -> int {
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
             KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
             return 0;
         }));
         int final_preset = 0, rounds = 0;
-        const char* epiv_env = getenv("KIRAG_AMD_EPIV");
-        const int epiv = epiv_env ? atoi(epiv_env) : 0;
         KR_TRY(run_rounds(ix, a, nq, bm, K1, cap, st, true, [&](const CoarseArgs& ca) -> int {
             if (q32) return launch_q32<T>(ca, kt64, ix->num_cu, ix->device, st);
             if (smallq) {
                 if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
                 else hipLaunchKernelGGL((k_coarse<T, false, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
             } else if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
-            else if (epiv == 1) hipLaunchKernelGGL((k_coarse<T, false, false, 1>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
             else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
             return 0;
         }, final_preset, rounds));
