@@ -68,6 +68,7 @@ class CorpusDist:
     """Synthetic corpus-embedding generators (rows are unit vectors, generated on the device chunk by chunk).
 
     ``gaussian``  iid Gaussian directions: pairwise cosines ~ N(0, 1/d) — the easy case for a low-precision scan.
+    ``neardup``   a corpus of near-duplicates (rows within 3e-5 of one direction): nothing certifies in the 16-bit pass; measures pass 2.
     ``e5like``    what real e5 / bge embeddings look like to the scan: every row shares a mean direction (pairwise cosines centred at
                   ``mean_cos`` = 0.75) and the remainder is anisotropic (spectrum lambda_i ~ 1/i over randomly permuted axes: effective
                   dimension (sum lambda)^2 / sum lambda^2 ~ 34 at d = 1024), so query-passage scores sit in a narrow band, sigma ~ 0.04: at 5M
@@ -75,10 +76,10 @@ class CorpusDist:
     """
 
     def __init__(self, kind: str, d: int, device, seed: int = 3, mean_cos: float = 0.75):
-        assert kind in ("gaussian", "e5like"), kind
+        assert kind in ("gaussian", "e5like", "neardup"), kind
         self.kind, self.d, self.device, self.mean_cos = kind, d, device, mean_cos
         g = torch.Generator(device=device); g.manual_seed(seed * 7919 + 11)
-        if kind == "e5like":
+        if kind in ("e5like", "neardup"):
             mu = torch.randn(d, generator=g, device=device)
             self.mu = mu / mu.norm()
             lam = 1.0 / torch.arange(1, d + 1, device=device, dtype=torch.float32)
@@ -89,6 +90,10 @@ class CorpusDist:
         z = torch.randn(m, self.d, generator=gen, device=self.device)
         if self.kind == "gaussian":
             return torch.nn.functional.normalize(z, dim=1)
+        if self.kind == "neardup":
+            # adversarial for a 16-bit scan: every row within ~3e-5 of one direction, so ALL scores of a query fall inside the bf16 error bound and
+            # pass 1 can certify nothing (the data the fp64 pass 2 exists for; round 1 answered it with one full fp32 scan PER QUERY)
+            return torch.nn.functional.normalize(self.mu + 3e-5 * z, dim=1)
         u = z * self.scale
         u = u - (u @ self.mu)[:, None] * self.mu                     # remainder orthogonal to the mean direction
         u = torch.nn.functional.normalize(u, dim=1)
@@ -101,6 +106,8 @@ class CorpusDist:
         z = torch.randn(head.shape, generator=gen, device=self.device)
         if self.kind == "gaussian":
             return torch.nn.functional.normalize(head + noise * z, dim=1)
+        if self.kind == "neardup":
+            return torch.nn.functional.normalize(self.mu + 0.3 * torch.nn.functional.normalize(z, dim=1), dim=1)
         u = torch.nn.functional.normalize(head - (head @ self.mu)[:, None] * self.mu, dim=1)
         w = z * self.scale
         w = torch.nn.functional.normalize(w - (w @ self.mu)[:, None] * self.mu, dim=1)
