@@ -77,7 +77,17 @@ struct Encoder {
     bool pending = false;            // an asynchronous forward's error word has not been looked at yet
     hipStream_t last_stream = nullptr;
     int num_cu = 256;
+    struct GraphEntryT { uint64_t key; int calls; hipGraphExec_t exec; };
+    std::vector<GraphEntryT> graphs;   // captured forwards of small batch shapes (run_forward)
+    hipStream_t gstream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    bool graphs_off = false;
 };
+
+typedef Encoder::GraphEntryT GraphEntry;
+static void drop_graphs(Encoder* e) {
+    for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    e->graphs.clear();
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // small kernels
@@ -804,6 +814,7 @@ static int dmalloc(P** p, size_t bytes) {
 }
 
 static void free_ws(Encoder* e) {
+    if (!e->graphs.empty()) { (void)hipDeviceSynchronize(); drop_graphs(e); }   // captured kernels hold workspace pointers
     void* ptrs[] = {e->d_ids, e->d_mask, e->seq_off, e->seq_nk, e->seq_nq, e->seq_cls, e->seq_has0, e->tok_id, e->tok_pos, e->xlo, e->y, e->out,
                     e->xb, e->q, e->k, e->vT, e->ctx, e->h};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1010,6 +1021,7 @@ int kr_encoder_create(const kr_bert_cfg* cfg, int device, kr_encoder** out) {
     Encoder* e = new Encoder();
     e->cfg = *cfg; e->device = device;
     { const char* v = getenv("KIRAG_AMD_RESIDUAL_LO"); e->use_lo = v && atoi(v) != 0; }
+    { const char* v = getenv("KIRAG_AMD_GRAPH"); e->graphs_off = !(v && atoi(v) != 0); }   // opt-in: measured SLOWER than eager launches on ROCm 7.2 (see run_forward)
     { const char* v = getenv("KIRAG_AMD_HPAD"); e->h_pad = v ? (atoi(v) / 8) * 8 : 0; }   // diagnostic (tools/stamp_hpad.py): a row pitch of h that is not a power of two made no difference
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) e->num_cu = (p.multiProcessorCount / 8) * 8; }
     e->L.resize(cfg->layers);
@@ -1036,6 +1048,9 @@ void kr_encoder_destroy(kr_encoder* h) {
     free_ws(e);
     if (e->h_err) (void)hipHostFree(e->h_err);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    if (e->gstream) (void)hipStreamDestroy(e->gstream);
     void* ptrs[] = {e->word, e->pos, e->type, e->elng, e->elnb, e->stage, e->d_T, e->d_err};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& l : e->L) {
@@ -1112,37 +1127,10 @@ int kr_encoder_finalize(kr_encoder* h) {
     return 0;
 }
 
-// the sticky device error word has been copied to e->h_err and that copy has completed
-static int report_token_error(Encoder* e, hipStream_t st) {
-    if (*e->h_err == 0) return 0;
-    *e->h_err = 0;
-    KR_HIP(hipMemsetAsync(e->d_err, 0, sizeof(int), st));
-    return fail(KR_EINVAL, "input_ids contain a token id outside [0, %d)", e->cfg.vocab);
-}
-
-int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* attention_mask, int B, int S, int pool, float* out, void* stream) {
-    if (!h) return fail(KR_EINVAL, "encoder is NULL");
-    Encoder* e = reinterpret_cast<Encoder*>(h);
-    if (!e->ready) return fail(KR_ESTATE, "encoder weights incomplete: call kr_encoder_finalize after loading every tensor");
-    if (B < 0 || S <= 0 || (B > 0 && (!input_ids || !attention_mask || !out))) return fail(KR_EINVAL, "bad input pointers / shape");
-    if (S > e->cfg.max_pos) return fail(KR_EINVAL, "sequence length %d exceeds max_position_embeddings %d", S, e->cfg.max_pos);
-    if (pool != KR_POOL_MEAN && pool != KR_POOL_CLS) return fail(KR_EINVAL, "pool must be 0 (mean) or 1 (cls)");
-    if (B == 0) return 0;
-    if (B > 65535) return fail(KR_EINVAL, "at most 65535 sequences per call");
-    KR_TRY(select_device(e->device));
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (e->pending) {
-        if (st != e->last_stream) KR_HIP(hipEventSynchronize(e->ev_done));      // the workspace is shared: a forward on another stream waits for the previous one
-        if (hipEventQuery(e->ev_done) == hipSuccess) {                          // finished: report its token-id error now (never blocks)
-            e->pending = false;
-            KR_TRY(report_token_error(e, st));
-        }
-    }
-    KR_TRY(ensure_ws(e, B, S));
+// every kernel of one forward, enqueued on `st` (inputs already in e->d_ids / e->d_mask, result left in e->out)
+static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
     const int H = e->cfg.hidden, FF = e->cfg.intermediate;
     const float eps = e->cfg.ln_eps;
-    KR_HIP(hipMemcpyAsync(e->d_ids, input_ids, (size_t)B * S * 8, hipMemcpyDefault, st));
-    KR_HIP(hipMemcpyAsync(e->d_mask, attention_mask, (size_t)B * S * 8, hipMemcpyDefault, st));
     hipLaunchKernelGGL(k_seq_len, dim3(B), dim3(64), 0, st, e->d_mask, B, S, e->seq_nk, e->seq_has0);
     hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(64), 0, st, e->seq_nk, e->seq_has0, B, pool, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->d_err);
     hipLaunchKernelGGL(k_fill_tokens, dim3(B), dim3(64), 0, st, e->d_ids, e->d_mask, S, e->cfg.vocab, e->seq_off, e->seq_nk, e->seq_nq, e->tok_id,
@@ -1183,6 +1171,84 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
     }
     hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);
     KR_HIP(hipGetLastError());
+    return 0;
+}
+
+// Small batches are launch-bound (a 1 x 32-token forward is ~175 launches of 6-13 us).  With KIRAG_AMD_GRAPH=1 (read at kr_encoder_create; OFF by
+// default) the kernel sequence of a (B, S, pool) shape is replayed as ONE hipGraph from its second forward on.  Measured on MI355X / ROCm 7.2
+// (tools/graph_bench.py, two encoders interleaved in one process, outputs bit-identical): replay is SLOWER than the eager launches, both back to back
+// and with a synchronisation after every forward — 1 x 32 tokens 1.40 vs 1.20 ms, 2 x 256 2.14 vs 1.95, 8 x 128 2.31 vs 2.12, 100 x 32 3.42 vs 3.29 —
+// about 1.1 us per graph node more than the launch it replaces, so the default stays eager (the asynchronous boundary already lets the host run ahead).  The first forward of a shape runs eagerly (it also sets the function
+// attributes, which must not happen during capture); capture and replay use an internal stream (the caller's may be the legacy default stream,
+// which cannot be captured), ordered against the caller's stream by events.  Any failure falls back to eager launches for good.
+constexpr int64_t GRAPH_MAX_TOKENS = 4096;
+static int run_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
+    const int64_t maxT = (int64_t)B * (S + 4);
+    if (e->graphs_off || maxT > GRAPH_MAX_TOKENS) return enqueue_forward(e, B, S, pool, st);
+    const uint64_t key = ((uint64_t)B << 32) | ((uint64_t)S << 8) | (uint64_t)pool;
+    GraphEntry* ent = nullptr;
+    for (auto& g : e->graphs) if (g.key == key) { ent = &g; break; }
+    if (!ent) {
+        if (e->graphs.size() >= 32) drop_graphs(e);
+        e->graphs.push_back(GraphEntry{key, 0, nullptr});
+        ent = &e->graphs.back();
+    }
+    ent->calls++;
+    if (ent->calls == 1) return enqueue_forward(e, B, S, pool, st);
+    if (!e->gstream) {
+        if (hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e->graphs_off = true; return enqueue_forward(e, B, S, pool, st); }
+    }
+    if (!ent->exec) {
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(e->gstream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const int rc = enqueue_forward(e, B, S, pool, e->gstream);
+            const hipError_t ce = hipStreamEndCapture(e->gstream, &graph);
+            ok = rc == 0 && ce == hipSuccess && graph != nullptr && hipGraphInstantiate(&ent->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        if (!ok) { (void)hipGetLastError(); ent->exec = nullptr; e->graphs_off = true; return enqueue_forward(e, B, S, pool, st); }
+    }
+    KR_HIP(hipEventRecord(e->ev_in, st));
+    KR_HIP(hipStreamWaitEvent(e->gstream, e->ev_in, 0));
+    KR_HIP(hipGraphLaunch(ent->exec, e->gstream));
+    KR_HIP(hipEventRecord(e->ev_out, e->gstream));
+    KR_HIP(hipStreamWaitEvent(st, e->ev_out, 0));
+    return 0;
+}
+
+// the sticky device error word has been copied to e->h_err and that copy has completed
+static int report_token_error(Encoder* e, hipStream_t st) {
+    if (*e->h_err == 0) return 0;
+    *e->h_err = 0;
+    KR_HIP(hipMemsetAsync(e->d_err, 0, sizeof(int), st));
+    return fail(KR_EINVAL, "input_ids contain a token id outside [0, %d)", e->cfg.vocab);
+}
+
+int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* attention_mask, int B, int S, int pool, float* out, void* stream) {
+    if (!h) return fail(KR_EINVAL, "encoder is NULL");
+    Encoder* e = reinterpret_cast<Encoder*>(h);
+    if (!e->ready) return fail(KR_ESTATE, "encoder weights incomplete: call kr_encoder_finalize after loading every tensor");
+    if (B < 0 || S <= 0 || (B > 0 && (!input_ids || !attention_mask || !out))) return fail(KR_EINVAL, "bad input pointers / shape");
+    if (S > e->cfg.max_pos) return fail(KR_EINVAL, "sequence length %d exceeds max_position_embeddings %d", S, e->cfg.max_pos);
+    if (pool != KR_POOL_MEAN && pool != KR_POOL_CLS) return fail(KR_EINVAL, "pool must be 0 (mean) or 1 (cls)");
+    if (B == 0) return 0;
+    if (B > 65535) return fail(KR_EINVAL, "at most 65535 sequences per call");
+    KR_TRY(select_device(e->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (e->pending) {
+        if (st != e->last_stream) KR_HIP(hipEventSynchronize(e->ev_done));      // the workspace is shared: a forward on another stream waits for the previous one
+        if (hipEventQuery(e->ev_done) == hipSuccess) {                          // finished: report its token-id error now (never blocks)
+            e->pending = false;
+            KR_TRY(report_token_error(e, st));
+        }
+    }
+    KR_TRY(ensure_ws(e, B, S));
+    const int H = e->cfg.hidden;
+    KR_HIP(hipMemcpyAsync(e->d_ids, input_ids, (size_t)B * S * 8, hipMemcpyDefault, st));
+    KR_HIP(hipMemcpyAsync(e->d_mask, attention_mask, (size_t)B * S * 8, hipMemcpyDefault, st));
+    KR_TRY(run_forward(e, B, S, pool, st));
     KR_HIP(hipMemcpyAsync(out, e->out, (size_t)B * H * 4, hipMemcpyDefault, st));
     e->lastB = B; e->lastS = S; e->last_stream = st;
     KR_HIP(hipMemcpyAsync(e->h_err, e->d_err, sizeof(int), hipMemcpyDeviceToHost, st));

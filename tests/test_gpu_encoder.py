@@ -223,3 +223,40 @@ def test_projection_paths_are_bit_identical(golden, monkeypatch):
     for tile in ("128", "130", "32"):
         assert np.array_equal(outs[tile][0].view(np.uint32), outs["256"][0].view(np.uint32)), tile
         assert np.array_equal(outs[tile][1].view(np.uint32), outs["256"][1].view(np.uint32)), tile
+
+
+def test_small_batch_forwards_replayed_as_hip_graphs_are_bit_identical():
+    """KIRAG_AMD_GRAPH=1 (opt-in; measured slower than eager launches on this stack, so off by default): from the second forward of a (B, S, pool) shape
+    with at most 4096 tokens on, the ~175 launches of a forward are replayed as one hipGraph.  Replays must equal the eager forwards bit for bit, for
+    changing inputs, interleaved shapes, both pooling modes and a workspace re-allocation in between (captured pointers are dropped)."""
+    import os
+    from types import SimpleNamespace
+    import torch
+    from oracle import encoder_np as E
+    from kirag_amd.retriever.encoders import HipBertForward
+    cfg = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
+                          max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    w = E.synth_weights(128, 2, 512, 1000, 512, seed=5)
+    eager = HipBertForward(cfg, 0); eager.load_state(w)
+    os.environ["KIRAG_AMD_GRAPH"] = "1"
+    try:
+        h = HipBertForward(cfg, 0); h.load_state(w)
+    finally:
+        del os.environ["KIRAG_AMD_GRAPH"]
+    shapes = [(1, 32), (2, 256), (8, 128), (1, 32), (4, 64)]
+    data = {}
+    for rnd in range(4):
+        for (B, S) in shapes:
+            ids, mask = E.synth_tokens(B, S, seed=100 * rnd + B + S, ragged=True, vocab_lo=5, vocab_hi=1000, min_len=3)
+            for pool in (0, 1):
+                a = h.forward(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda(), pool)      # eager on round 0, captured on round 1, replayed after
+                b = eager.forward(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda(), pool)
+                assert torch.equal(a, b), (rnd, B, S, pool)
+        if rnd == 1:                                                    # a bigger batch re-allocates the workspace: every captured graph must go
+            ids, mask = E.synth_tokens(64, 200, seed=7, ragged=True, vocab_lo=5, vocab_hi=1000, min_len=3)
+            assert torch.equal(h.forward(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda(), 0),
+                               eager.forward(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda(), 0))
+    ids, mask = E.synth_tokens(2, 40, seed=3, ragged=True, vocab_lo=5, vocab_hi=1000, min_len=3)
+    ref = E.e5_encode(w, ids, mask, 2)
+    for _ in range(3):
+        assert np.abs(h.forward_np(ids, mask, 0) - ref).max() < 4e-3    # host-pointer path through the same replay
