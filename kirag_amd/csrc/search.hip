@@ -22,6 +22,7 @@
 #include "gemm_nt.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <type_traits>
@@ -42,6 +43,7 @@ constexpr int SORT_CHUNK = 4096;             // keys per block of the merge tree
 // physical chunks are mapped as the row count grows (hipMemAddressReserve / hipMemCreate / hipMemMap).  The rows never move, so appending to a
 // 100-GB index needs neither a second allocation nor a device-to-device copy (round 1: grow() = hipMalloc of 1.5x + full copy, a transient 2.5x
 // footprint whenever the caller had not called reserve()).
+static std::atomic<unsigned long long> g_va_retired{0};   // bytes of virtual address space retired by released VBufs (see VBuf::release)
 struct VBuf {
     char* base = nullptr;
     size_t reserved = 0, mapped = 0, chunk = 0;
@@ -88,7 +90,15 @@ struct VBuf {
     void release() {
         for (size_t i = 0; i < handles.size(); ++i) { (void)hipMemUnmap(base + i * chunk, chunk); (void)hipMemRelease(handles[i]); }
         handles.clear(); mapped = 0;
-        if (base) (void)hipMemAddressFree(base, reserved);
+        // The address range is deliberately NOT handed back (hipMemAddressFree): on ROCm 7.2 / gfx950 a range that is freed, reserved again (the runtime
+        // returns the same addresses) and mapped to new physical chunks is read by kernels through stale translations — the fp32 rows a copy engine
+        // reads back are correct while the scan kernels see other memory (found by tests/soak_gpu.py; tools/vmm_va_reuse_repro.py, fixed when the range
+        // is never reused).  Physical memory IS returned (unmap + release above); only virtual addresses are retired, counted in g_va_retired, and
+        // grow() stops using this path before the 47-bit address space could run short.
+        if (base) {
+            if (getenv("KIRAG_AMD_DEBUG_FREE_VA")) (void)hipMemAddressFree(base, reserved);   // the broken behaviour, for the repro tool only
+            else g_va_retired.fetch_add(reserved);
+        }
         base = nullptr; reserved = 0;
     }
 };
@@ -882,7 +892,7 @@ static int grow(Index* ix, int64_t want) {
     if (ix->vmm < 0 && (size_t)want * (row_f + row_c) >= ((size_t)256 << 20)) {
         ix->vmm = 0;
         size_t free_b = 0, total_b = 0;
-        if (!getenv("KIRAG_AMD_NO_VMM") && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+        if (!getenv("KIRAG_AMD_NO_VMM") && g_va_retired.load() < (48ull << 40) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
             const size_t max_rows = total_b / (row_f + row_c) + 4096;          // more rows than the device could ever hold
             if (ix->vf.init(ix->device, max_rows * row_f) == 0 && ix->vc.init(ix->device, max_rows * row_c) == 0) ix->vmm = 1;
             else { ix->vf.release(); ix->vc.release(); }

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised soak of the HIP paths on one GPU (python tests/soak_gpu.py [seconds] [seed]; not collected by pytest): every case is checked on the device itself —
-  * index: certified MFMA scan (mode 0, every coarse kernel variant: <= 32 / <= 128 / 1024-query blocks, 1..4 rounds, incremental adds) must equal the
-    exact fp64 scan (mode 1) in rows and score bits;
+  * index: certified MFMA scan (mode 0, every coarse kernel variant: <= 32 / <= 128 / 1024-query blocks, 1..4 rounds, incremental adds, k up to 1024,
+    clustered / near-duplicate data that sends queries to pass 2) must equal the exact scan (mode 1) AND the fp64-MFMA pass alone (mode 2) in rows and
+    score bits; every fourth case with every canonical score forced through the integer super-accumulator; every sixth case with non-unit row norms;
+    a sample of scores against torch's fp32 matmul (independent arithmetic);
   * encoder (tiny config): the four projection main loops (KIRAG_AMD_PROJ_TILE = 256 / 130 / 128 / 32) must agree bit for bit, and a sequence's
     embedding must not depend on the rest of the batch.
 Exits non-zero on the first mismatch; prints one line per 25 cases."""
@@ -14,6 +16,7 @@ import torch
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
+from kirag_amd import _lib
 from kirag_amd.retriever.index import FlatIPIndex
 from kirag_amd.retriever.encoders import HipBertForward
 
@@ -31,9 +34,13 @@ while time.time() < t_end - budget * 0.35:
     d = int(rng.choice([64, 128, 384, 512, 768, 1024]))
     n = int(rng.choice([1, 7, 100, 1000, 5000, 33333, 120000, 300000])) + int(rng.integers(0, 50))
     nq = int(rng.choice([1, 2, 5, 31, 32, 33, 100, 128, 129, 300, 1000]))
-    k = int(min(n, rng.choice([1, 3, 10, 20, 100, 256])))
+    k = int(min(n, rng.choice([1, 3, 10, 20, 100, 256, 600, 1024])))
     ix = FlatIPIndex(d, device=0)
     x = unit(n, d)
+    if cases % 5 == 1 and n > 50:                       # a tight cluster (half of the rows within ~1e-4 of one direction): pass 1 cannot certify there
+        x[: n // 2] = torch.nn.functional.normalize(x[0] + float(rng.choice([1e-3, 1e-4, 2e-5])) * torch.randn(n // 2, d, device="cuda"), dim=1)
+    if cases % 6 == 2:
+        x = x * float(rng.choice([0.01, 3.0, 250.0]))
     if n > 10 and rng.random() < 0.5:
         cut = int(rng.integers(1, n))
         ix.add(x[:cut]); ix.add(x[cut:])
@@ -44,14 +51,39 @@ while time.time() < t_end - budget * 0.35:
         ix = FlatIPIndex(d, device=0); ix.add(x2); x = x2
     pick = torch.from_numpy(rng.integers(0, n, nq)).cuda()
     q = torch.nn.functional.normalize(x[pick] + 0.3 * torch.randn(nq, d, device="cuda") / d ** 0.5, dim=1)
+    force = cases % 4 == 3
+    if force:
+        _lib.check(_lib.load().kr_set_option(b"force_exact_scores", 1))
     s0, i0 = ix.search(q, k)
-    s1, i1 = ix.search(q, k, mode=1)
-    if not (np.array_equal(i0, i1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32))):
-        print("INDEX MISMATCH", dict(n=n, d=d, nq=nq, k=k, seed=seed, case=cases), flush=True)
+    if force:
+        _lib.check(_lib.load().kr_set_option(b"force_exact_scores", 0))
+    nq1 = min(nq, 8)                                    # the per-query exact scan is slow by design: a few queries
+    s1, i1 = ix.search(q[:nq1], k, mode=1)
+    why = []
+    ok = np.array_equal(i0[:nq1], i1) and np.array_equal(s0[:nq1].view(np.uint32), s1.view(np.uint32))
+    if not ok:
+        why.append(("mode0 != mode1", int((i0[:nq1] != i1).sum()), int((s0[:nq1].view(np.uint32) != s1.view(np.uint32)).sum())))
+    if d <= 2048:
+        s2, i2 = ix.search(q, k, mode=2)
+        ok2 = np.array_equal(i0, i2) and np.array_equal(s0.view(np.uint32), s2.view(np.uint32))
+        if not ok2:
+            bad = np.nonzero((i0 != i2).any(1) | (s0.view(np.uint32) != s2.view(np.uint32)).any(1))[0]
+            why.append(("mode0 != mode2", bad[:5].tolist(), i0[bad[0]][:4].tolist(), i2[bad[0]][:4].tolist(), s0[bad[0]][:4].tolist(), s2[bad[0]][:4].tolist(), ix.stats()))
+        ok = ok and ok2
+    ref = (q[:4] @ x.T).cpu().numpy()                   # independent arithmetic: fp32 matmul scores of the returned rows
+    got = np.take_along_axis(ref, i0[:4], axis=1)
+    scale = float(np.abs(ref).max()) + 1e-30
+    ok3 = np.abs(got - s0[:4]).max() <= 4e-6 * scale and (np.diff(s0, axis=1) <= 0).all()
+    if not ok3:
+        why.append(("fp32 matmul / order", float(np.abs(got - s0[:4]).max()), scale, i0[:4, :3].tolist(), pick[:4].tolist(), s0[:4, :3].tolist(), got[:, :3].tolist(),
+                    (q[:4] * x[torch.from_numpy(i0[:4, 0]).cuda()]).sum(1).tolist(), float((ix.reconstruct_n(int(i0[0, 0]), 1)[0] - x[int(i0[0, 0])].cpu().numpy()).max())))
+    ok = ok and ok3
+    if not ok:
+        print("INDEX MISMATCH", dict(n=n, d=d, nq=nq, k=k, seed=seed, case=cases, force=force), why, flush=True)
         sys.exit(1)
     cases += 1
     if cases % 25 == 0:
-        print(f"[stress] {cases} cases ok (last index case n={n} d={d} nq={nq} k={k}, stats {ix.stats()['certified']}/{ix.stats()['queries']} certified)", flush=True)
+        print(f"[stress] {cases} cases ok (last index case n={n} d={d} nq={nq} k={k}, stats {ix.stats()['certified']} certified / {ix.stats()['fine']} fine / {ix.stats()['exact']} exact of {ix.stats()['queries']})", flush=True)
     del ix, x
 
 # ---- encoder -----------------------------------------------------------------------------------------------------------------------------

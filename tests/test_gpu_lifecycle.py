@@ -140,3 +140,25 @@ def test_large_index_grows_in_place_without_copies():
     del ix
     torch.cuda.synchronize()
     assert base - _free_bytes() < (64 << 20)
+
+
+def test_large_index_destroyed_and_recreated_sees_its_own_rows():
+    """Found by tests/soak_gpu.py: a large (mapped-chunk) index is destroyed and another one created right after, with no other allocation in between.
+    The second one must get fresh virtual addresses: on ROCm 7.2 a freed-and-reused range is read by kernels through stale translations (self-matches
+    were not found while reconstruct_n returned the right rows).  Several cycles, one and two adds, searches in all three modes."""
+    from kirag_amd.retriever.index import FlatIPIndex
+    n, d = 120_018, 1024
+    x = torch.nn.functional.normalize(torch.randn(n, d, device="cuda"), dim=1)
+    ix = FlatIPIndex(d); ix.add(x[:70_000]); ix.add(x[70_000:])
+    for cycle in range(4):
+        x2 = x.clone(); x2[n - 3] = x2[1]
+        if cycle % 2:
+            del ix
+        ix = FlatIPIndex(d); ix.add(x2); x = x2
+        q = x[:7].clone()
+        for mode in (0, 2, 1):
+            s, i = ix.search(q, 1, mode=mode)
+            assert i[:, 0].tolist() == [0, 1, 2, 3, 4, 5, 6] and (s[:, 0] > 0.9999).all(), (cycle, mode, i[:, 0].tolist(), s[:, 0].tolist())
+        s300, i300 = ix.search(x[1000:1300].clone(), 1)
+        assert np.array_equal(i300[:, 0], np.arange(1000, 1300))
+        assert np.array_equal(ix.reconstruct_n(n - 5, 5), x[n - 5:].cpu().numpy())
