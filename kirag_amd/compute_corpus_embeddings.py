@@ -116,17 +116,26 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
             if len(buf_ids) == cap:
                 flush(file_start + cap)
 
+    class _Done:                                             # event stand-in for a host-only model (the CPU tests of the file contract)
+        def synchronize(self): pass
+    on_gpu = torch.device(device).type == "cuda"
     hidden = None
     for cpu_inputs, ids in source:
-        inputs = {k: (v.pin_memory().to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in cpu_inputs.items()}
+        if on_gpu:
+            inputs = {k: (v.pin_memory().to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in cpu_inputs.items()}
+        else:
+            inputs = to_device(cpu_inputs, device)
         emb = model.doc(inputs).detach()                     # HIP path (eval mode), stays on the GPU; no host synchronisation
         if indexer is not None:
             indexer.index_data(ids, emb)                     # device-to-device append into the resident shard (stream-ordered)
         if write_files:
             hidden = emb.shape[1]
-            host = ring.pop() if ring and ring[-1].shape[0] >= emb.shape[0] else torch.empty((bs, hidden), dtype=torch.float32, pin_memory=True)
-            host[:emb.shape[0]].copy_(emb, non_blocking=True)
-            ev = torch.cuda.Event(); ev.record()
+            host = ring.pop() if ring and ring[-1].shape[0] >= emb.shape[0] else torch.empty((bs, hidden), dtype=torch.float32, pin_memory=on_gpu)
+            host[:emb.shape[0]].copy_(emb, non_blocking=on_gpu)
+            if on_gpu:
+                ev = torch.cuda.Event(); ev.record()
+            else:
+                ev = _Done()
             pending.append((ev, host, emb.shape[0], ids))
             drain(2)
     drain(0)
