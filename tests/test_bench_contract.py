@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r01/bench_plain.json, produced by `python bench.py` on an MI355X) carries every field of the driver's
+"""The committed bench line (profiles/r02/bench_plain.json, produced by `python bench.py` on an MI355X) carries every field of the driver's
 contract, with consistent arithmetic.  bench.py itself needs a GPU; this checks the artefact the round ships."""
 import json
 import os
@@ -7,7 +7,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(REPO, "profiles", "r01", "bench_plain.json")))
+    d = json.load(open(os.path.join(REPO, "profiles", "r02", "bench_plain.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
