@@ -310,6 +310,9 @@ class ShardedIndexer(Indexer):
             self.index_id_to_db_id = pickle.load(reader)
         self.row_offset, self.ntotal_global = self.index.row_offset, self.index.file_ntotal
         assert len(self.index_id_to_db_id) == self.ntotal_global, 'Deserialized index_id_to_db_id should match faiss index size'
+        # later index_data() calls append to this rank's shard: its ids so far are its slice of the loaded map
+        self._local_ids = [np.asarray(self.index_id_to_db_id[self.row_offset: self.row_offset + self.index.ntotal], dtype=np.int64)]
+        self._dirty = False
 
     def serialize(self, dir_path):
         """Collective.  Every rank writes its resident rows as one native shard file (``index_shard_RRRR_of_WWWW.krshard``); rank 0 also writes the
