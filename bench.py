@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=32)
-    ap.add_argument("--corpus-dist", default="gaussian", choices=["gaussian", "e5like", "neardup"],
+    ap.add_argument("--corpus-dist", default="gaussian", choices=["gaussian", "e5like", "mixed", "neardup"],
                     help="synthetic corpus: iid Gaussian directions (SURVEY 8d) or e5like (shared mean direction + anisotropic remainder: scores in a "
                          "narrow band around 0.75, rank-100 gaps ~5e-5 at 5M rows; kirag_amd/bench_support.py CorpusDist)")
     ap.add_argument("--plumbing-only", action="store_true",

@@ -68,6 +68,7 @@ class CorpusDist:
     """Synthetic corpus-embedding generators (rows are unit vectors, generated on the device chunk by chunk).
 
     ``gaussian``  iid Gaussian directions: pairwise cosines ~ N(0, 1/d) — the easy case for a low-precision scan.
+    ``mixed``     e5like with a 2 % cluster of near-duplicates of one passage and 3 % of the queries aiming at it: the realistic case for pass 2.
     ``neardup``   a corpus of near-duplicates (rows within 3e-5 of one direction): nothing certifies in the 16-bit pass; measures pass 2.
     ``e5like``    what real e5 / bge embeddings look like to the scan: every row shares a mean direction (pairwise cosines centred at
                   ``mean_cos`` = 0.75) and the remainder is anisotropic (spectrum lambda_i ~ 1/i over randomly permuted axes: effective
@@ -76,20 +77,32 @@ class CorpusDist:
     """
 
     def __init__(self, kind: str, d: int, device, seed: int = 3, mean_cos: float = 0.75):
-        assert kind in ("gaussian", "e5like", "neardup"), kind
+        assert kind in ("gaussian", "e5like", "neardup", "mixed"), kind
         self.kind, self.d, self.device, self.mean_cos = kind, d, device, mean_cos
         g = torch.Generator(device=device); g.manual_seed(seed * 7919 + 11)
-        if kind in ("e5like", "neardup"):
+        if kind in ("e5like", "neardup", "mixed"):
             mu = torch.randn(d, generator=g, device=device)
             self.mu = mu / mu.norm()
             lam = 1.0 / torch.arange(1, d + 1, device=device, dtype=torch.float32)
             self.scale = lam.sqrt()[torch.randperm(d, generator=g, device=device)]
+            b = torch.randn(d, generator=g, device=device) * self.scale
+            b = torch.nn.functional.normalize(b - (b @ self.mu) * self.mu, dim=0)
+            self.boiler = torch.nn.functional.normalize((mean_cos ** 0.5) * self.mu + ((1.0 - mean_cos) ** 0.5) * b, dim=0)   # the duplicated passage of "mixed"
 
     def rows(self, m: int, gen) -> torch.Tensor:
         """m unit-norm fp32 rows [m, d] drawn with the caller's generator."""
         z = torch.randn(m, self.d, generator=gen, device=self.device)
         if self.kind == "gaussian":
             return torch.nn.functional.normalize(z, dim=1)
+        if self.kind == "mixed":
+            # e5like, except that 2 % of the rows are near-duplicates of one passage (a boilerplate cluster): the queries that aim at it (3 % of a batch,
+            # queries_near) cannot be certified by the 16-bit pass and share one fp64 pass 2; everything else certifies in pass 1
+            u = z * self.scale
+            u = torch.nn.functional.normalize(u - (u @ self.mu)[:, None] * self.mu, dim=1)
+            x = torch.nn.functional.normalize((self.mean_cos ** 0.5) * self.mu + ((1.0 - self.mean_cos) ** 0.5) * u, dim=1)
+            dup = torch.rand(m, generator=gen, device=self.device) < 0.02
+            x[dup] = torch.nn.functional.normalize(self.boiler + 3e-5 * z[dup], dim=1)
+            return x
         if self.kind == "neardup":
             # adversarial for a 16-bit scan: every row within ~3e-5 of one direction, so ALL scores of a query fall inside the bf16 error bound and
             # pass 1 can certify nothing (the data the fp64 pass 2 exists for; round 1 answered it with one full fp32 scan PER QUERY)
@@ -108,6 +121,14 @@ class CorpusDist:
             return torch.nn.functional.normalize(head + noise * z, dim=1)
         if self.kind == "neardup":
             return torch.nn.functional.normalize(self.mu + 0.3 * torch.nn.functional.normalize(z, dim=1), dim=1)
+        if self.kind == "mixed":
+            kind, self.kind = self.kind, "e5like"
+            q = self.queries_near(head, gen, noise)
+            self.kind = kind
+            n_aim = max(1, int(0.03 * len(q)))                      # 3 % of the batch asks for the boilerplate passage
+            w = torch.nn.functional.normalize(z[:n_aim] * self.scale, dim=1)
+            q[:n_aim] = torch.nn.functional.normalize(self.boiler + 0.2 * w, dim=1)
+            return q
         u = torch.nn.functional.normalize(head - (head @ self.mu)[:, None] * self.mu, dim=1)
         w = z * self.scale
         w = torch.nn.functional.normalize(w - (w @ self.mu)[:, None] * self.mu, dim=1)

@@ -114,6 +114,9 @@ struct Index {
     // search workspace (sized for QBLK queries)
     float* q_f = nullptr;      // [QBLK, d]
     float* q_f2 = nullptr;     // [FINE_QMAX, d] compacted flagged queries of the high-precision pass
+    float* theta1 = nullptr;   // [QBLK] pass 1's b_k - 2 eps per query (k_rerank)
+    float* thr_mark = nullptr; // [32] the same, compacted for the group being pre-scanned
+    uint32_t* bitmap = nullptr; size_t bitmap_words = 0;   // one bit per 32-row slot (pass 2 pre-scan)
     int force_exact = 0;       // test hook: every canonical score through the integer super-accumulator
     uint16_t* q_c = nullptr;   // [QBLK, dpad]
     float* thr = nullptr;      // [QBLK]
@@ -223,6 +226,7 @@ struct CoarseArgs {
     int64_t tile_begin, tile_count;   // this round covers permuted tile slots [tile_begin, tile_begin + tile_count)
     int64_t ntiles, perm_mul;         // slot -> tile = (slot * perm_mul) % ntiles   (perm_mul coprime to ntiles)
     const float* xf; const float* qf; int d;   // high-precision pass (k_fine): fp32 master rows, compacted fp32 queries
+    uint32_t* bitmap;                          // one bit per 32-row slot: set by the marking scan (k_coarse_q32 MODE 2), read by k_fine (nullptr: every slot)
 };
 
 // persistent streaming coarse scan (gemm_nt_pingpong): grid = one block per CU, so nothing else on the CU hides an epilogue
@@ -376,7 +380,9 @@ template <int KT> constexpr int q32_lds() { return 4 * Q32Ring<KT>::value * 4096
 // (the body is a function with a __restrict__ corpus pointer on purpose: after inlining, the LDS-DMA carries that pointer's alias scope and the ring's
 // ds_reads are marked as not aliasing it, which is what lets the compiler's waitcnt pass leave the counted vmcnt waits alone; without it it inserts
 // s_waitcnt vmcnt(0) before every LDS read that follows an LDS-DMA, i.e. no K-tile would ever be in flight)
-template <class T, bool DIRECT, int KT>
+// MODE 0: threshold filter -> wave lists;  1: direct store of every score (round 0);  2: MARK — set bit `tile` of a.bitmap when any of the slot's
+// 32 x 32 scores reaches its query's threshold (a.thr; the pre-scan of pass 2, see search_block)
+template <class T, int MODE, int KT>
 __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint16_t* __restrict__ xc, const uint16_t* __restrict__ qc, char* smem) {
     constexpr int RING = Q32Ring<KT>::value;
     static_assert(KT % RING == 0, "ring slots must be static in the unrolled K loop");
@@ -393,6 +399,7 @@ __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint1
 #pragma unroll
         for (int ks = 0; ks < KT * 4; ++ks) bq[ks] = *reinterpret_cast<const uint4*>(qrow + ks * 16);
     }
+    constexpr bool DIRECT = MODE == 1;
     const float thr = DIRECT ? 0.f : a.thr[lane & 31];
     const uint32_t q = (uint32_t)(lane & 31);
     // this wave's tile slots: s = w, w + W, w + 2W, ... of the round's [0, tile_count)
@@ -455,6 +462,11 @@ __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint1
                         cq[ro] = make_key(acc[r], row_base + (uint32_t)ro);
                     }
                 }
+            } else if constexpr (MODE == 2) {
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) any |= (acc[r] >= thr);        // NaN scores (padding rows, NaN rows) never mark
+                if (__ballot(any) && lane == 0) atomicOr(a.bitmap + (m0 >> 10), 1u << ((m0 >> 5) & 31));
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -474,13 +486,13 @@ __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint1
             }
         }
     }
-    if constexpr (!DIRECT) scatter_wave_lists(a, smem, wave_id, wcnt, Q32_THREADS);
+    if constexpr (MODE == 0) scatter_wave_lists(a, smem, wave_id, wcnt, Q32_THREADS);
 }
 
-template <class T, bool DIRECT, int KT>
+template <class T, int MODE, int KT>
 __global__ __launch_bounds__(Q32_THREADS, 1) void k_coarse_q32(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    coarse_q32_body<T, DIRECT, KT>(a, a.xc, a.qc, smem);
+    coarse_q32_body<T, MODE, KT>(a, a.xc, a.qc, smem);
 }
 
 
@@ -534,6 +546,23 @@ __global__ __launch_bounds__(FINE_THREADS, 2) void k_fine(CoarseArgs a) {
         uint64_t qq; uint32_t tile;
         fast_divmod64((uint64_t)(a.tile_begin + w0 + i * W) * (uint64_t)a.perm_mul, (uint32_t)a.ntiles, qq, tile);
         const int64_t m0 = (int64_t)tile * 32;
+        if (a.bitmap != nullptr && !((a.bitmap[tile >> 5] >> (tile & 31)) & 1u)) {
+            // the 16-bit pre-scan found no row of this slot that any query of the group could still need (wave-uniform test, one scalar load)
+            if constexpr (DIRECT) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const uint32_t q = (uint32_t)(16 * nt + (lane & 15));
+                    if (q < (uint32_t)a.nq) {
+                        uint64_t* cq = a.cand + (int64_t)q * a.cand_cap + (w0 + i * W) * 32;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cq[16 * t + (lane >> 4) + 4 * r] = 0ull;
+                    }
+                }
+            }
+            continue;
+        }
         const float* pa[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -640,6 +669,12 @@ __global__ void k_gather_rows(const float* __restrict__ src, const int* __restri
     const int g = blockIdx.x;
     const float* s = src + (int64_t)qidx[g] * d;
     for (int i = threadIdx.x * 4; i < d; i += blockDim.x * 4) *reinterpret_cast<float4*>(dst + (int64_t)g * d + i) = *reinterpret_cast<const float4*>(s + i);
+}
+
+// thr_mark[g] = theta1[qidx[g]] for g < n, +inf for the padding up to 32 (the marking scan's per-query thresholds)
+__global__ void k_gather_theta(const float* __restrict__ theta1, const int* __restrict__ qidx, int n, float* __restrict__ out) {
+    const int g = threadIdx.x;
+    if (g < 32) out[g] = g < n ? theta1[qidx[g]] : INFINITY;
 }
 
 // state reset + error bound of the high-precision pass for queries [0, nq) of the compacted list (blocks nq .. nq_pad-1: padding, thr = +inf).
@@ -758,7 +793,9 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
                                                 uint32_t* __restrict__ flags, const float* __restrict__ thr, const float* __restrict__ eps,
                                                 const float* __restrict__ qf, const float* __restrict__ xf, int d, int k, int preset, int rmax,
                                                 float* __restrict__ out_s, int64_t* __restrict__ out_r, uint32_t* __restrict__ nrer,
-                                                const int* __restrict__ qmap, int force_exact) {
+                                                const int* __restrict__ qmap, int force_exact, float* __restrict__ theta_out) {
+    // theta_out[q] (pass 1 only): b_k - 2 eps of THIS pass = a bound below which a row's score in this pass's arithmetic rules it out of the top-k
+    // (-inf when the query has fewer than k candidates); pass 2 pre-scans with it so that its fp64 work touches only slots that can matter
     // qmap != nullptr: the blocks work on a compacted query list (the high-precision pass over flagged queries); results go to row qmap[q]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ unsigned long long exact_limbs[4][EXACT_NLIMB];
@@ -771,7 +808,7 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
     bool ok = (flags[q] == 0u);
     if (m > cand_cap) { m = cand_cap; ok = false; }
     if (m < k) {   // fewer candidates than k (NaN rows, overflow truncation): the exact scan decides
-        if (tid == 0) { flags[q] |= 2u; nrer[q] = 0; }
+        if (tid == 0) { flags[q] |= 2u; nrer[q] = 0; if (theta_out) theta_out[q] = -INFINITY; }
         return;
     }
     const uint64_t* c = cand + (int64_t)q * cand_cap;
@@ -780,6 +817,7 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
     __syncthreads();
     const float bk = ord_f32(radix_select_desc<256>(s, m, k, hist, tid));               // k-th best coarse score (NaN if fewer than k real scores)
     const float theta = bk - 2.f * eps[q];
+    if (theta_out && tid == 0) theta_out[q] = (theta == theta) ? theta : -INFINITY;
     // the buffer is complete for coarse scores >= thr (everything at or above the threshold of the last round was appended / kept)
     const bool certified = ok && (theta > thr[q]);
     for (int i = tid; i < m; i += 256) {
@@ -957,6 +995,8 @@ static int ensure_ws(Index* ix, int k, int cand_cap) {
         KR_HIP(hipMalloc(&ix->flags, QBLK * sizeof(uint32_t)));
         KR_HIP(hipMalloc(&ix->nrer, QBLK * sizeof(uint32_t)));
         KR_HIP(hipMalloc(&ix->q_f2, (size_t)32 * ix->d * sizeof(float)));
+        KR_HIP(hipMalloc(&ix->theta1, QBLK * sizeof(float)));
+        KR_HIP(hipMalloc(&ix->thr_mark, 32 * sizeof(float)));
         KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->h_status), (5 * QBLK + 8) * sizeof(uint32_t), hipHostMallocDefault));
         KR_HIP(hipMalloc(&ix->ex_qidx, QBLK * sizeof(int)));
         KR_HIP(hipMalloc(&ix->blk_list, (size_t)ix->num_cu * ShapeC::NWAVE * WLISTCAP * sizeof(uint4)));
@@ -1037,12 +1077,14 @@ static int launch_q32_kt(const CoarseArgs& a, int num_cu, int device, hipStream_
     constexpr int lds = q32_lds<KT>();
     static DevOnce once;
     KR_TRY(once_per_device(once, device, [&]() -> int {
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse_q32<T, true, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse_q32<T, false, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse_q32<T, 1, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse_q32<T, 0, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse_q32<T, 2, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         return 0;
     }));
-    if (a.direct) hipLaunchKernelGGL((k_coarse_q32<T, true, KT>), dim3(num_cu), dim3(Q32_THREADS), lds, st, a);
-    else hipLaunchKernelGGL((k_coarse_q32<T, false, KT>), dim3(num_cu), dim3(Q32_THREADS), lds, st, a);
+    if (a.direct == 2) hipLaunchKernelGGL((k_coarse_q32<T, 2, KT>), dim3(num_cu), dim3(Q32_THREADS), lds, st, a);
+    else if (a.direct) hipLaunchKernelGGL((k_coarse_q32<T, 1, KT>), dim3(num_cu), dim3(Q32_THREADS), lds, st, a);
+    else hipLaunchKernelGGL((k_coarse_q32<T, 0, KT>), dim3(num_cu), dim3(Q32_THREADS), lds, st, a);
     return 0;
 }
 template <class T>
@@ -1117,7 +1159,7 @@ static int launch_rerank(Index* ix, int nq, int k, int rmax, int final_preset, c
     const size_t rer_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + (size_t)rmax * sizeof(uint64_t) + 264 * sizeof(unsigned int);
     auto rerank = ix->d <= 1024 ? &k_rerank<4> : ix->d <= 2048 ? &k_rerank<8> : &k_rerank<16>;   // row steps held in registers
     hipLaunchKernelGGL(rerank, dim3(nq), dim3(256), rer_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, ix->eps, qf, ix->xf, ix->d, k,
-                       final_preset, rmax, ix->out_s, ix->out_r, ix->nrer, qmap, ix->force_exact);
+                       final_preset, rmax, ix->out_s, ix->out_r, ix->nrer, qmap, ix->force_exact, qmap ? nullptr : ix->theta1);
     KR_HIP(hipGetLastError());
     return 0;
 }
@@ -1153,7 +1195,7 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
     a.xc = ix->xc; a.n = ix->n; a.dpad = ix->dpad; a.qc = ix->q_c;
     a.thr = ix->thr; a.cnt = ix->cnt; a.flags = ix->flags; a.cand = ix->cand; a.cand_cap = ix->cand_cap;
     a.blk_list = ix->blk_list; a.blk_cnt = ix->blk_cnt; a.list_overflow = ix->blk_cnt + ix->num_cu * ShapeC::NWAVE;
-    a.xf = ix->xf; a.d = ix->d;
+    a.xf = ix->xf; a.d = ix->d; a.bitmap = nullptr;
     const size_t blk_cnt_bytes = ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int);
     // ---- pass 1: 16-bit MFMA scan + certified re-rank, all queries -----------------------------------------------------------------------
     if (coarse_pass) {
@@ -1216,6 +1258,30 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
             const int nt = g <= 16 ? 1 : 2;
             const int* qmap = ix->ex_qidx + g0;
             hipLaunchKernelGGL(k_gather_rows, dim3(g), dim3(256), 0, st, ix->q_f, qmap, ix->q_f2, ix->d);
+            // pre-scan: one HBM-bound pass of the 16-bit copy with the group's queries in registers (the <= 32-query stream kernel, MODE 2) marks the
+            // 32-row slots in which some row reaches theta1 = b_k - 2 eps of pass 1 for some query of the group; a row below that bound is strictly
+            // below the query's k-th exact score (the k best coarse rows all have exact >= b_k - eps), so the fp64 scan may skip every unmarked slot.
+            // A boilerplate cluster of 2 % of the corpus thus costs one 1.6-ms stream + 2 % of the fp64 work instead of the full 6-ms fp64 pass.
+            a.bitmap = nullptr;
+            const bool can_mark = coarse_pass && (kt64 == 16 || kt64 == 12 || kt64 == 8 || kt64 == 6) && !getenv("KIRAG_AMD_NO_MARK");
+            if (can_mark) {
+                const size_t words = (size_t)((ix->n + 31) / 32 + 31) / 32 + 1;
+                if (words > ix->bitmap_words) {
+                    if (ix->bitmap) (void)hipFree(ix->bitmap);
+                    ix->bitmap = nullptr; ix->bitmap_words = 0;
+                    KR_HIP(hipMalloc(&ix->bitmap, words * sizeof(uint32_t)));
+                    ix->bitmap_words = words;
+                }
+                KR_HIP(hipMemsetAsync(ix->bitmap, 0, words * sizeof(uint32_t), st));
+                hipLaunchKernelGGL(k_prep_queries<T>, dim3(32), dim3(64), 0, st, ix->q_f2, ix->q_c, g, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr, ix->cnt, ix->flags);
+                hipLaunchKernelGGL(k_gather_theta, dim3(1), dim3(64), 0, st, ix->theta1, qmap, g, ix->thr_mark);
+                CoarseArgs m = a;
+                m.qc = ix->q_c; m.nq_pad = 32; m.nq = g; m.thr = ix->thr_mark; m.bitmap = ix->bitmap; m.direct = 2;
+                m.ntiles = (ix->n + 31) / 32; m.perm_mul = 1; m.tile_begin = 0; m.tile_count = m.ntiles;
+                KR_TRY((launch_q32<T>(m, kt64, ix->num_cu, ix->device, st)));
+                a.bitmap = ix->bitmap;
+                ix->st.marked_passes++;
+            }
             hipLaunchKernelGGL(k_prep_fine<0>, dim3(16 * nt), dim3(64), 0, st, ix->q_f2, g, ix->d, ix->bounds, ix->eps, ix->thr, ix->cnt, ix->flags);
             KR_HIP(hipMemsetAsync(ix->blk_cnt, 0, blk_cnt_bytes, st));
             a.nq_pad = 16 * nt; a.nq = g; a.qf = ix->q_f2;
@@ -1352,7 +1418,7 @@ void kr_index_destroy(kr_index* h) {
     Index* ix = reinterpret_cast<Index*>(h);
     (void)hipSetDevice(ix->device);
     if (ix->vmm == 1) { (void)hipDeviceSynchronize(); ix->vf.release(); ix->vc.release(); ix->xf = nullptr; ix->xc = nullptr; }
-    void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_f2, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
+    void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_f2, ix->theta1, ix->thr_mark, ix->bitmap, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
                     ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ix->h_status) (void)hipHostFree(ix->h_status);
