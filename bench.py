@@ -306,7 +306,7 @@ def main():
                                  "around each launch on its stream; algorithmic FLOPs = 2*nq*rows*dim; the bf16 MFMA-only loop measured on this "
                                  "device sustains ~1.6-1.7 PFLOP/s on random data (tools/gemm_bench.hip)"},
             "encode": enc_info,
-            "search_stats": {kk: st[kk] for kk in ("queries", "certified", "fallback", "fine", "exact", "overflow", "reranked_rows", "coarse_rounds", "fine_rounds")},
+            "search_stats": {kk: st[kk] for kk in ("queries", "certified", "fallback", "fine", "exact", "overflow", "reranked_rows", "coarse_rounds", "fine_rounds", "marked_passes", "marked_rows")},
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(args, q_vec.cpu().numpy(), encoder is not None, args.corpus_dist)

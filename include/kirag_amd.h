@@ -100,7 +100,8 @@ typedef struct {
     int64_t exact;            /* answered by pass 3 (exact scan) */
     int64_t fine_rounds;      /* pass-2 scan launches */
     double last_fine_ms;      /* device time of pass 2 in the last search call */
-    int64_t marked_passes;    /* pass-2 groups that were pre-scanned (16-bit stream marking the 32-row slots the fp64 scan has to visit) */
+    int64_t marked_passes;    /* pass-2 groups that were pre-scanned (16-bit stream marking the rows the fp64 scan has to visit) */
+    int64_t marked_rows;      /* rows marked by those pre-scans, summed over the groups */
 } kr_search_stats;
 int kr_index_stats(kr_index* ix, kr_search_stats* out, int reset);
 

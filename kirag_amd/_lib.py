@@ -25,7 +25,7 @@ class SearchStats(C.Structure):
     _fields_ = [("queries", C.c_int64), ("certified", C.c_int64), ("fallback", C.c_int64), ("overflow", C.c_int64),
                 ("reranked_rows", C.c_int64), ("coarse_rounds", C.c_int64), ("last_coarse_ms", C.c_double),
                 ("last_total_ms", C.c_double), ("fine", C.c_int64), ("exact", C.c_int64), ("fine_rounds", C.c_int64),
-                ("last_fine_ms", C.c_double), ("marked_passes", C.c_int64)]
+                ("last_fine_ms", C.c_double), ("marked_passes", C.c_int64), ("marked_rows", C.c_int64)]
 
 
 class BertCfg(C.Structure):

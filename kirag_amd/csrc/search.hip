@@ -116,7 +116,8 @@ struct Index {
     float* q_f2 = nullptr;     // [FINE_QMAX, d] compacted flagged queries of the high-precision pass
     float* theta1 = nullptr;   // [QBLK] pass 1's b_k - 2 eps per query (k_rerank)
     float* thr_mark = nullptr; // [32] the same, compacted for the group being pre-scanned
-    uint32_t* bitmap = nullptr; size_t bitmap_words = 0;   // one bit per 32-row slot (pass 2 pre-scan)
+    uint32_t* bitmap = nullptr; size_t bitmap_words = 0;   // one bit per row (+ one word: the list length) — pass 2 pre-scan
+    uint32_t* rowlist = nullptr;                           // the marked rows, compacted
     int force_exact = 0;       // test hook: every canonical score through the integer super-accumulator
     uint16_t* q_c = nullptr;   // [QBLK, dpad]
     float* thr = nullptr;      // [QBLK]
@@ -226,7 +227,8 @@ struct CoarseArgs {
     int64_t tile_begin, tile_count;   // this round covers permuted tile slots [tile_begin, tile_begin + tile_count)
     int64_t ntiles, perm_mul;         // slot -> tile = (slot * perm_mul) % ntiles   (perm_mul coprime to ntiles)
     const float* xf; const float* qf; int d;   // high-precision pass (k_fine): fp32 master rows, compacted fp32 queries
-    uint32_t* bitmap;                          // one bit per 32-row slot: set by the marking scan (k_coarse_q32 MODE 2), read by k_fine (nullptr: every slot)
+    uint32_t* bitmap;                          // one bit per ROW, set by the marking scan (k_coarse_q32 MODE 2)
+    const uint32_t* rowlist; int64_t nlist;    // k_fine: scan rows rowlist[0 .. nlist) instead of 0 .. n (nullptr: every row)
 };
 
 // persistent streaming coarse scan (gemm_nt_pingpong): grid = one block per CU, so nothing else on the CU hides an epilogue
@@ -463,10 +465,17 @@ __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint1
                     }
                 }
             } else if constexpr (MODE == 2) {
-                bool any = false;
+                // register r holds, for the lane's query, row (r & 3) + 8 (r >> 2) of the tile in lanes 0..31 and that row + 4 in lanes 32..63;
+                // NaN scores (padding rows, NaN rows) never mark.  The 32 rows of a tile share one bitmap word (m0 is a multiple of 32).
+                unsigned int bits = 0u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) any |= (acc[r] >= thr);        // NaN scores (padding rows, NaN rows) never mark
-                if (__ballot(any) && lane == 0) atomicOr(a.bitmap + (m0 >> 10), 1u << ((m0 >> 5) & 31));
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned long long mask = __ballot(acc[r] >= thr);
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if ((unsigned)mask) bits |= 1u << ro;
+                    if ((unsigned)(mask >> 32)) bits |= 1u << (ro + 4);
+                }
+                if (bits && lane == 0) atomicOr(a.bitmap + (m0 >> 5), bits);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -546,28 +555,13 @@ __global__ __launch_bounds__(FINE_THREADS, 2) void k_fine(CoarseArgs a) {
         uint64_t qq; uint32_t tile;
         fast_divmod64((uint64_t)(a.tile_begin + w0 + i * W) * (uint64_t)a.perm_mul, (uint32_t)a.ntiles, qq, tile);
         const int64_t m0 = (int64_t)tile * 32;
-        if (a.bitmap != nullptr && !((a.bitmap[tile >> 5] >> (tile & 31)) & 1u)) {
-            // the 16-bit pre-scan found no row of this slot that any query of the group could still need (wave-uniform test, one scalar load)
-            if constexpr (DIRECT) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const uint32_t q = (uint32_t)(16 * nt + (lane & 15));
-                    if (q < (uint32_t)a.nq) {
-                        uint64_t* cq = a.cand + (int64_t)q * a.cand_cap + (w0 + i * W) * 32;
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) cq[16 * t + (lane >> 4) + 4 * r] = 0ull;
-                    }
-                }
-            }
-            continue;
-        }
+        const int64_t n_eff = a.rowlist ? a.nlist : a.n;   // with a row list, "row" below is a position in the list; the stored key carries the real row
         const float* pa[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             int64_t row = m0 + 16 * t + (lane & 15);
-            if (row >= a.n) row = a.n - 1;             // clamped rows are masked in the epilogue
+            if (row >= n_eff) row = n_eff - 1;         // clamped rows are masked in the epilogue
+            if (a.rowlist) row = (int64_t)a.rowlist[row];
             pa[t] = a.xf + row * d + kq;
         }
         f64x4 acc[2][NT];
@@ -637,7 +631,7 @@ __global__ __launch_bounds__(FINE_THREADS, 2) void k_fine(CoarseArgs a) {
                         for (int r = 0; r < 4; ++r) {
                             const int ro = 16 * t + (lane >> 4) + 4 * r;
                             const int64_t row = m0 + ro;
-                            cq[ro] = row < a.n ? make_key((float)acc[t][nt][r], (uint32_t)row) : 0ull;
+                            cq[ro] = row < n_eff ? make_key((float)acc[t][nt][r], a.rowlist ? a.rowlist[row] : (uint32_t)row) : 0ull;
                         }
                 }
             } else {
@@ -647,12 +641,12 @@ __global__ __launch_bounds__(FINE_THREADS, 2) void k_fine(CoarseArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const int64_t row = m0 + 16 * t + (lane >> 4) + 4 * r;
                         const float sc = (float)acc[t][nt][r];
-                        const bool p = (sc >= thr[nt]) && row < a.n;          // thr = +inf for padded queries
+                        const bool p = (sc >= thr[nt]) && row < n_eff;        // thr = +inf for padded queries
                         const unsigned long long mask = __ballot(p);
                         if (mask) {
                             if (p) {
                                 const unsigned int slot = wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                                u32x4 e = {__float_as_uint(sc), (uint32_t)row, q, 0u};
+                                u32x4 e = {__float_as_uint(sc), a.rowlist ? a.rowlist[row] : (uint32_t)row, q, 0u};
                                 __builtin_amdgcn_raw_buffer_store_b128(e, wlist, slot * 16u, 0, 0);
                             }
                             wcnt += (unsigned)__popcll(mask);
@@ -669,6 +663,23 @@ __global__ void k_gather_rows(const float* __restrict__ src, const int* __restri
     const int g = blockIdx.x;
     const float* s = src + (int64_t)qidx[g] * d;
     for (int i = threadIdx.x * 4; i < d; i += blockDim.x * 4) *reinterpret_cast<float4*>(dst + (int64_t)g * d + i) = *reinterpret_cast<const float4*>(s + i);
+}
+
+// bitmap (one bit per row) -> unordered list of the marked rows; *count = its length (the order is irrelevant: the re-rank sorts by (score, row))
+__global__ __launch_bounds__(256) void k_compact_rows(const uint32_t* __restrict__ bitmap, int64_t nwords, uint32_t* __restrict__ rowlist, unsigned int* __restrict__ count) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bits = w < nwords ? bitmap[w] : 0u;
+    const unsigned c = __popc(bits);
+    // wave-aggregated reservation: one atomic per wave
+    unsigned incl = c;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) { const unsigned t = __shfl_up(incl, dlt, 64); if ((int)(threadIdx.x & 63) >= dlt) incl += t; }
+    const unsigned total = __shfl(incl, 63, 64);
+    unsigned base = 0;
+    if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(count, total);
+    base = __shfl(base, 63, 64);
+    unsigned pos = base + incl - c;
+    while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; rowlist[pos++] = (uint32_t)(w * 32 + b); }
 }
 
 // thr_mark[g] = theta1[qidx[g]] for g < n, +inf for the padding up to 32 (the marking scan's per-query thresholds)
@@ -997,7 +1008,7 @@ static int ensure_ws(Index* ix, int k, int cand_cap) {
         KR_HIP(hipMalloc(&ix->q_f2, (size_t)32 * ix->d * sizeof(float)));
         KR_HIP(hipMalloc(&ix->theta1, QBLK * sizeof(float)));
         KR_HIP(hipMalloc(&ix->thr_mark, 32 * sizeof(float)));
-        KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->h_status), (5 * QBLK + 8) * sizeof(uint32_t), hipHostMallocDefault));
+        KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->h_status), (5 * QBLK + 16) * sizeof(uint32_t), hipHostMallocDefault));
         KR_HIP(hipMalloc(&ix->ex_qidx, QBLK * sizeof(int)));
         KR_HIP(hipMalloc(&ix->blk_list, (size_t)ix->num_cu * ShapeC::NWAVE * WLISTCAP * sizeof(uint4)));
         KR_HIP(hipMalloc(&ix->blk_cnt, ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int)));
@@ -1114,8 +1125,8 @@ static void plan_buffers(int k, int& K1, int& cap, int& rmax) {
 //   thr = K1-th best; as soon as rows_seen * (cap / 64) >= rows_left the rest is ONE final round whose threshold is the r-th best seen with
 //   r = (cap/2) * seen / left  (expected cap/2 survivors), 32 <= r <= K1.
 template <class Launch>
-static int run_rounds(Index* ix, CoarseArgs& a, int nq, int bm, int K1, int cap, hipStream_t st, bool timed, Launch&& launch, int& final_preset, int& rounds) {
-    a.ntiles = (ix->n + bm - 1) / bm;
+static int run_rounds(Index* ix, CoarseArgs& a, int64_t n_rows, int nq, int bm, int K1, int cap, hipStream_t st, bool timed, Launch&& launch, int& final_preset, int& rounds) {
+    a.ntiles = (n_rows + bm - 1) / bm;
     // interleaving permutation: multiplier near ntiles / golden ratio, coprime to ntiles
     int64_t mul = std::max<int64_t>(1, (int64_t)((double)a.ntiles * 0.6180339887498949));
     while (gcd64(mul, a.ntiles) != 1) ++mul;
@@ -1138,7 +1149,7 @@ static int run_rounds(Index* ix, CoarseArgs& a, int nq, int bm, int K1, int cap,
         done += cnt_t;
         a.direct = 0;
         if (done >= a.ntiles) { final_preset = preset; break; }   // last round: k_rerank reads the buffer as it is; thr stays
-        const int64_t seen = done * bm, left = ix->n - seen;
+        const int64_t seen = done * bm, left = n_rows - seen;
         int rank = K1;
         // final round only once the rank it needs is >= 32 WITHOUT clamping: (cap/2) * seen / left >= 32.  (With a fixed "seen * 64 >= left" the
         // small buffer of k <= 25 (cap = 1024) got rank 32 with up to 32 * 64 = 2048 expected survivors: overflow -> fallback.)
@@ -1195,7 +1206,7 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
     a.xc = ix->xc; a.n = ix->n; a.dpad = ix->dpad; a.qc = ix->q_c;
     a.thr = ix->thr; a.cnt = ix->cnt; a.flags = ix->flags; a.cand = ix->cand; a.cand_cap = ix->cand_cap;
     a.blk_list = ix->blk_list; a.blk_cnt = ix->blk_cnt; a.list_overflow = ix->blk_cnt + ix->num_cu * ShapeC::NWAVE;
-    a.xf = ix->xf; a.d = ix->d; a.bitmap = nullptr;
+    a.xf = ix->xf; a.d = ix->d; a.bitmap = nullptr; a.rowlist = nullptr; a.nlist = 0;
     const size_t blk_cnt_bytes = ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int);
     // ---- pass 1: 16-bit MFMA scan + certified re-rank, all queries -----------------------------------------------------------------------
     if (coarse_pass) {
@@ -1214,7 +1225,7 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
             return 0;
         }));
         int final_preset = 0, rounds = 0;
-        KR_TRY(run_rounds(ix, a, nq, bm, K1, cap, st, true, [&](const CoarseArgs& ca) -> int {
+        KR_TRY(run_rounds(ix, a, ix->n, nq, bm, K1, cap, st, true, [&](const CoarseArgs& ca) -> int {
             if (q32) return launch_q32<T>(ca, kt64, ix->num_cu, ix->device, st);
             if (smallq) {
                 if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
@@ -1258,36 +1269,46 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
             const int nt = g <= 16 ? 1 : 2;
             const int* qmap = ix->ex_qidx + g0;
             hipLaunchKernelGGL(k_gather_rows, dim3(g), dim3(256), 0, st, ix->q_f, qmap, ix->q_f2, ix->d);
-            // pre-scan: one HBM-bound pass of the 16-bit copy with the group's queries in registers (the <= 32-query stream kernel, MODE 2) marks the
-            // 32-row slots in which some row reaches theta1 = b_k - 2 eps of pass 1 for some query of the group; a row below that bound is strictly
-            // below the query's k-th exact score (the k best coarse rows all have exact >= b_k - eps), so the fp64 scan may skip every unmarked slot.
-            // A boilerplate cluster of 2 % of the corpus thus costs one 1.6-ms stream + 2 % of the fp64 work instead of the full 6-ms fp64 pass.
-            a.bitmap = nullptr;
+            // pre-scan: one HBM-bound pass of the 16-bit copy with the group's queries in registers (the <= 32-query stream kernel, MODE 2) sets one bit
+            // per ROW that reaches theta1 = b_k - 2 eps of pass 1 for some query of the group; a row below that bound is strictly below the query's
+            // k-th exact score (the k best coarse rows all have exact >= b_k - eps), so the fp64 scan only has to visit the marked rows, which
+            // k_compact_rows turns into a list (k_fine addresses its rows through it).  A boilerplate cluster of 2 % of the corpus, scattered over the
+            // whole row range, thus costs one 1.6-ms stream + 2 % of the fp64 work instead of the full 6-ms fp64 pass; a corpus in which every row
+            // is marked costs the stream on top.
+            a.rowlist = nullptr; a.nlist = 0;
+            int64_t n_scan = ix->n;
             const bool can_mark = coarse_pass && (kt64 == 16 || kt64 == 12 || kt64 == 8 || kt64 == 6) && !getenv("KIRAG_AMD_NO_MARK");
             if (can_mark) {
-                const size_t words = (size_t)((ix->n + 31) / 32 + 31) / 32 + 1;
+                const size_t words = (size_t)((ix->n + 31) / 32);
                 if (words > ix->bitmap_words) {
                     if (ix->bitmap) (void)hipFree(ix->bitmap);
-                    ix->bitmap = nullptr; ix->bitmap_words = 0;
-                    KR_HIP(hipMalloc(&ix->bitmap, words * sizeof(uint32_t)));
+                    if (ix->rowlist) (void)hipFree(ix->rowlist);
+                    ix->bitmap = nullptr; ix->rowlist = nullptr; ix->bitmap_words = 0;
+                    KR_HIP(hipMalloc(&ix->bitmap, (words + 1) * sizeof(uint32_t)));      // + 1: the list length lives behind the bits
+                    KR_HIP(hipMalloc(&ix->rowlist, words * 32 * sizeof(uint32_t)));
                     ix->bitmap_words = words;
                 }
-                KR_HIP(hipMemsetAsync(ix->bitmap, 0, words * sizeof(uint32_t), st));
+                KR_HIP(hipMemsetAsync(ix->bitmap, 0, (words + 1) * sizeof(uint32_t), st));
                 hipLaunchKernelGGL(k_prep_queries<T>, dim3(32), dim3(64), 0, st, ix->q_f2, ix->q_c, g, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr, ix->cnt, ix->flags);
                 hipLaunchKernelGGL(k_gather_theta, dim3(1), dim3(64), 0, st, ix->theta1, qmap, g, ix->thr_mark);
                 CoarseArgs m = a;
                 m.qc = ix->q_c; m.nq_pad = 32; m.nq = g; m.thr = ix->thr_mark; m.bitmap = ix->bitmap; m.direct = 2;
                 m.ntiles = (ix->n + 31) / 32; m.perm_mul = 1; m.tile_begin = 0; m.tile_count = m.ntiles;
                 KR_TRY((launch_q32<T>(m, kt64, ix->num_cu, ix->device, st)));
-                a.bitmap = ix->bitmap;
-                ix->st.marked_passes++;
+                unsigned int* cnt_word = ix->bitmap + words;
+                hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ix->bitmap, (int64_t)words, ix->rowlist, cnt_word);
+                KR_HIP(hipMemcpyAsync(ix->h_status + 5 * QBLK + 4, cnt_word, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                KR_HIP(hipStreamSynchronize(st));                 // the row count sizes the rounds of this group (pass 2 is the rare path)
+                const int64_t marked = (int64_t)ix->h_status[5 * QBLK + 4];
+                if (marked >= k) { a.rowlist = ix->rowlist; a.nlist = marked; n_scan = marked; }
+                ix->st.marked_passes++; ix->st.marked_rows += marked;
             }
             hipLaunchKernelGGL(k_prep_fine<0>, dim3(16 * nt), dim3(64), 0, st, ix->q_f2, g, ix->d, ix->bounds, ix->eps, ix->thr, ix->cnt, ix->flags);
             KR_HIP(hipMemsetAsync(ix->blk_cnt, 0, blk_cnt_bytes, st));
             a.nq_pad = 16 * nt; a.nq = g; a.qf = ix->q_f2;
             const int lds = fine_lds_bytes(ix->d, 16 * nt);
             int final_preset = 0, rounds = 0;
-            KR_TRY(run_rounds(ix, a, g, 32, K1, cap, st, false, [&](const CoarseArgs& ca) -> int {
+            KR_TRY(run_rounds(ix, a, n_scan, g, 32, K1, cap, st, false, [&](const CoarseArgs& ca) -> int {
                 if (nt == 1) {
                     if (ca.direct) hipLaunchKernelGGL((k_fine<true, 1>), dim3(ix->num_cu), dim3(FINE_THREADS), lds, st, ca);
                     else hipLaunchKernelGGL((k_fine<false, 1>), dim3(ix->num_cu), dim3(FINE_THREADS), lds, st, ca);
@@ -1418,7 +1439,7 @@ void kr_index_destroy(kr_index* h) {
     Index* ix = reinterpret_cast<Index*>(h);
     (void)hipSetDevice(ix->device);
     if (ix->vmm == 1) { (void)hipDeviceSynchronize(); ix->vf.release(); ix->vc.release(); ix->xf = nullptr; ix->xc = nullptr; }
-    void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_f2, ix->theta1, ix->thr_mark, ix->bitmap, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
+    void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_f2, ix->theta1, ix->thr_mark, ix->bitmap, ix->rowlist, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
                     ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ix->h_status) (void)hipHostFree(ix->h_status);

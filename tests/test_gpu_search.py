@@ -538,17 +538,17 @@ def test_config4_size_21M_search_only_vs_independent_topk():
 
 
 def test_pass2_prescan_marks_only_the_slots_that_matter():
-    """A boilerplate cluster inside an ordinary corpus (2000 near-duplicates of one row among 60k Gaussian rows, scattered over the row range): queries that
-    aim at the cluster cannot be certified by the 16-bit pass; pass 2 first marks, with the 16-bit stream kernel and pass 1's own bound b_k - 2 eps, the 32-row
-    slots that can still matter and runs its fp64 scan only there.  Results must equal the oracle bit for bit, with and without the pre-scan, and the other
+    """A boilerplate cluster inside an ordinary corpus (5000 near-duplicates of one row among 60k Gaussian rows, scattered over the row range): queries that
+    aim at the cluster cannot be certified by the 16-bit pass; pass 2 first marks, with the 16-bit stream kernel and pass 1's own bound b_k - 2 eps, the ROWS
+    that can still matter and runs its fp64 scan over that list only.  Results must equal the oracle bit for bit, with and without the pre-scan, and the other
     queries must certify in pass 1."""
     import os
     rng = np.random.default_rng(51)
     n, d = 60_000, 1024
     x = _unit(rng, n, d)
-    where = rng.choice(n, 2000, replace=False)
+    where = rng.choice(n, 5000, replace=False)                          # more rows inside the 16-bit bound than the certified re-rank holds
     base = _unit(rng, 1, d)
-    x[where] = base + 3e-5 * rng.standard_normal((2000, d)).astype(np.float32)
+    x[where] = base + 3e-5 * rng.standard_normal((5000, d)).astype(np.float32)
     x[where] /= np.linalg.norm(x[where], axis=1, keepdims=True)
     q_plain, _ = _queries_near(rng, x, 40)
     q_aim = base + 0.2 * _unit(rng, 24, d)
@@ -561,6 +561,7 @@ def test_pass2_prescan_marks_only_the_slots_that_matter():
     print(f"[prescan] {st}")
     assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
     assert st["fine"] >= 24 and st["exact"] == 0 and st["marked_passes"] >= 1 and st["certified"] >= 30, st
+    assert 5000 <= st["marked_rows"] / st["marked_passes"] <= 5600, st          # the cluster and little else
     assert set(i[0].tolist()) <= set(where.tolist())                         # a cluster query's top-100 are cluster rows
     os.environ["KIRAG_AMD_NO_MARK"] = "1"
     try:
