@@ -1264,6 +1264,7 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         KR_HIP(hipMemcpyAsync(ix->ex_qidx, fl.data(), fl.size() * sizeof(int), hipMemcpyHostToDevice, st));
         KR_HIP(hipEventRecord(ix->ev[1], st));
         int ngroups = 0;
+        bool mark_useful = true;
         for (size_t g0 = 0; g0 < fl.size(); g0 += gmax, ++ngroups) {
             const int g = (int)std::min<size_t>(gmax, fl.size() - g0);
             const int nt = g <= 16 ? 1 : 2;
@@ -1277,7 +1278,8 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
             // is marked costs the stream on top.
             a.rowlist = nullptr; a.nlist = 0;
             int64_t n_scan = ix->n;
-            const bool can_mark = coarse_pass && (kt64 == 16 || kt64 == 12 || kt64 == 8 || kt64 == 6) && !getenv("KIRAG_AMD_NO_MARK");
+            // (once a group's pre-scan marks more than a quarter of the rows, the remaining groups of this call skip it: on such data it only adds its stream)
+            const bool can_mark = coarse_pass && mark_useful && (kt64 == 16 || kt64 == 12 || kt64 == 8 || kt64 == 6) && !getenv("KIRAG_AMD_NO_MARK");
             if (can_mark) {
                 const size_t words = (size_t)((ix->n + 31) / 32);
                 if (words > ix->bitmap_words) {
@@ -1300,7 +1302,8 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
                 KR_HIP(hipMemcpyAsync(ix->h_status + 5 * QBLK + 4, cnt_word, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
                 KR_HIP(hipStreamSynchronize(st));                 // the row count sizes the rounds of this group (pass 2 is the rare path)
                 const int64_t marked = (int64_t)ix->h_status[5 * QBLK + 4];
-                if (marked >= k) { a.rowlist = ix->rowlist; a.nlist = marked; n_scan = marked; }
+                if (marked >= k && marked <= ix->n / 2) { a.rowlist = ix->rowlist; a.nlist = marked; n_scan = marked; }
+                if (marked > ix->n / 4) mark_useful = false;
                 ix->st.marked_passes++; ix->st.marked_rows += marked;
             }
             hipLaunchKernelGGL(k_prep_fine<0>, dim3(16 * nt), dim3(64), 0, st, ix->q_f2, g, ix->d, ix->bounds, ix->eps, ix->thr, ix->cnt, ix->flags);
