@@ -32,6 +32,8 @@ class ShardedSearcher:
     """``search(q, k)`` over all ranks' shards.  ``index`` needs ``ntotal``, ``search(q, k)`` (numpy out) and,
     on GPU ranks, ``search_into(q, k, scores_t, rows_t)``."""
 
+    DEVICE_MERGE_MAX = 8192      # kr_topk_merge_device holds nshards * k entries per query in LDS
+
     def __init__(self, index, row_offset: int = 0, world: Optional[int] = None, group=None):
         import torch.distributed as dist
         self.index = index
@@ -105,7 +107,7 @@ class ShardedSearcher:
         if self.row_offset and kl > 0:
             (ids if kl == k else ids[:, :kl]).add_(self.row_offset)
         dist.all_gather_into_tensor(self._all, self._mine, group=self.group)
-        if W * k > 8192:
+        if W * k > self.DEVICE_MERGE_MAX:
             # beyond the device merge's LDS capacity (kr_topk_merge_device: nshards * k <= 8192, e.g. 16 shards x k = 1024): merge on the host
             host = self._all.cpu().numpy().reshape(W, block)
             ids_h = np.ascontiguousarray(host[:, :nq * k * 8]).view(np.int64).reshape(W, nq, k)

@@ -37,6 +37,11 @@ def _worker(rank, world, port, ret):
         s, i = ShardedSearcher(ix, row_offset=a, world=world).search(torch.from_numpy(q).cuda(), k)
         so, io = S.search_canonical(q, x, k)
         assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+        # more gathered entries than the device merge holds (16 shards x k = 1024 in production): the host-merge fallback, forced here by a small limit
+        searcher = ShardedSearcher(ix, row_offset=a, world=world)
+        searcher.DEVICE_MERGE_MAX = 64
+        s_h, i_h = searcher.search(torch.from_numpy(q).cuda(), k)
+        assert np.array_equal(i_h, io) and np.array_equal(s_h.view(np.uint32), so.view(np.uint32))
         # a shard with fewer rows than k contributes what it has (padded lists through the device merge)
         lo, hi = (0, 5) if rank == 0 else (5, 605)
         small = FlatIPIndex(d, device=0); small.add(torch.from_numpy(x[lo:hi]).cuda())
