@@ -323,6 +323,109 @@ __global__ __launch_bounds__(256) void k_ln(const uint16_t* __restrict__ y, cons
     }
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two floats -> packed bf16 pair (lo in bits 0..15): ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
+}
+
+// k_ln with 16-byte accesses: a lane owns 8 consecutive elements per 512-element step (one global_load_dwordx4 per tensor and step instead of two
+// 8-byte ones: 8-byte accesses reach 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md).  NS 512-element steps cover a row (H <= 512 NS, H % 8 == 0).
+// Same arithmetic per element as k_ln; the row sums add the elements in a different lane order (tolerances of DESIGN.md section 2 unaffected; rows stay
+// independent of the batch).  KIRAG_AMD_LN8=1 selects the 8-byte kernel (A/B).
+template <int NS>
+__global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, const float* __restrict__ ybias, const int* __restrict__ Tp, const float* __restrict__ g,
+                                              const float* __restrict__ bta, float eps, int H, const uint16_t* xlo_in, uint16_t* xlo, uint16_t* xb) {
+    const int lane = threadIdx.x & 63;
+    const int T = *Tp;
+    float gg[NS][8], bb[NS][8], yb[NS][8];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int i = lane * 8 + j * 512;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { gg[j][c] = 0.f; bb[j][c] = 0.f; yb[j][c] = 0.f; }
+        if (i < H) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 a = *reinterpret_cast<const float4*>(g + i + 4 * h), b = *reinterpret_cast<const float4*>(bta + i + 4 * h), c = *reinterpret_cast<const float4*>(ybias + i + 4 * h);
+                gg[j][4 * h] = a.x; gg[j][4 * h + 1] = a.y; gg[j][4 * h + 2] = a.z; gg[j][4 * h + 3] = a.w;
+                bb[j][4 * h] = b.x; bb[j][4 * h + 1] = b.y; bb[j][4 * h + 2] = b.z; bb[j][4 * h + 3] = b.w;
+                yb[j][4 * h] = c.x; yb[j][4 * h + 1] = c.y; yb[j][4 * h + 2] = c.z; yb[j][4 * h + 3] = c.w;
+            }
+        }
+    }
+    const int64_t step = (int64_t)gridDim.x * 4;
+    int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint4 a[NS], rh[NS], rl[NS];
+    auto load_row = [&](int64_t row) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int i = lane * 8 + j * 512;
+            a[j] = rh[j] = rl[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < H && row < T) {
+                a[j] = *reinterpret_cast<const uint4*>(y + row * H + i);
+                rh[j] = *reinterpret_cast<const uint4*>(xb + row * H + i);
+                if (xlo_in) rl[j] = *reinterpret_cast<const uint4*>(xlo_in + row * H + i);
+            }
+        }
+    };
+    auto lo16 = [](unsigned int w) { return __builtin_bit_cast(float, w << 16); };
+    auto hi16 = [](unsigned int w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
+    load_row(t);
+    for (; t < T; t += step) {
+        float v[NS][8];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const unsigned int aw[4] = {a[j].x, a[j].y, a[j].z, a[j].w}, hw[4] = {rh[j].x, rh[j].y, rh[j].z, rh[j].w}, lw[4] = {rl[j].x, rl[j].y, rl[j].z, rl[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[j][2 * c] = (lo16(aw[c]) + yb[j][2 * c]) + (lo16(hw[c]) + lo16(lw[c]));
+                v[j][2 * c + 1] = (hi16(aw[c]) + yb[j][2 * c + 1]) + (hi16(hw[c]) + hi16(lw[c]));
+            }
+        }
+        load_row(t + step);                                   // next row's loads in flight while this one is reduced and stored
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (lane * 8 + j * 512 < H)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) s += v[j][c];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        const float mu = s / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (lane * 8 + j * 512 < H)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { const float dlt = v[j][c] - mu; q += dlt * dlt; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+        uint16_t* xb_row = xb + t * H;
+        uint16_t* xlo_row = xlo ? xlo + t * H : nullptr;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int i = lane * 8 + j * 512;
+            if (i < H) {
+                float o[8];
+                unsigned int ob[4], ol[4];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = (v[j][c] - mu) * rstd * gg[j][c] + bb[j][c];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ob[c] = pack_bf16x2(o[2 * c], o[2 * c + 1]);
+                *reinterpret_cast<uint4*>(xb_row + i) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+                if (xlo_row) {   // optional low half: o = hi + lo with lo = bf16(o - hi)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ol[c] = pack_bf16x2(o[2 * c] - lo16(ob[c]), o[2 * c + 1] - hi16(ob[c]));
+                    *reinterpret_cast<uint4*>(xlo_row + i) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // projections: C[token, feature] = X[token, :] . W[feature, :]   (rows = tokens, cols = output features)
 // ---------------------------------------------------------------------------------------------------------
@@ -343,7 +446,6 @@ enum { EPI_QKV = 0, EPI_DENSE = 1, EPI_GELU = 2 };
 // 2^-9 relative), no sign handling, and ONE quarter-rate transcendental (v_exp_f32) per element instead of two: 13 VALU instructions per element
 // pair (76 issue cycles) against 22 (136) for the Abramowitz-Stegun 7.1.26 form used before, in an epilogue that nothing overlaps with (the GELU
 // was 1557 VALU instructions per wave and 256x256 tile, with both waves of a SIMD in it at the same time).
-typedef __attribute__((ext_vector_type(2))) float f32x2;
 // two elements at once: the polynomial / products run as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32), only exp2 / abs / max stay scalar
 __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
     const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
@@ -355,12 +457,6 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
     const f32x2 e = {__builtin_amdgcn_exp2f(-q.x), __builtin_amdgcn_exp2f(-q.y)};
     const f32x2 r = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
     return __builtin_elementwise_fma(ax * e, f32x2{-0.5f, -0.5f}, r);
-}
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-// two floats -> packed bf16 pair (lo in bits 0..15): ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
 }
 
 // A 32x32 MFMA accumulator has its COLUMN on the lane, so a direct store writes 2-byte elements (128 store instructions per lane per
@@ -1138,7 +1234,8 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
     const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + 3) & ~3);   // upper bound of the packed token count (each sequence is padded to 4)
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
     const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu * 4u);   // k_ln is grid-stride (its parameters stay in registers across rows)
-    auto ln_kernel = H <= 1024 ? &k_ln<4> : &k_ln<8>;
+    const char* ln8e = getenv("KIRAG_AMD_LN8"); const bool ln8 = ln8e && atoi(ln8e) != 0;      // A/B knob: the 8-byte-access LayerNorm of round 1
+    auto ln_kernel = ln8 ? (H <= 1024 ? &k_ln<4> : &k_ln<8>) : (H <= 512 ? &k_ln16<1> : H <= 1024 ? &k_ln16<2> : &k_ln16<4>);
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->use_lo ? e->xlo : nullptr, e->xb);
     uint16_t* const lo_rw = e->use_lo ? e->xlo : nullptr;      // low half read / written by the inner LayerNorms
