@@ -51,5 +51,23 @@ int main() {
         run(k_store<1, false>, "2 rows x 512 B, plain");
         run(k_store<1, true>, "2 rows x 512 B, nt");
     }
+    // per-CU store rate: fewer blocks (one per CU at most), each writing 32 tiles — is 128 KiB per tile bound by the CU's own store path or by the chip's?
+    for (int blocks : {8, 32, 64, 128, 256}) {
+        const int tpb = 32;
+        const int tiles_n = F / 256, tiles_m = (blocks * tpb + tiles_n - 1) / tiles_n;
+        for (int nt = 0; nt < 2; ++nt) {
+            float best = 1e9f;
+            for (int it = 0; it < 8; ++it) {
+                CK(hipEventRecord(e0));
+                if (nt) hipLaunchKernelGGL((k_store<0, true>), dim3(blocks), dim3(512), 0, 0, out, (int64_t)F, tiles_m, tiles_n, tpb);
+                else hipLaunchKernelGGL((k_store<0, false>), dim3(blocks), dim3(512), 0, 0, out, (int64_t)F, tiles_m, tiles_n, tpb);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+            }
+            const double bytes = (double)blocks * tpb * 256 * 256 * 2;
+            printf("blocks %3d  %-6s %8.1f us  %7.1f GB/s total  %6.1f GB/s per block  (128 KiB tile in %.2f us)\n", blocks, nt ? "nt" : "plain", best * 1e3, bytes / best / 1e6,
+                   bytes / best / 1e6 / blocks, best * 1e3 / tpb);
+        }
+    }
     return 0;
 }
