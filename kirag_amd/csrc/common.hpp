@@ -196,28 +196,34 @@ __device__ __forceinline__ float canonical_finish(double S, double A, const floa
 // load of both rows is issued before the first use, so a wave pays one memory round trip per pair of rows instead of one per 256-element step
 // (the re-rank gathers one 4-KiB fp32 row per candidate from HBM).  NCH = number of 256-element steps (d <= 256 NCH).  q points at the same
 // query in memory (exact path only).
+template <int NCH> struct RowPair { float4 a[NCH], b[NCH]; };   // two fp32 rows, lane-sliced like the query registers
+
 template <int NCH>
-__device__ __forceinline__ void canonical_score_wave2(const float4 (&qr)[NCH], const float* __restrict__ q, const float* __restrict__ x0,
-                                                      const float* __restrict__ x1, int d, int lane, unsigned long long* limbs, bool force_exact,
-                                                      float& f0, float& f1) {
-    float4 a[NCH], b[NCH];
+__device__ __forceinline__ void load_rows2(RowPair<NCH>& r, const float* __restrict__ x0, const float* __restrict__ x1, int d, int lane) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int i = lane * 4 + j * 256;
-        a[j] = make_float4(0.f, 0.f, 0.f, 0.f); b[j] = a[j];
-        if (i < d) { a[j] = *reinterpret_cast<const float4*>(x0 + i); b[j] = *reinterpret_cast<const float4*>(x1 + i); }
+        r.a[j] = make_float4(0.f, 0.f, 0.f, 0.f); r.b[j] = r.a[j];
+        if (i < d) { r.a[j] = *reinterpret_cast<const float4*>(x0 + i); r.b[j] = *reinterpret_cast<const float4*>(x1 + i); }
     }
+}
+
+// The products are exact in fp64 (24 x 24 bits), so s + q x rounds once either way: fma(q, x, s) is bit-identical to the product-then-add form and one
+// instruction less per element; |q x| = |q| |x| takes the absolute values as free source modifiers.
+template <int NCH>
+__device__ __forceinline__ void score_rows2(const float4 (&qr)[NCH], const float* __restrict__ q, const RowPair<NCH>& r, const float* __restrict__ x0,
+                                            const float* __restrict__ x1, int d, int lane, unsigned long long* limbs, bool force_exact, float& f0, float& f1) {
     double s0 = 0.0, s1 = 0.0, m0 = 0.0, m1 = 0.0;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         if (lane * 4 + j * 256 < d) {
             const float qv[4] = {qr[j].x, qr[j].y, qr[j].z, qr[j].w};
-            const float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w}, bv[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
+            const float av[4] = {r.a[j].x, r.a[j].y, r.a[j].z, r.a[j].w}, bv[4] = {r.b[j].x, r.b[j].y, r.b[j].z, r.b[j].w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const double p0 = (double)qv[c] * (double)av[c], p1 = (double)qv[c] * (double)bv[c];   // exact
-                s0 += p0; m0 += __builtin_fabs(p0);
-                s1 += p1; m1 += __builtin_fabs(p1);
+                const double qd = (double)qv[c], ad = (double)av[c], bd = (double)bv[c];
+                s0 = __builtin_fma(qd, ad, s0); m0 = __builtin_fma(__builtin_fabs(qd), __builtin_fabs(ad), m0);
+                s1 = __builtin_fma(qd, bd, s1); m1 = __builtin_fma(__builtin_fabs(qd), __builtin_fabs(bd), m1);
             }
         }
     }
@@ -228,6 +234,15 @@ __device__ __forceinline__ void canonical_score_wave2(const float4 (&qr)[NCH], c
     }
     f0 = canonical_finish(s0, m0, q, x0, d, lane, limbs, force_exact);
     f1 = canonical_finish(s1, m1, q, x1, d, lane, limbs, force_exact);
+}
+
+template <int NCH>
+__device__ __forceinline__ void canonical_score_wave2(const float4 (&qr)[NCH], const float* __restrict__ q, const float* __restrict__ x0,
+                                                      const float* __restrict__ x1, int d, int lane, unsigned long long* limbs, bool force_exact,
+                                                      float& f0, float& f1) {
+    RowPair<NCH> r;
+    load_rows2<NCH>(r, x0, x1, d, lane);
+    score_rows2<NCH>(qr, q, r, x0, x1, d, lane, limbs, force_exact, f0, f1);
 }
 
 // in-LDS bitonic sort of n (power of two) uint64 keys, DESCENDING, by a block of nthreads threads

@@ -850,15 +850,25 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
             const int i = lane * 4 + j * 256;
             qr[j] = (i < d) ? *reinterpret_cast<const float4*>(qv + i) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        for (int i = wave; i < P; i += 8) {                    // two candidate rows per wave and step: i and i + 4
-            const bool v0 = i < r, v1 = i + 4 < r;
-            const uint32_t row0 = v0 ? key_row(sel[i]) : 0u, row1 = v1 ? key_row(sel[i + 4]) : row0;
+        // two candidate rows per wave and step (i and i + 4); the rows of the NEXT step are requested before this step's arithmetic, so a wave pays
+        // the ~2 us of a scattered 4-KiB gather once, not once per pair (this loop was a latency chain: 275 rows per query = 35 round trips)
+        RowPair<NCH> cur, nxt;
+        int i = wave;
+        bool v0 = i < r, v1 = i + 4 < r;
+        uint32_t row0 = v0 ? key_row(sel[i]) : 0u, row1 = v1 ? key_row(sel[i + 4]) : row0;
+        if (v0) load_rows2<NCH>(cur, xf + (int64_t)row0 * d, xf + (int64_t)row1 * d, d, lane);
+        for (; i < P; i += 8) {
+            const int in = i + 8;
+            const bool nv0 = in < r, nv1 = in + 4 < r;
+            const uint32_t nrow0 = nv0 ? key_row(sel[in]) : 0u, nrow1 = nv1 ? key_row(sel[in + 4]) : nrow0;
+            if (nv0) load_rows2<NCH>(nxt, xf + (int64_t)nrow0 * d, xf + (int64_t)nrow1 * d, d, lane);
             float e0 = 0.f, e1 = 0.f;
-            if (v0) canonical_score_wave2<NCH>(qr, qv, xf + (int64_t)row0 * d, xf + (int64_t)row1 * d, d, lane, exact_limbs[wave], force_exact != 0, e0, e1);
+            if (v0) score_rows2<NCH>(qr, qv, cur, xf + (int64_t)row0 * d, xf + (int64_t)row1 * d, d, lane, exact_limbs[wave], force_exact != 0, e0, e1);
             if (lane == 0) {
                 sel[i] = v0 ? make_key(e0, row0) : 0ull;
                 if (i + 4 < P) sel[i + 4] = v1 ? make_key(e1, row1) : 0ull;
             }
+            cur = nxt; v0 = nv0; v1 = nv1; row0 = nrow0; row1 = nrow1;
         }
     }
     bitonic_sort_desc(sel, P, tid, 256);
