@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m = -INFINITY, l = 0.f;
-    constexpr int NB = 4;                                 // loads in flight per thread and batch (register budget: 3 blocks per CU = 168 VGPRs)
+    constexpr int NB = HPB == 1 ? 4 : 2;                  // loads in flight per thread, head and batch (register budget: 3 blocks per CU = 168 VGPRs; HPB = 4 means <= 32 keys: 2 cover a head)
     for (int kc0 = 0; kc0 < nk; kc0 += kchunk) {
         // ---- stage keys [kc0, kc0 + kchunk) of the block's heads: every global load of a batch is issued before the first LDS store
         // (a load -> store loop would serialise one memory round trip per iteration)
@@ -712,46 +712,66 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
         const int cpr = nkp >> 2;                         // 8-byte chunks (4 keys) per V^T row
         const unsigned cpr_magic = 0xFFFFFFFFu / (unsigned)cpr + 1u;
         if (kc0 > 0) __syncthreads();                     // every wave is done with the previous chunk
-#pragma unroll
-        for (int h2 = 0; h2 < HPB; ++h2) {
-            const int head2 = hb * HPB + h2;
-            if (head2 >= heads) break;
-            char* Kw = Ks + (size_t)h2 * kchunk * 128;
-            char* Vw = Vs + (size_t)h2 * 64 * vpitch;
+        {
+            // all heads of the block in ONE batch: every global load (K and V^T of up to HPB heads) is issued before the first LDS store, so a block with
+            // 2 / 4 heads pays one memory round trip per batch, not one per head (a 32-token sequence is a single batch)
             const int nkcs = nkp * 8, nvc = 64 * cpr;
             for (int base = 0; base < nkcs || base < nvc; base += 256 * NB) {
-                uint4 kv[NB]; uint2 vv[NB]; int vd[NB], vk[NB];
+                uint4 kv[HPB][NB]; uint2 vv[HPB][NB]; int vd[NB], vk[NB];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int i = base + j * 256 + tid;
-                    const int key = i >> 3, ch = i & 7;
-                    kv[j] = make_uint4(0u, 0u, 0u, 0u);
-                    if (i < nkcs && key < nkc) kv[j] = *reinterpret_cast<const uint4*>(k + (off + kc0 + key) * H + head2 * 64 + ch * 8);
+                for (int h2 = 0; h2 < HPB; ++h2) {
+                    const int head2 = hb * HPB + h2;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int i = base + j * 256 + tid;
+                        const int key = i >> 3, ch = i & 7;
+                        kv[h2][j] = make_uint4(0u, 0u, 0u, 0u);
+                        if (head2 < heads && i < nkcs && key < nkc) kv[h2][j] = *reinterpret_cast<const uint4*>(k + (off + kc0 + key) * H + head2 * 64 + ch * 8);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const int i = base + j * 256 + tid;
                     const int d = (int)__umulhi((unsigned)i, cpr_magic), kc = i - d * cpr;   // i / cpr (exact: i < 2^16, cpr <= 128)
                     vd[j] = d; vk[j] = kc;
-                    vv[j] = make_uint2(0u, 0u);
-                    if (i < nvc && kc * 4 < nkc) vv[j] = *reinterpret_cast<const uint2*>(vT + (int64_t)(head2 * 64 + d) * ldv + off + kc0 + kc * 4);   // off, kc0 % 4 == 0: 8-B aligned
                 }
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int i = base + j * 256 + tid;
-                    const int key = i >> 3, ch = i & 7;
-                    if (i < nkcs) *reinterpret_cast<uint4*>(Kw + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kv[j];
-                }
+                for (int h2 = 0; h2 < HPB; ++h2) {
+                    const int head2 = hb * HPB + h2;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int i = base + j * 256 + tid;
-                    const int key0 = vk[j] * 4;
-                    uint2 v = vv[j];
-                    if (key0 + 4 > nkc) {      // keys >= nk (padding / the next sequence) are stored as zero
-                        v.x &= (key0 + 0 < nkc ? 0xffffu : 0u) | (key0 + 1 < nkc ? 0xffff0000u : 0u);
-                        v.y &= (key0 + 2 < nkc ? 0xffffu : 0u) | (key0 + 3 < nkc ? 0xffff0000u : 0u);
+                    for (int j = 0; j < NB; ++j) {
+                        const int i = base + j * 256 + tid;
+                        vv[h2][j] = make_uint2(0u, 0u);
+                        if (head2 < heads && i < nvc && vk[j] * 4 < nkc)
+                            vv[h2][j] = *reinterpret_cast<const uint2*>(vT + (int64_t)(head2 * 64 + vd[j]) * ldv + off + kc0 + vk[j] * 4);   // off, kc0 % 4 == 0: 8-B aligned
                     }
-                    if (i < nvc) *reinterpret_cast<uint2*>(Vw + vd[j] * vpitch + vk[j] * 8) = v;
+                }
+#pragma unroll
+                for (int h2 = 0; h2 < HPB; ++h2) {
+                    if (hb * HPB + h2 >= heads) continue;
+                    char* Kw = Ks + (size_t)h2 * kchunk * 128;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int i = base + j * 256 + tid;
+                        const int key = i >> 3, ch = i & 7;
+                        if (i < nkcs) *reinterpret_cast<uint4*>(Kw + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kv[h2][j];
+                    }
+                }
+#pragma unroll
+                for (int h2 = 0; h2 < HPB; ++h2) {
+                    if (hb * HPB + h2 >= heads) continue;
+                    char* Vw = Vs + (size_t)h2 * 64 * vpitch;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int i = base + j * 256 + tid;
+                        const int key0 = vk[j] * 4;
+                        uint2 v = vv[h2][j];
+                        if (key0 + 4 > nkc) {      // keys >= nk (padding / the next sequence) are stored as zero
+                            v.x &= (key0 + 0 < nkc ? 0xffffu : 0u) | (key0 + 1 < nkc ? 0xffff0000u : 0u);
+                            v.y &= (key0 + 2 < nkc ? 0xffffu : 0u) | (key0 + 3 < nkc ? 0xffff0000u : 0u);
+                        }
+                        if (i < nvc) *reinterpret_cast<uint2*>(Vw + vd[j] * vpitch + vk[j] * 8) = v;
+                    }
                 }
             }
         }
