@@ -899,11 +899,19 @@ __global__ __launch_bounds__(256) void k_exact_scan(const float* __restrict__ qf
         const int i = lane * 4 + j * 256;
         qr[j] = (i < d) ? *reinterpret_cast<const float4*>(qv + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // as in k_rerank: the next pair of rows is requested before the current pair is scored
+    RowPair<NCH> cur, nxt;
+    if (r0 + wave < n) load_rows2<NCH>(cur, xf + (r0 + wave) * d, xf + ((r0 + wave + 4 < n && wave + 4 < rc) ? r0 + wave + 4 : r0 + wave) * d, d, lane);
     for (int i = wave; i < rc; i += 8) {
         const int64_t row0 = r0 + i, row1 = r0 + i + 4;
         const bool v0 = row0 < n, v1 = row1 < n && i + 4 < rc;
+        const int in = i + 8;
+        const int64_t nrow0 = r0 + in, nrow1 = r0 + in + 4;
+        const bool nv0 = in < rc && nrow0 < n, nv1 = nrow1 < n && in + 4 < rc;
+        if (nv0) load_rows2<NCH>(nxt, xf + nrow0 * d, xf + (nv1 ? nrow1 : nrow0) * d, d, lane);
         float e0 = 0.f, e1 = 0.f;
-        if (v0) canonical_score_wave2<NCH>(qr, qv, xf + row0 * d, xf + (v1 ? row1 : row0) * d, d, lane, exact_limbs[wave], force_exact != 0, e0, e1);
+        if (v0) score_rows2<NCH>(qr, qv, cur, xf + row0 * d, xf + (v1 ? row1 : row0) * d, d, lane, exact_limbs[wave], force_exact != 0, e0, e1);
+        cur = nxt;
         if (lane == 0) {
             uint64_t k0 = v0 ? make_key(e0, (uint32_t)row0) : 0ull, k1 = v1 ? make_key(e1, (uint32_t)row1) : 0ull;
             if (v0 && k0 == 0ull) k0 = 1ull;   // cannot happen for row < 2^32-1; keeps "0 = padding" unambiguous
