@@ -32,13 +32,14 @@ extern "C" {
 #define KR_EHIP (-5)      /* a HIP runtime call failed; see kr_last_error() */
 #define KR_ESTATE (-1)    /* handle not ready (e.g. encoder weights missing) */
 
-#define KR_ABI_VERSION 2
+#define KR_ABI_VERSION 3
 int kr_abi_version(void);
 const char* kr_last_error(void);
 int kr_device_count(void);
 /* process-wide test / diagnostic switches.  "force_exact_scores" (0/1): every canonical score goes through the integer
  * super-accumulator instead of the certified fp64 fast path (same results by definition; exercises the rare path).
- * Unknown names: KR_EINVAL. */
+ * "debug_va_retired_tib" (TiB) / "debug_vmm_min_reserve_mib" (MiB; 0 = default): test hooks of the large-index address-space
+ * budget and of the smallest address range reserved per large index.  Unknown names: KR_EINVAL. */
 int kr_set_option(const char* name, int value);
 /* frees the per-device scratch buffers kr_score_topk keeps between calls */
 void kr_release_scratch(void);
@@ -86,6 +87,14 @@ int kr_index_add_raw(kr_index* ix, const float* xf, const uint16_t* xc, int64_t 
  *             32); pass 3 = exact scan, query by query, for what is left (mass ties);
  *         1 = exact scan only, 2 = pass 2 (+3) only — slow; used by tests as on-device cross-checks. */
 int kr_index_search(kr_index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int mode, void* stream);
+/* The same search (mode 0) in two halves.  kr_index_search_async ENQUEUES pass 1 of every 1024-query block on `stream` and returns without waiting
+ * for the device (given device pointers it performs no host synchronisation at all): the results of every query whose exactness certificate holds
+ * are written to scores / rows in stream order, and the per-query certificate flags are copied to pinned memory behind them.
+ * kr_index_search_finish waits for that point, reads the flags and - only for queries pass 1 could not certify - runs passes 2 / 3 and overwrites
+ * their rows; after it returns the results are final and the statistics are updated.  q, scores and rows must stay valid until then.  One search
+ * may be in flight per handle: any other call on the handle finishes it first.  kr_index_search(mode 0) == kr_index_search_async + _finish. */
+int kr_index_search_async(kr_index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, void* stream);
+int kr_index_search_finish(kr_index* ix);
 
 typedef struct {
     int64_t queries;          /* queries answered since creation / last reset */
@@ -102,6 +111,8 @@ typedef struct {
     double last_fine_ms;      /* device time of pass 2 in the last search call */
     int64_t marked_passes;    /* pass-2 groups that were pre-scanned (16-bit stream marking the rows the fp64 scan has to visit) */
     int64_t marked_rows;      /* rows marked by those pre-scans, summed over the groups */
+    int64_t va_retired_bytes; /* process-wide: virtual addresses retired by released / moved indexes (never reused) */
+    int64_t grow_mode;        /* this index: -1 undecided (< 256 MiB), 0 hipMalloc + copy-on-grow, 1 chunks mapped into a reserved address range */
 } kr_search_stats;
 int kr_index_stats(kr_index* ix, kr_search_stats* out, int reset);
 

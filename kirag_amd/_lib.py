@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KIRAG_AMD_LIB") or os.path.join(_HERE, "libkirag_amd.so")   # KIRAG_AMD_LIB: diagnostic builds (tools/stamp_build.sh)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class KiragAmdError(RuntimeError):
@@ -25,7 +25,8 @@ class SearchStats(C.Structure):
     _fields_ = [("queries", C.c_int64), ("certified", C.c_int64), ("fallback", C.c_int64), ("overflow", C.c_int64),
                 ("reranked_rows", C.c_int64), ("coarse_rounds", C.c_int64), ("last_coarse_ms", C.c_double),
                 ("last_total_ms", C.c_double), ("fine", C.c_int64), ("exact", C.c_int64), ("fine_rounds", C.c_int64),
-                ("last_fine_ms", C.c_double), ("marked_passes", C.c_int64), ("marked_rows", C.c_int64)]
+                ("last_fine_ms", C.c_double), ("marked_passes", C.c_int64), ("marked_rows", C.c_int64),
+                ("va_retired_bytes", C.c_int64), ("grow_mode", C.c_int64)]
 
 
 class BertCfg(C.Structure):
@@ -53,6 +54,8 @@ SIGNATURES = {
     "kr_index_get_bounds": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kr_index_add_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "kr_index_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "kr_index_search_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kr_index_search_finish": (C.c_int, [C.c_void_p]),
     "kr_index_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "kr_score_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kr_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

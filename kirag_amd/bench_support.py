@@ -141,3 +141,19 @@ def encoder_flops(cfg, lens) -> float:
     H, L = cfg.hidden_size, cfg.num_hidden_layers
     lens = lens.double()
     return float((L * lens * (24.0 * H * H + 4.0 * lens * H)).sum().item())
+
+
+def wordpiece_tokenizer(vocab_file: str, do_lower_case: bool = True):
+    """``BertTokenizerFast`` over a plain ``vocab.txt`` (synthetic vocabularies of the tests / feed benchmark; real checkpoints go through
+    ``AutoTokenizer.from_pretrained`` exactly as in the reference).  transformers >= 5 takes the vocabulary as ``vocab=`` and silently IGNORES the
+    ``vocab_file=`` keyword of 4.x — every word then tokenises to [UNK] (rounds 1-2 of this repo tested the collators that way without noticing);
+    this helper uses whichever spelling yields the file's vocabulary and fails loudly otherwise."""
+    from transformers import BertTokenizerFast
+    with open(vocab_file) as f:
+        n_lines = sum(1 for line in f if line.rstrip("\n"))
+    tok = BertTokenizerFast(vocab_file=vocab_file, do_lower_case=do_lower_case)
+    if tok.vocab_size != n_lines:
+        tok = BertTokenizerFast(vocab=vocab_file, do_lower_case=do_lower_case)
+    if tok.vocab_size != n_lines:
+        raise RuntimeError(f"BertTokenizerFast loaded {tok.vocab_size} of the {n_lines} entries of {vocab_file}")
+    return tok

@@ -37,6 +37,8 @@ int fail(int code, const char* fmt, ...);
 int select_device(int device);  // hipSetDevice + arch check (gfx950)
 bool is_device_pointer(const void* p);   // hipMalloc memory (as opposed to pageable / pinned host memory)
 extern std::atomic<int> g_force_exact;   // kr_set_option("force_exact_scores")
+extern std::atomic<unsigned long long> g_vmm_min_reserve;   // kr_set_option("debug_vmm_min_reserve_mib"): smallest address range reserved for a large index (default 16 GiB)
+extern std::atomic<unsigned long long> g_va_retired_bias;   // kr_set_option("debug_va_retired_tib"): test hook of the index's address-space budget
 
 // ---- 16-bit element tags ------------------------------------------------------------------------------------
 struct BF16 {

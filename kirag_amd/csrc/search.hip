@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <vector>
 
 namespace kr {
@@ -38,6 +39,9 @@ constexpr int COARSE_STAGES = 2;
 constexpr int QBLK = 1024;                   // queries per search block (reference index_batch_size)
 constexpr int EXACT_RC = 1024;               // rows per block of the exact scan
 constexpr int SORT_CHUNK = 4096;             // keys per block of the merge tree
+constexpr int THETA_BLOCKS = 16;             // pass 1's theta is kept for the first 16 query blocks of a call (later blocks: pass 2 without the pre-scan)
+constexpr int TIMED_BLOCKS = 4;              // blocks of a call whose coarse rounds are bracketed by events
+constexpr int STATUS_STRIDE = 2 * QBLK + 4;  // per-block status record in pinned memory: [QBLK] flags | [QBLK] re-ranked rows | [4] list overflow
 
 // Growable device array without copies: a virtual address range reserved once (sized for the whole HBM: an index can never need more) into which
 // physical chunks are mapped as the row count grows (hipMemAddressReserve / hipMemCreate / hipMemMap).  The rows never move, so appending to a
@@ -114,7 +118,7 @@ struct Index {
     // search workspace (sized for QBLK queries)
     float* q_f = nullptr;      // [QBLK, d]
     float* q_f2 = nullptr;     // [FINE_QMAX, d] compacted flagged queries of the high-precision pass
-    float* theta1 = nullptr;   // [QBLK] pass 1's b_k - 2 eps per query (k_rerank)
+    float* theta1 = nullptr;   // [THETA_BLOCKS, QBLK] pass 1's b_k - 2 eps per query (k_rerank)
     float* thr_mark = nullptr; // [32] the same, compacted for the group being pre-scanned
     uint32_t* bitmap = nullptr; size_t bitmap_words = 0;   // one bit per row (+ one word: the list length) — pass 2 pre-scan
     uint32_t* rowlist = nullptr;                           // the marked rows, compacted
@@ -129,16 +133,27 @@ struct Index {
     float* out_s = nullptr;    // [QBLK, kmax]
     int64_t* out_r = nullptr;  // [QBLK, kmax]
     uint32_t* nrer = nullptr;  // [QBLK] re-ranked rows (stats)
-    uint32_t* h_status = nullptr;   // pinned host: [QBLK] flags | [QBLK] nrer | [4] list overflow | pass 2: [QBLK] flags | [QBLK] nrer | [QBLK] group list overflow
+    uint32_t* h_status = nullptr;   // pinned host: pass 2: [QBLK] flags | [QBLK] nrer | [QBLK] group list overflow | [16] marked rows; then one STATUS_STRIDE record per query block
     int out_k = 0;
     uint64_t* ex_a = nullptr; uint64_t* ex_b = nullptr; size_t ex_bytes = 0;  // exact-scan ping/pong
     int* ex_qidx = nullptr;    // [QBLK] flagged query list
     uint4* blk_list = nullptr; unsigned int* blk_cnt = nullptr;   // [num_cu*8, WLISTCAP] per-wave survivor lists, [num_cu*8 + 1] counts (+ overflow word)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t evc[2 * 16] = {};   // begin/end pairs around each coarse round (roofline timing)
+    hipEvent_t evc[TIMED_BLOCKS * 2 * 16] = {};   // begin/end pairs around each coarse round of the first blocks of a call (roofline timing)
     hipEvent_t ev_add = nullptr;   // recorded behind the last (asynchronous) add: searches on another stream wait for it
     kr_search_stats st{};
     int num_cu = 256;
+    // environment switches, read ONCE at kr_index_create (round 2 called getenv() on every search)
+    bool no_q32 = false, no_fine = false, no_mark = false, no_vmm = false;
+    // asynchronous search (kr_index_search_async ... kr_index_search_finish): pass 1 of every block is enqueued, the per-query certificate flags
+    // land in pinned memory behind it; finish() reads them and runs the rare passes 2 / 3
+    struct Pending {
+        bool active = false;
+        const float* q = nullptr; int nq = 0, k = 0; float* scores = nullptr; int64_t* rows = nullptr; hipStream_t st = nullptr;
+        std::vector<int> rounds;        // coarse rounds per block (event pairs to read)
+    } pend;
+    int status_blocks = 0;          // h_status holds this many per-block status records
+    hipEvent_t ev_done = nullptr;   // behind the last enqueued block of an asynchronous search
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -951,47 +966,81 @@ __global__ void k_keys_to_out(const uint64_t* __restrict__ keys, int64_t stride,
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
+// rows added by an asynchronous kr_index_add (device source: only ev_add was recorded) must have landed before anything reads or moves them on
+// ANOTHER stream: the blocking copies below run on the NULL stream, which does not order against a caller's non-blocking stream
+static int wait_adds_host(Index* ix) {
+    if (ix->ev_add) KR_HIP(hipEventSynchronize(ix->ev_add));
+    return 0;
+}
+
+static unsigned long long va_retired_total() { return g_va_retired.load() + g_va_retired_bias.load(); }
+constexpr unsigned long long VA_BUDGET = 48ull << 40;         // of the 47-bit address space; beyond it new indexes grow by hipMalloc + copy
+
+// Move the index into a fresh pair of mapped ranges that can hold `want` rows (reserve: 8 x want, at least 16 GiB of rows, at most what the device
+// could ever hold), copying the n rows present.  Nothing of *ix changes unless every step succeeded.  -1: mechanism unavailable, KR_E*: hard error.
+static int vmm_move(Index* ix, int64_t want) {
+    const size_t row_f = (size_t)ix->d * sizeof(float), row_c = (size_t)ix->dpad * 2;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); return -1; }
+    const int64_t max_rows = (int64_t)(total_b / (row_f + row_c)) + 4096;          // more rows than the device could ever hold
+    int64_t res_rows = std::max<int64_t>(8 * want, (int64_t)((size_t)g_vmm_min_reserve.load() / (row_f + row_c)));
+    res_rows = std::min(std::max(res_rows, want), std::max(max_rows, want));
+    VBuf nf, nc;
+    if (nf.init(ix->device, (size_t)res_rows * row_f) != 0 || nc.init(ix->device, (size_t)res_rows * row_c) != 0) { nf.release(); nc.release(); return -1; }
+    const int64_t ncap = round_up(want, 256);
+    const int rf = nf.ensure((size_t)ncap * row_f), rc = rf == 0 ? nc.ensure((size_t)ncap * row_c) : rf;
+    if (rf != 0 || rc != 0) {
+        nf.release(); nc.release();
+        if (rf == KR_ENOMEM || rc == KR_ENOMEM) return fail(KR_ENOMEM, "out of device memory growing the index to %lld rows", (long long)want);
+        return -1;
+    }
+    if (ix->n > 0) {   // includes the NaN padding rows of the 16-bit copy
+        hipError_t e = hipMemcpy(nf.base, ix->xf, (size_t)ix->n * row_f, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(nc.base, ix->xc, (size_t)round_up(ix->n, 256) * row_c, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) { nf.release(); nc.release(); return fail(KR_EHIP, "moving the index rows failed: %s", hipGetErrorString(e)); }
+    }
+    if (ix->vmm == 1) { (void)hipDeviceSynchronize(); ix->vf.release(); ix->vc.release(); }
+    else { if (ix->xf) (void)hipFree(ix->xf); if (ix->xc) (void)hipFree(ix->xc); }
+    ix->vf = nf; ix->vc = nc; ix->vmm = 1;
+    ix->xf = reinterpret_cast<float*>(ix->vf.base); ix->xc = reinterpret_cast<uint16_t*>(ix->vc.base);
+    ix->cap_rows = (int64_t)std::min(ix->vf.mapped / row_f, ix->vc.mapped / row_c) / 256 * 256;
+    return 0;
+}
+
 static int grow(Index* ix, int64_t want) {
     if (want <= ix->cap_rows) return 0;
     const size_t row_f = (size_t)ix->d * sizeof(float), row_c = (size_t)ix->dpad * 2;
+    KR_TRY(wait_adds_host(ix));
     // small indexes (< 256 MiB of rows) live in plain hipMalloc memory and grow by copy; from 256 MiB on the rows move ONCE into mapped chunks
-    // (64 MiB each) and never again
+    // (64 MiB each) inside a reserved address range of max(16 GiB, 8 x the requested rows), where they stay until that range is used up (then: ONE
+    // more move into a range 8 x larger, i.e. the whole device — a 100-GB index appended without reserve() copies its first 16 GiB once).  Round 2
+    // reserved the whole HBM for every index: ~170 create / destroy cycles used up the address budget below; now > 3000 for indexes up to 16 GiB.
     if (ix->vmm < 0 && (size_t)want * (row_f + row_c) >= ((size_t)256 << 20)) {
         ix->vmm = 0;
-        size_t free_b = 0, total_b = 0;
-        if (!getenv("KIRAG_AMD_NO_VMM") && g_va_retired.load() < (48ull << 40) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
-            const size_t max_rows = total_b / (row_f + row_c) + 4096;          // more rows than the device could ever hold
-            if (ix->vf.init(ix->device, max_rows * row_f) == 0 && ix->vc.init(ix->device, max_rows * row_c) == 0) ix->vmm = 1;
-            else { ix->vf.release(); ix->vc.release(); }
-        }
-        if (ix->vmm == 1) {
-            const int64_t ncap = round_up(want, 256);
-            const int rf = ix->vf.ensure((size_t)ncap * row_f), rc = rf == 0 ? ix->vc.ensure((size_t)ncap * row_c) : rf;
-            if (rf != 0 || rc != 0) {
-                ix->vf.release(); ix->vc.release(); ix->vmm = 0;
-                if (rf == KR_ENOMEM || rc == KR_ENOMEM) return fail(KR_ENOMEM, "out of device memory growing the index to %lld rows", (long long)want);
-            } else {
-                float* nf = reinterpret_cast<float*>(ix->vf.base); uint16_t* nc = reinterpret_cast<uint16_t*>(ix->vc.base);
-                if (ix->n > 0) {   // the one migration copy (< 256 MiB); includes the NaN padding rows of the 16-bit copy
-                    KR_HIP(hipMemcpy(nf, ix->xf, (size_t)ix->n * row_f, hipMemcpyDeviceToDevice));
-                    KR_HIP(hipMemcpy(nc, ix->xc, (size_t)round_up(ix->n, 256) * row_c, hipMemcpyDeviceToDevice));
-                }
-                if (ix->xf) (void)hipFree(ix->xf);
-                if (ix->xc) (void)hipFree(ix->xc);
-                ix->xf = nf; ix->xc = nc;
-                ix->cap_rows = (int64_t)std::min(ix->vf.mapped / row_f, ix->vc.mapped / row_c) / 256 * 256;
-                return 0;
-            }
+        if (ix->no_vmm) {
+        } else if (va_retired_total() >= VA_BUDGET) {
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true)) fprintf(stderr, "kirag_amd: %.1f TiB of virtual addresses retired by earlier indexes; new indexes grow by hipMalloc + copy\n",
+                                              (double)va_retired_total() / (double)(1ull << 40));
+        } else {
+            const int rc = vmm_move(ix, want);
+            if (rc == 0) return 0;
+            if (rc != -1) return rc;
         }
     } else if (ix->vmm == 1) {
         const int64_t ncap = round_up(want, 256);
-        const int rf = ix->vf.ensure((size_t)ncap * row_f), rc = rf == 0 ? ix->vc.ensure((size_t)ncap * row_c) : rf;
-        if (rf == 0 && rc == 0) {
-            ix->cap_rows = (int64_t)std::min(ix->vf.mapped / row_f, ix->vc.mapped / row_c) / 256 * 256;
-            return 0;                                                           // rows did not move; the NaN padding behind row n is still in place
+        if ((size_t)ncap * row_f <= ix->vf.reserved && (size_t)ncap * row_c <= ix->vc.reserved) {
+            const int rf = ix->vf.ensure((size_t)ncap * row_f), rc = rf == 0 ? ix->vc.ensure((size_t)ncap * row_c) : rf;
+            if (rf == 0 && rc == 0) {
+                ix->cap_rows = (int64_t)std::min(ix->vf.mapped / row_f, ix->vc.mapped / row_c) / 256 * 256;
+                return 0;                                                       // rows did not move; the NaN padding behind row n is still in place
+            }
+            if (rf == KR_ENOMEM || rc == KR_ENOMEM) return fail(KR_ENOMEM, "out of device memory growing the index to %lld rows", (long long)want);
+            return fail(KR_EHIP, "mapping more index memory failed");
         }
-        if (rf == KR_ENOMEM || rc == KR_ENOMEM) return fail(KR_ENOMEM, "out of device memory growing the index to %lld rows", (long long)want);
-        return fail(KR_EHIP, "mapping more index memory failed");
+        const int rc = vmm_move(ix, want);                                      // reservation used up: one move into a larger one
+        if (rc == 0) return 0;
+        return rc != -1 ? rc : fail(KR_EHIP, "reserving a larger address range for the index failed");
     }
     int64_t ncap = std::max<int64_t>(want, ix->cap_rows + ix->cap_rows / 2);
     ncap = round_up(ncap, 256);
@@ -1000,8 +1049,9 @@ static int grow(Index* ix, int64_t want) {
     hipError_t e = hipMalloc(&nc, (size_t)ncap * ix->dpad * 2);
     if (e != hipSuccess) { (void)hipFree(nf); return fail(KR_ENOMEM, "hipMalloc of the coarse copy failed: %s", hipGetErrorString(e)); }
     if (ix->n > 0) {
-        KR_HIP(hipMemcpy(nf, ix->xf, (size_t)ix->n * ix->d * sizeof(float), hipMemcpyDeviceToDevice));
-        KR_HIP(hipMemcpy(nc, ix->xc, (size_t)ix->n * ix->dpad * 2, hipMemcpyDeviceToDevice));
+        e = hipMemcpy(nf, ix->xf, (size_t)ix->n * ix->d * sizeof(float), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(nc, ix->xc, (size_t)ix->n * ix->dpad * 2, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) { (void)hipFree(nf); (void)hipFree(nc); return fail(KR_EHIP, "copying the index rows failed: %s", hipGetErrorString(e)); }
     }
     if (ix->xf) (void)hipFree(ix->xf);
     if (ix->xc) (void)hipFree(ix->xc);
@@ -1024,9 +1074,8 @@ static int ensure_ws(Index* ix, int k, int cand_cap) {
         KR_HIP(hipMalloc(&ix->flags, QBLK * sizeof(uint32_t)));
         KR_HIP(hipMalloc(&ix->nrer, QBLK * sizeof(uint32_t)));
         KR_HIP(hipMalloc(&ix->q_f2, (size_t)32 * ix->d * sizeof(float)));
-        KR_HIP(hipMalloc(&ix->theta1, QBLK * sizeof(float)));
+        KR_HIP(hipMalloc(&ix->theta1, (size_t)THETA_BLOCKS * QBLK * sizeof(float)));
         KR_HIP(hipMalloc(&ix->thr_mark, 32 * sizeof(float)));
-        KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->h_status), (5 * QBLK + 16) * sizeof(uint32_t), hipHostMallocDefault));
         KR_HIP(hipMalloc(&ix->ex_qidx, QBLK * sizeof(int)));
         KR_HIP(hipMalloc(&ix->blk_list, (size_t)ix->num_cu * ShapeC::NWAVE * WLISTCAP * sizeof(uint4)));
         KR_HIP(hipMalloc(&ix->blk_cnt, ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int)));
@@ -1143,7 +1192,7 @@ static void plan_buffers(int k, int& K1, int& cap, int& rmax) {
 //   thr = K1-th best; as soon as rows_seen * (cap / 64) >= rows_left the rest is ONE final round whose threshold is the r-th best seen with
 //   r = (cap/2) * seen / left  (expected cap/2 survivors), 32 <= r <= K1.
 template <class Launch>
-static int run_rounds(Index* ix, CoarseArgs& a, int64_t n_rows, int nq, int bm, int K1, int cap, hipStream_t st, bool timed, Launch&& launch, int& final_preset, int& rounds) {
+static int run_rounds(Index* ix, CoarseArgs& a, int64_t n_rows, int nq, int bm, int K1, int cap, hipStream_t st, hipEvent_t* timed, Launch&& launch, int& final_preset, int& rounds) {
     a.ntiles = (n_rows + bm - 1) / bm;
     // interleaving permutation: multiplier near ntiles / golden ratio, coprime to ntiles
     int64_t mul = std::max<int64_t>(1, (int64_t)((double)a.ntiles * 0.6180339887498949));
@@ -1159,9 +1208,9 @@ static int run_rounds(Index* ix, CoarseArgs& a, int64_t n_rows, int nq, int bm, 
     while (done < a.ntiles) {
         const int64_t cnt_t = std::min<int64_t>(step, a.ntiles - done);
         a.tile_begin = done; a.tile_count = cnt_t;
-        if (timed && round < 16) KR_HIP(hipEventRecord(ix->evc[2 * round], st));
+        if (timed && round < 16) KR_HIP(hipEventRecord(timed[2 * round], st));
         KR_TRY(launch(a));
-        if (timed && round < 16) KR_HIP(hipEventRecord(ix->evc[2 * round + 1], st));
+        if (timed && round < 16) KR_HIP(hipEventRecord(timed[2 * round + 1], st));
         const int preset = a.direct ? (int)(cnt_t * bm) : 0;
         ++round;
         done += cnt_t;
@@ -1184,28 +1233,40 @@ static int run_rounds(Index* ix, CoarseArgs& a, int64_t n_rows, int nq, int bm, 
     return 0;
 }
 
-static int launch_rerank(Index* ix, int nq, int k, int rmax, int final_preset, const float* qf, const int* qmap, hipStream_t st) {
+static int launch_rerank(Index* ix, int nq, int k, int rmax, int final_preset, const float* qf, const int* qmap, float* theta_out, hipStream_t st) {
     const size_t rer_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + (size_t)rmax * sizeof(uint64_t) + 264 * sizeof(unsigned int);
     auto rerank = ix->d <= 1024 ? &k_rerank<4> : ix->d <= 2048 ? &k_rerank<8> : &k_rerank<16>;   // row steps held in registers
     hipLaunchKernelGGL(rerank, dim3(nq), dim3(256), rer_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, ix->eps, qf, ix->xf, ix->d, k,
-                       final_preset, rmax, ix->out_s, ix->out_r, ix->nrer, qmap, ix->force_exact, qmap ? nullptr : ix->theta1);
+                       final_preset, rmax, ix->out_s, ix->out_r, ix->nrer, qmap, ix->force_exact, theta_out);
     KR_HIP(hipGetLastError());
     return 0;
 }
 
-template <class T>
-static int search_block(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int mode, hipStream_t st) {
-    const bool smallq = nq <= ShapeSplit::BN;             // one 128-query tile: HBM-bound scan on the producer / consumer loop
-    const int kt64 = ix->dpad / 64;
-    const bool q32 = nq <= 32 && (kt64 == 16 || kt64 == 12 || kt64 == 8 || kt64 == 6) && !getenv("KIRAG_AMD_NO_Q32");   // register-resident queries, pure stream
-    const int nq_pad = q32 ? 32 : (int)round_up(nq, smallq ? ShapeSplit::BN : ShapeC::BN);   // <= QBLK = 1024 = 4 x 256
-    int K1, cap, rmax;
-    plan_buffers(k, K1, cap, rmax);
-    const bool coarse_pass = mode == 0;                   // mode 1: exact scan only; mode 2: high-precision pass only (test hooks)
-    const bool fine_ok = mode != 1 && ix->d <= FINE_DMAX && !getenv("KIRAG_AMD_NO_FINE");
-    KR_TRY(ensure_ws(ix, k, cap));
+constexpr int P2_WORDS = 3 * QBLK + 16;      // pass-2 status region at the head of h_status
+static int ensure_status(Index* ix, int nblocks) {
+    if (nblocks <= ix->status_blocks) return 0;
+    const int nb = std::max(nblocks, 4);
+    if (ix->h_status) (void)hipHostFree(ix->h_status);
+    ix->h_status = nullptr; ix->status_blocks = 0;
+    KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->h_status), ((size_t)P2_WORDS + (size_t)nb * STATUS_STRIDE) * sizeof(uint32_t), hipHostMallocDefault));
+    ix->status_blocks = nb;
+    return 0;
+}
+
+struct BlockPlan { bool smallq, q32; int kt64, nq_pad, K1, cap, rmax; };
+static BlockPlan plan_block(const Index* ix, int nq, int k) {
+    BlockPlan p;
+    p.smallq = nq <= ShapeSplit::BN;             // one 128-query tile: HBM-bound scan on the producer / consumer loop
+    p.kt64 = ix->dpad / 64;
+    p.q32 = nq <= 32 && (p.kt64 == 16 || p.kt64 == 12 || p.kt64 == 8 || p.kt64 == 6) && !ix->no_q32;   // register-resident queries, pure stream
+    p.nq_pad = p.q32 ? 32 : (int)round_up(nq, p.smallq ? ShapeSplit::BN : ShapeC::BN);   // <= QBLK = 1024 = 4 x 256
+    plan_buffers(k, p.K1, p.cap, p.rmax);
+    return p;
+}
+
+static int search_attrs(Index* ix) {
     static DevOnce sel_once;
-    KR_TRY(once_per_device(sel_once, ix->device, [&]() -> int {   // cap = 8192 needs 64 KiB + of dynamic LDS
+    return once_per_device(sel_once, ix->device, [&]() -> int {   // cap = 8192 needs 64 KiB + of dynamic LDS
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 8192 * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 8192 * 8 + 264 * 4));
@@ -1215,69 +1276,93 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return 0;
-    }));
-    KR_HIP(hipMemcpyAsync(ix->q_f, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyDefault, st));
-    KR_HIP(hipEventRecord(ix->ev[0], st));
-    std::vector<uint32_t> hflags(nq, 2u);
-    double coarse_ms = 0.0;
-    CoarseArgs a{};
+    });
+}
+
+static void fill_args(const Index* ix, CoarseArgs& a) {
+    a = CoarseArgs{};
     a.xc = ix->xc; a.n = ix->n; a.dpad = ix->dpad; a.qc = ix->q_c;
     a.thr = ix->thr; a.cnt = ix->cnt; a.flags = ix->flags; a.cand = ix->cand; a.cand_cap = ix->cand_cap;
     a.blk_list = ix->blk_list; a.blk_cnt = ix->blk_cnt; a.list_overflow = ix->blk_cnt + ix->num_cu * ShapeC::NWAVE;
     a.xf = ix->xf; a.d = ix->d; a.bitmap = nullptr; a.rowlist = nullptr; a.nlist = 0;
+}
+
+// ---- pass 1 of one block of <= 1024 queries: 16-bit MFMA scan + certified re-rank.  ENQUEUE ONLY: the per-query certificate flags, the re-rank counts and
+// the list-overflow word go to the block's status record in pinned memory, the (optimistic) results straight into the caller's buffers; nothing here waits
+// for the device.  kr_index_search_finish reads the status records and re-answers the flagged queries (slow_passes).
+template <class T>
+static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int blk, hipStream_t st, int& rounds) {
+    const BlockPlan p = plan_block(ix, nq, k);
+    KR_TRY(ensure_ws(ix, k, p.cap));
+    KR_TRY(search_attrs(ix));
+    KR_HIP(hipMemcpyAsync(ix->q_f, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyDefault, st));
+    CoarseArgs a; fill_args(ix, a);
     const size_t blk_cnt_bytes = ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int);
-    // ---- pass 1: 16-bit MFMA scan + certified re-rank, all queries -----------------------------------------------------------------------
-    if (coarse_pass) {
-        hipLaunchKernelGGL(k_prep_queries<T>, dim3(nq_pad), dim3(64), 0, st, ix->q_f, ix->q_c, nq, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr,
-                           ix->cnt, ix->flags);
-        a.nq_pad = nq_pad; a.nq = nq;
-        KR_HIP(hipMemsetAsync(ix->blk_cnt, 0, blk_cnt_bytes, st));
-        const int bm = q32 ? 32 : smallq ? ShapeSplit::BM : ShapeC::BM;
-        const int lds = smallq ? COARSE_LDS_SMALLQ : COARSE_LDS;
-        static DevOnce coarse_once;
-        KR_TRY(once_per_device(coarse_once, ix->device, [&]() -> int {
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
-            KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
-            return 0;
-        }));
-        int final_preset = 0, rounds = 0;
-        KR_TRY(run_rounds(ix, a, ix->n, nq, bm, K1, cap, st, true, [&](const CoarseArgs& ca) -> int {
-            if (q32) return launch_q32<T>(ca, kt64, ix->num_cu, ix->device, st);
-            if (smallq) {
-                if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
-                else hipLaunchKernelGGL((k_coarse<T, false, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
-            } else if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
-            else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
-            return 0;
-        }, final_preset, rounds));
-        ix->st.coarse_rounds += rounds;
-        KR_TRY(launch_rerank(ix, nq, k, rmax, final_preset, ix->q_f, nullptr, st));
-        // one round trip: status words into pinned memory and (optimistically) the results into the caller's buffers, ONE stream sync;
-        // only if a query was flagged do the further passes run and overwrite its rows
-        KR_HIP(hipMemcpyAsync(ix->h_status, ix->flags, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        KR_HIP(hipMemcpyAsync(ix->h_status + QBLK, ix->nrer, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        KR_HIP(hipMemcpyAsync(ix->h_status + 2 * QBLK, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-        KR_HIP(hipMemcpyAsync(scores, ix->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
-        KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
-        KR_HIP(hipEventRecord(ix->ev[3], st));
-        KR_HIP(hipStreamSynchronize(st));
-        const bool list_ovf = ix->h_status[2 * QBLK] != 0u;   // a block list overflowed (sticky for the call): every query goes on to the next pass
-        for (int i = 0; i < nq; ++i) { hflags[i] = ix->h_status[i] | (list_ovf ? 1u : 0u); ix->st.reranked_rows += ix->h_status[QBLK + i]; }
-        for (int r = 0; r < rounds && r < 16; ++r) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ix->evc[2 * r], ix->evc[2 * r + 1]) == hipSuccess) coarse_ms += ms;
+    hipLaunchKernelGGL(k_prep_queries<T>, dim3(p.nq_pad), dim3(64), 0, st, ix->q_f, ix->q_c, nq, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr,
+                       ix->cnt, ix->flags);
+    a.nq_pad = p.nq_pad; a.nq = nq;
+    KR_HIP(hipMemsetAsync(ix->blk_cnt, 0, blk_cnt_bytes, st));
+    const int bm = p.q32 ? 32 : p.smallq ? ShapeSplit::BM : ShapeC::BM;
+    const int lds = p.smallq ? COARSE_LDS_SMALLQ : COARSE_LDS;
+    static DevOnce coarse_once;
+    KR_TRY(once_per_device(coarse_once, ix->device, [&]() -> int {
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
+        return 0;
+    }));
+    int final_preset = 0;
+    rounds = 0;
+    KR_TRY(run_rounds(ix, a, ix->n, nq, bm, p.K1, p.cap, st, blk < TIMED_BLOCKS ? ix->evc + blk * 32 : nullptr, [&](const CoarseArgs& ca) -> int {
+        if (p.q32) return launch_q32<T>(ca, p.kt64, ix->num_cu, ix->device, st);
+        if (p.smallq) {
+            if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+            else hipLaunchKernelGGL((k_coarse<T, false, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+        } else if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+        else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+        return 0;
+    }, final_preset, rounds));
+    ix->st.coarse_rounds += rounds;
+    KR_TRY(launch_rerank(ix, nq, k, p.rmax, final_preset, ix->q_f, nullptr, blk < THETA_BLOCKS ? ix->theta1 + (size_t)blk * QBLK : nullptr, st));
+    uint32_t* rec = ix->h_status + P2_WORDS + (size_t)blk * STATUS_STRIDE;
+    KR_HIP(hipMemcpyAsync(rec, ix->flags, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    KR_HIP(hipMemcpyAsync(rec + QBLK, ix->nrer, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    KR_HIP(hipMemcpyAsync(rec + 2 * QBLK, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    KR_HIP(hipMemcpyAsync(scores, ix->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
+    KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
+    return 0;
+}
+
+// ---- passes 2 and 3 for the queries of one block whose hflags entry is non-zero (blocking: the rare path).  `restore`: the workspace no longer holds this
+// block (a later block of the same call went through it): its queries are copied in again and, when pass 1 produced results, its result rows too.
+template <class T>
+static int slow_passes(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int blk, hipStream_t st,
+                       const std::vector<uint32_t>& hflags, bool coarse_pass, bool fine_allowed, bool restore) {
+    const BlockPlan p = plan_block(ix, nq, k);
+    const int K1 = p.K1, cap = p.cap, rmax = p.rmax, kt64 = p.kt64;
+    const bool fine_ok = fine_allowed && ix->d <= FINE_DMAX && !ix->no_fine;
+    KR_TRY(ensure_ws(ix, k, cap));
+    KR_TRY(search_attrs(ix));
+    if (restore) {
+        KR_HIP(hipMemcpyAsync(ix->q_f, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyDefault, st));
+        if (coarse_pass) {
+            KR_HIP(hipMemcpyAsync(ix->out_s, scores, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
+            KR_HIP(hipMemcpyAsync(ix->out_r, rows, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
         }
     }
+    CoarseArgs a; fill_args(ix, a);
+    const size_t blk_cnt_bytes = ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int);
     std::vector<int> fl;
     for (int i = 0; i < nq; ++i) {
         if (hflags[i]) { fl.push_back(i); if (coarse_pass && (hflags[i] & 1u)) ix->st.overflow++; }
     }
     const int64_t n_flagged = (int64_t)fl.size();
+    if (fl.empty()) return 0;
+    uint32_t* const hs = ix->h_status;                      // pass-2 status region
     // ---- pass 2: fp64 MFMA scan of the fp32 master rows for the flagged queries, in groups that share one pass over the corpus -------------------
     std::vector<int> fl3;
-    if (!fl.empty() && fine_ok) {
+    if (fine_ok) {
         const int gmax = ix->d <= 1024 ? FINE_QMAX : 16;
         KR_HIP(hipMemcpyAsync(ix->ex_qidx, fl.data(), fl.size() * sizeof(int), hipMemcpyHostToDevice, st));
         KR_HIP(hipEventRecord(ix->ev[1], st));
@@ -1297,7 +1382,7 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
             a.rowlist = nullptr; a.nlist = 0;
             int64_t n_scan = ix->n;
             // (once a group's pre-scan marks more than a quarter of the rows, the remaining groups of this call skip it: on such data it only adds its stream)
-            const bool can_mark = coarse_pass && mark_useful && (kt64 == 16 || kt64 == 12 || kt64 == 8 || kt64 == 6) && !getenv("KIRAG_AMD_NO_MARK");
+            const bool can_mark = coarse_pass && blk < THETA_BLOCKS && mark_useful && (kt64 == 16 || kt64 == 12 || kt64 == 8 || kt64 == 6) && !ix->no_mark;
             if (can_mark) {
                 const size_t words = (size_t)((ix->n + 31) / 32);
                 if (words > ix->bitmap_words) {
@@ -1310,16 +1395,16 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
                 }
                 KR_HIP(hipMemsetAsync(ix->bitmap, 0, (words + 1) * sizeof(uint32_t), st));
                 hipLaunchKernelGGL(k_prep_queries<T>, dim3(32), dim3(64), 0, st, ix->q_f2, ix->q_c, g, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr, ix->cnt, ix->flags);
-                hipLaunchKernelGGL(k_gather_theta, dim3(1), dim3(64), 0, st, ix->theta1, qmap, g, ix->thr_mark);
+                hipLaunchKernelGGL(k_gather_theta, dim3(1), dim3(64), 0, st, ix->theta1 + (size_t)blk * QBLK, qmap, g, ix->thr_mark);
                 CoarseArgs m = a;
                 m.qc = ix->q_c; m.nq_pad = 32; m.nq = g; m.thr = ix->thr_mark; m.bitmap = ix->bitmap; m.direct = 2;
                 m.ntiles = (ix->n + 31) / 32; m.perm_mul = 1; m.tile_begin = 0; m.tile_count = m.ntiles;
                 KR_TRY((launch_q32<T>(m, kt64, ix->num_cu, ix->device, st)));
                 unsigned int* cnt_word = ix->bitmap + words;
                 hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ix->bitmap, (int64_t)words, ix->rowlist, cnt_word);
-                KR_HIP(hipMemcpyAsync(ix->h_status + 5 * QBLK + 4, cnt_word, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                KR_HIP(hipMemcpyAsync(hs + 3 * QBLK + 8, cnt_word, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
                 KR_HIP(hipStreamSynchronize(st));                 // the row count sizes the rounds of this group (pass 2 is the rare path)
-                const int64_t marked = (int64_t)ix->h_status[5 * QBLK + 4];
+                const int64_t marked = (int64_t)hs[3 * QBLK + 8];
                 if (marked >= k && marked <= ix->n / 2) { a.rowlist = ix->rowlist; a.nlist = marked; n_scan = marked; }
                 if (marked > ix->n / 4) mark_useful = false;
                 ix->st.marked_passes++; ix->st.marked_rows += marked;
@@ -1329,7 +1414,7 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
             a.nq_pad = 16 * nt; a.nq = g; a.qf = ix->q_f2;
             const int lds = fine_lds_bytes(ix->d, 16 * nt);
             int final_preset = 0, rounds = 0;
-            KR_TRY(run_rounds(ix, a, n_scan, g, 32, K1, cap, st, false, [&](const CoarseArgs& ca) -> int {
+            KR_TRY(run_rounds(ix, a, n_scan, g, 32, K1, cap, st, nullptr, [&](const CoarseArgs& ca) -> int {
                 if (nt == 1) {
                     if (ca.direct) hipLaunchKernelGGL((k_fine<true, 1>), dim3(ix->num_cu), dim3(FINE_THREADS), lds, st, ca);
                     else hipLaunchKernelGGL((k_fine<false, 1>), dim3(ix->num_cu), dim3(FINE_THREADS), lds, st, ca);
@@ -1340,15 +1425,13 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
                 return 0;
             }, final_preset, rounds));
             ix->st.fine_rounds += rounds;
-            KR_TRY(launch_rerank(ix, g, k, rmax, final_preset, ix->q_f2, qmap, st));
-            uint32_t* hs = ix->h_status + 2 * QBLK + 4;
+            KR_TRY(launch_rerank(ix, g, k, rmax, final_preset, ix->q_f2, qmap, nullptr, st));
             KR_HIP(hipMemcpyAsync(hs + g0, ix->flags, g * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             KR_HIP(hipMemcpyAsync(hs + QBLK + g0, ix->nrer, g * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             KR_HIP(hipMemcpyAsync(hs + 2 * QBLK + ngroups, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
         }
         KR_HIP(hipEventRecord(ix->ev[2], st));
         KR_HIP(hipStreamSynchronize(st));
-        const uint32_t* hs = ix->h_status + 2 * QBLK + 4;
         for (size_t j = 0; j < fl.size(); ++j) {
             const bool ovf = hs[2 * QBLK + j / gmax] != 0u;
             ix->st.reranked_rows += hs[QBLK + j];
@@ -1366,18 +1449,77 @@ static int search_block(Index* ix, const float* q, int nq, int k, float* scores,
         KR_TRY(exact_scan(ix, (int)fl3.size(), k, st));
         ix->st.exact += (int64_t)fl3.size();
     }
-    if (!fl.empty()) {
-        KR_HIP(hipMemcpyAsync(scores, ix->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
-        KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
-        KR_HIP(hipEventRecord(ix->ev[3], st));
-        KR_HIP(hipStreamSynchronize(st));
+    KR_HIP(hipMemcpyAsync(scores, ix->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
+    KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
+    KR_HIP(hipStreamSynchronize(st));
+    ix->st.fallback += n_flagged;
+    return 0;
+}
+
+// enqueue pass 1 of every block of a search; ix->pend describes the call until finish_search() has run
+static int begin_search(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, hipStream_t st) {
+    const int nblocks = (nq + QBLK - 1) / QBLK;
+    KR_TRY(ensure_status(ix, nblocks));
+    if (!ix->ev_done) KR_HIP(hipEventCreateWithFlags(&ix->ev_done, hipEventDisableTiming));
+    if (ix->ev_add) KR_HIP(hipStreamWaitEvent(st, ix->ev_add, 0));   // rows added asynchronously on another stream
+    ix->force_exact = g_force_exact.load();
+    ix->st.last_coarse_ms = 0.0; ix->st.last_total_ms = 0.0; ix->st.last_fine_ms = 0.0;
+    Index::Pending& pd = ix->pend;
+    pd.q = q; pd.nq = nq; pd.k = k; pd.scores = scores; pd.rows = rows; pd.st = st; pd.rounds.assign(nblocks, 0);
+    {   // ensure_ws creates the events on first use: make sure they exist before the first record
+        int K1, cap, rmax; plan_buffers(k, K1, cap, rmax);
+        KR_TRY(ensure_ws(ix, k, cap));
+    }
+    KR_HIP(hipEventRecord(ix->ev[0], st));
+    pd.active = true;      // from here on finish_search() has something to wait for, also when a later block fails to enqueue
+    for (int b = 0; b < nblocks; ++b) {
+        const int nb = std::min(QBLK, nq - b * QBLK);
+        const float* qb = q + (size_t)b * QBLK * ix->d;
+        float* sb = scores + (size_t)b * QBLK * k; int64_t* rb = rows + (size_t)b * QBLK * k;
+        int rc;
+        if (ix->coarse == KR_COARSE_BF16) rc = pass1_enqueue<BF16>(ix, qb, nb, k, sb, rb, b, st, pd.rounds[b]);
+        else rc = pass1_enqueue<F16>(ix, qb, nb, k, sb, rb, b, st, pd.rounds[b]);
+        if (rc) { (void)hipStreamSynchronize(st); pd.active = false; return rc; }
+    }
+    KR_HIP(hipEventRecord(ix->ev[3], st));
+    KR_HIP(hipEventRecord(ix->ev_done, st));
+    return 0;
+}
+
+// wait for the enqueued pass 1, read the status records, run passes 2 / 3 for flagged queries (patching the caller's buffers), update the statistics
+static int finish_search(Index* ix) {
+    Index::Pending& pd = ix->pend;
+    if (!pd.active) return 0;
+    pd.active = false;
+    KR_HIP(hipEventSynchronize(ix->ev_done));
+    const int nblocks = (pd.nq + QBLK - 1) / QBLK;
+    int64_t flagged_total = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        const int nb = std::min(QBLK, pd.nq - b * QBLK);
+        const uint32_t* rec = ix->h_status + P2_WORDS + (size_t)b * STATUS_STRIDE;
+        const bool list_ovf = rec[2 * QBLK] != 0u;   // a block list overflowed: every query of the block goes on to the next pass
+        std::vector<uint32_t> hflags(nb);
+        int64_t nfl = 0;
+        for (int i = 0; i < nb; ++i) { hflags[i] = rec[i] | (list_ovf ? 1u : 0u); ix->st.reranked_rows += rec[QBLK + i]; nfl += hflags[i] != 0u; }
+        if (b < TIMED_BLOCKS)
+            for (int r = 0; r < pd.rounds[b] && r < 16; ++r) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ix->evc[b * 32 + 2 * r], ix->evc[b * 32 + 2 * r + 1]) == hipSuccess) ix->st.last_coarse_ms += ms;
+            }
+        if (nfl) {
+            const float* qb = pd.q + (size_t)b * QBLK * ix->d;
+            float* sb = pd.scores + (size_t)b * QBLK * pd.k; int64_t* rb = pd.rows + (size_t)b * QBLK * pd.k;
+            int rc;
+            if (ix->coarse == KR_COARSE_BF16) rc = slow_passes<BF16>(ix, qb, nb, pd.k, sb, rb, b, pd.st, hflags, true, true, nblocks > 1);
+            else rc = slow_passes<F16>(ix, qb, nb, pd.k, sb, rb, b, pd.st, hflags, true, true, nblocks > 1);
+            if (rc) return rc;
+        }
+        flagged_total += nfl;
     }
     float tot = 0.f;
     if (hipEventElapsedTime(&tot, ix->ev[0], ix->ev[3]) == hipSuccess) ix->st.last_total_ms += tot;
-    ix->st.last_coarse_ms += coarse_ms;
-    ix->st.queries += nq;
-    ix->st.fallback += n_flagged;
-    ix->st.certified += nq - n_flagged;
+    ix->st.queries += pd.nq;
+    ix->st.certified += pd.nq - flagged_total;
     return 0;
 }
 
@@ -1451,6 +1593,8 @@ int kr_index_create(int d, int metric, int coarse_dtype, int device, kr_index** 
     hipError_t e = hipMalloc(&ix->bounds, 2 * sizeof(float));
     if (e != hipSuccess) { delete ix; return fail(KR_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
     (void)hipMemset(ix->bounds, 0, 2 * sizeof(float));
+    ix->no_q32 = getenv("KIRAG_AMD_NO_Q32") != nullptr; ix->no_fine = getenv("KIRAG_AMD_NO_FINE") != nullptr;
+    ix->no_mark = getenv("KIRAG_AMD_NO_MARK") != nullptr; ix->no_vmm = getenv("KIRAG_AMD_NO_VMM") != nullptr;
     *out = reinterpret_cast<kr_index*>(ix);
     return 0;
 }
@@ -1459,6 +1603,8 @@ void kr_index_destroy(kr_index* h) {
     if (!h) return;
     Index* ix = reinterpret_cast<Index*>(h);
     (void)hipSetDevice(ix->device);
+    if (ix->pend.active) { (void)hipEventSynchronize(ix->ev_done); ix->pend.active = false; }   // an unfinished asynchronous search: let its kernels drain
+    if (ix->ev_done) (void)hipEventDestroy(ix->ev_done);
     if (ix->vmm == 1) { (void)hipDeviceSynchronize(); ix->vf.release(); ix->vc.release(); ix->xf = nullptr; ix->xc = nullptr; }
     void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_f2, ix->theta1, ix->thr_mark, ix->bitmap, ix->rowlist, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
                     ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt};
@@ -1475,6 +1621,7 @@ int kr_index_reserve(kr_index* h, int64_t n_rows) {
     Index* ix = reinterpret_cast<Index*>(h);
     KR_TRY(select_device(ix->device));
     if (n_rows > 0xFFFFFFF0ll) return fail(KR_EINVAL, "at most 2^32-16 rows per index shard");
+    KR_TRY(finish_search(ix));
     return grow(ix, n_rows);
 }
 
@@ -1486,7 +1633,9 @@ int kr_index_add(kr_index* h, const float* x, int64_t n, void* stream) {
     KR_TRY(select_device(ix->device));
     if (ix->n + n > 0xFFFFFFF0ll) return fail(KR_EINVAL, "at most 2^32-16 rows per index shard");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    KR_TRY(finish_search(ix));
     KR_TRY(grow(ix, ix->n + n));
+    if (ix->ev_add) KR_HIP(hipStreamWaitEvent(st, ix->ev_add, 0));   // the NaN padding rows this add overwrites were written by the previous add's stream
     float* dst = ix->xf + ix->n * ix->d;
     KR_HIP(hipMemcpyAsync(dst, x, (size_t)n * ix->d * sizeof(float), hipMemcpyDefault, st));
     const unsigned grid = (unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)ix->num_cu * 16);   // grid-stride: 16 blocks of 4 waves per CU
@@ -1521,6 +1670,8 @@ int kr_index_get_rows(kr_index* h, int64_t start, int64_t n, float* out, void* s
     if (n == 0) return 0;
     KR_TRY(select_device(ix->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    KR_TRY(finish_search(ix));
+    if (ix->ev_add) KR_HIP(hipStreamWaitEvent(st, ix->ev_add, 0));   // rows appended asynchronously on another stream
     KR_HIP(hipMemcpyAsync(out, ix->xf + start * ix->d, (size_t)n * ix->d * sizeof(float), hipMemcpyDefault, st));
     KR_HIP(hipStreamSynchronize(st));
     return 0;
@@ -1538,6 +1689,8 @@ int kr_index_get_coarse(kr_index* h, int64_t start, int64_t n, uint16_t* out, vo
     if (n == 0) return 0;
     KR_TRY(select_device(ix->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    KR_TRY(finish_search(ix));
+    if (ix->ev_add) KR_HIP(hipStreamWaitEvent(st, ix->ev_add, 0));
     KR_HIP(hipMemcpyAsync(out, ix->xc + start * ix->dpad, (size_t)n * ix->dpad * 2, hipMemcpyDefault, st));
     KR_HIP(hipStreamSynchronize(st));
     return 0;
@@ -1547,6 +1700,7 @@ int kr_index_get_bounds(kr_index* h, float* out2) {
     if (!h || !out2) return fail(KR_EINVAL, "NULL argument");
     Index* ix = reinterpret_cast<Index*>(h);
     KR_TRY(select_device(ix->device));
+    KR_TRY(wait_adds_host(ix));          // the bounds are updated by the add kernels; this copy runs on the NULL stream
     KR_HIP(hipMemcpy(out2, ix->bounds, 2 * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1566,7 +1720,9 @@ int kr_index_add_raw(kr_index* h, const float* xf, const uint16_t* xc, int64_t n
     KR_TRY(select_device(ix->device));
     if (ix->n + n > 0xFFFFFFF0ll) return fail(KR_EINVAL, "at most 2^32-16 rows per index shard");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    KR_TRY(finish_search(ix));
     KR_TRY(grow(ix, ix->n + n));
+    if (ix->ev_add) KR_HIP(hipStreamWaitEvent(st, ix->ev_add, 0));
     KR_HIP(hipMemcpyAsync(ix->xf + ix->n * ix->d, xf, (size_t)n * ix->d * sizeof(float), hipMemcpyDefault, st));
     KR_HIP(hipMemcpyAsync(ix->xc + ix->n * ix->dpad, xc, (size_t)n * ix->dpad * 2, hipMemcpyDefault, st));
     hipLaunchKernelGGL(k_max_bounds, dim3(1), dim3(1), 0, st, ix->bounds, bounds2[0], bounds2[1]);
@@ -1580,27 +1736,58 @@ int kr_index_add_raw(kr_index* h, const float* xf, const uint16_t* xc, int64_t n
     return 0;
 }
 
-int kr_index_search(kr_index* h, const float* q, int nq, int k, float* scores, int64_t* rows, int mode, void* stream) {
-    if (!h) return fail(KR_EINVAL, "index is NULL");
-    Index* ix = reinterpret_cast<Index*>(h);
+static int check_search_args(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows) {
     if (nq < 0 || (nq > 0 && (!q || !scores || !rows))) return fail(KR_EINVAL, "bad query/output pointers");
     if (k <= 0 || (int64_t)k > ix->n) return fail(KR_EINVAL, "k=%d must satisfy 0 < k <= ntotal=%lld", k, (long long)ix->n);
     if (k > EXACT_RC) return fail(KR_EINVAL, "k=%d exceeds the supported maximum of %d", k, EXACT_RC);
+    return 0;
+}
+
+int kr_index_search(kr_index* h, const float* q, int nq, int k, float* scores, int64_t* rows, int mode, void* stream) {
+    if (!h) return fail(KR_EINVAL, "index is NULL");
+    Index* ix = reinterpret_cast<Index*>(h);
+    KR_TRY(check_search_args(ix, q, nq, k, scores, rows));
     if (mode < 0 || mode > 2) return fail(KR_EINVAL, "mode must be 0 (auto), 1 (exact scan only) or 2 (high-precision pass only)");
     if (nq == 0) return 0;
     KR_TRY(select_device(ix->device));
+    KR_TRY(finish_search(ix));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (ix->ev_add) KR_HIP(hipStreamWaitEvent(st, ix->ev_add, 0));   // rows added asynchronously on another stream
+    if (mode == 0) {   // every block's pass 1 is enqueued before the first status word is read: one host round trip per CALL
+        KR_TRY(begin_search(ix, q, nq, k, scores, rows, st));
+        return finish_search(ix);
+    }
+    // test hooks: mode 1 = exact scan only, mode 2 = high-precision pass (+ exact scan) only; every query takes the slow path
+    if (ix->ev_add) KR_HIP(hipStreamWaitEvent(st, ix->ev_add, 0));
     ix->force_exact = g_force_exact.load();
     ix->st.last_coarse_ms = 0.0; ix->st.last_total_ms = 0.0; ix->st.last_fine_ms = 0.0;
+    KR_TRY(ensure_status(ix, 1));
     for (int b = 0; b < nq; b += QBLK) {
         const int nb = std::min(QBLK, nq - b);
+        const std::vector<uint32_t> hflags(nb, 2u);
         int rc;
-        if (ix->coarse == KR_COARSE_BF16) rc = search_block<BF16>(ix, q + (size_t)b * ix->d, nb, k, scores + (size_t)b * k, rows + (size_t)b * k, mode, st);
-        else rc = search_block<F16>(ix, q + (size_t)b * ix->d, nb, k, scores + (size_t)b * k, rows + (size_t)b * k, mode, st);
+        if (ix->coarse == KR_COARSE_BF16) rc = slow_passes<BF16>(ix, q + (size_t)b * ix->d, nb, k, scores + (size_t)b * k, rows + (size_t)b * k, THETA_BLOCKS, st, hflags, false, mode != 1, true);
+        else rc = slow_passes<F16>(ix, q + (size_t)b * ix->d, nb, k, scores + (size_t)b * k, rows + (size_t)b * k, THETA_BLOCKS, st, hflags, false, mode != 1, true);
         if (rc) return rc;
+        ix->st.queries += nb;
     }
     return 0;
+}
+
+int kr_index_search_async(kr_index* h, const float* q, int nq, int k, float* scores, int64_t* rows, void* stream) {
+    if (!h) return fail(KR_EINVAL, "index is NULL");
+    Index* ix = reinterpret_cast<Index*>(h);
+    KR_TRY(check_search_args(ix, q, nq, k, scores, rows));
+    if (nq == 0) return 0;
+    KR_TRY(select_device(ix->device));
+    KR_TRY(finish_search(ix));                       // at most one search in flight per handle
+    return begin_search(ix, q, nq, k, scores, rows, reinterpret_cast<hipStream_t>(stream));
+}
+
+int kr_index_search_finish(kr_index* h) {
+    if (!h) return fail(KR_EINVAL, "index is NULL");
+    Index* ix = reinterpret_cast<Index*>(h);
+    KR_TRY(select_device(ix->device));
+    return finish_search(ix);
 }
 
 // exact top-k of q x^T for a small, transient candidate set (the KiRAG loop's aligner step): canonical scores of every (query, row)
@@ -1679,6 +1866,8 @@ int kr_index_stats(kr_index* h, kr_search_stats* out, int reset) {
     if (!h || !out) return fail(KR_EINVAL, "NULL argument");
     Index* ix = reinterpret_cast<Index*>(h);
     *out = ix->st;
+    out->va_retired_bytes = (int64_t)va_retired_total();
+    out->grow_mode = ix->vmm;
     if (reset) ix->st = kr_search_stats{};
     return 0;
 }

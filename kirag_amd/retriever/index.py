@@ -124,6 +124,30 @@ class FlatIPIndex:
         _lib.check(self._lib.kr_index_search(self._h, p, nq, k, int(scores_out.data_ptr()), int(rows_out.data_ptr()), int(mode),
                                              self._stream(q, scores_out, rows_out)))
 
+    def search_async(self, q, k: int, scores_out, rows_out) -> None:
+        """Enqueue-only half of ``search_into`` (``kr_index_search_async``): pass 1 of every 1024-query block goes onto torch's current stream and the
+        call returns without waiting for the device; ``q`` (a contiguous float32 CUDA tensor), ``scores_out`` and ``rows_out`` must stay alive and
+        untouched until ``finish()`` — which waits, re-answers the queries whose exactness certificate did not hold, and makes the results final."""
+        import torch
+        if not (torch.is_tensor(q) and q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()):
+            raise ValueError("search_async needs a contiguous float32 CUDA tensor of queries")
+        nq, k = int(q.shape[0]), int(k)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError(f"expected [nq,{self.d}] queries, got {tuple(q.shape)}")
+        if not 0 < k <= self.ntotal:
+            raise ValueError(f"top_docs={k} must satisfy 0 < k <= ntotal={self.ntotal}")
+        assert tuple(scores_out.shape) == (nq, k) and tuple(rows_out.shape) == (nq, k)
+        assert scores_out.is_contiguous() and rows_out.is_contiguous() and scores_out.dtype == torch.float32 and rows_out.dtype == torch.int64
+        self._pending = (q, scores_out, rows_out)                                  # keep-alive until finish()
+        _lib.check(self._lib.kr_index_search_async(self._h, int(q.data_ptr()), nq, k, int(scores_out.data_ptr()), int(rows_out.data_ptr()),
+                                                   self._stream(q, scores_out, rows_out)))
+
+    def finish(self) -> None:
+        try:
+            _lib.check(self._lib.kr_index_search_finish(self._h))
+        finally:
+            self._pending = None
+
     def reconstruct_n(self, start: int, n: int) -> np.ndarray:
         out = np.empty((n, self.d), np.float32)
         _lib.check(self._lib.kr_index_get_rows(self._h, int(start), int(n), out.ctypes.data, None))
@@ -211,6 +235,9 @@ class Indexer(object):
         write_faiss_flat_ip(self.index, index_file)
         with open(meta_file, mode='wb') as f:
             pickle.dump(self.index_id_to_db_id, f)
+        stale = os.path.join(dir_path, SHARD_MANIFEST)      # native shards of an EARLIER index in this directory must not shadow these files on reload
+        if os.path.exists(stale):
+            os.remove(stale)
 
     def deserialize_from(self, dir_path):
         index_file = os.path.join(dir_path, "index.faiss")
@@ -261,7 +288,17 @@ class ShardedIndexer(Indexer):
     def sync_shards(self):
         """Collective: assemble ``index_id_to_db_id`` (all ranks' ids in rank order), ``row_offset`` and ``ntotal_global`` after ``index_data`` calls."""
         import torch.distributed as dist
-        if not self._dirty:
+        dirty = bool(self._dirty)
+        if self.world > 1:
+            # the decision itself is collective: a rank whose share of a streamed build was empty (or that appended nothing after a reload) has
+            # _dirty == False while the others are already waiting in the gather below
+            backend = dist.get_backend(self.group)
+            import torch
+            flag = torch.tensor([1 if dirty else 0], dtype=torch.int32,
+                                device=torch.device("cuda", self.index.device) if backend == "nccl" else torch.device("cpu"))
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            dirty = bool(int(flag.item()))
+        if not dirty:
             return
         local = np.concatenate(self._local_ids, axis=0) if self._local_ids else np.empty((0), dtype=np.int64)
         parts = [None] * self.world
@@ -299,15 +336,19 @@ class ShardedIndexer(Indexer):
         ``index.faiss`` (``index.py:66-79``), of which each rank reads only its byte range."""
         meta_file = os.path.join(dir_path, "index_meta.faiss")
         manifest = os.path.join(dir_path, SHARD_MANIFEST)
-        if os.path.exists(manifest):
+        with open(meta_file, "rb") as reader:
+            id_map = pickle.load(reader)
+        if os.path.exists(manifest) and not _manifest_matches(manifest, id_map):
+            logger.warning(f'{manifest} does not belong to {meta_file} (row count or id-map checksum differ): ignoring the native shards')
+            manifest = None
+        if manifest is not None and os.path.exists(manifest):
             logger.info(f'Loading rank {self.rank}/{self.world} share of the native shards in {dir_path}')
             self.index = read_native_shards(dir_path, device=self.index.device, coarse_dtype=self.index.coarse_dtype, row_range=(self.rank, self.world))
         else:
             index_file = os.path.join(dir_path, "index.faiss")
             logger.info(f'Loading rank {self.rank}/{self.world} share of {index_file}, meta data from {meta_file}')
             self.index = read_faiss_flat_ip(index_file, device=self.index.device, coarse_dtype=self.index.coarse_dtype, row_range=(self.rank, self.world))
-        with open(meta_file, "rb") as reader:
-            self.index_id_to_db_id = pickle.load(reader)
+        self.index_id_to_db_id = id_map
         self.row_offset, self.ntotal_global = self.index.row_offset, self.index.file_ntotal
         assert len(self.index_id_to_db_id) == self.ntotal_global, 'Deserialized index_id_to_db_id should match faiss index size'
         # later index_data() calls append to this rank's shard: its ids so far are its slice of the loaded map
@@ -333,7 +374,7 @@ class ShardedIndexer(Indexer):
         if self.rank == 0:
             import json
             with open(os.path.join(dir_path, SHARD_MANIFEST), "w") as f:
-                json.dump({"format": "krshard-1", "d": self.index.d, "coarse_dim": self.index.coarse_dim, "coarse_dtype": self.index.coarse_dtype,
+                json.dump({"format": "krshard-1", "meta_crc32": _ids_crc32(self.index_id_to_db_id), "d": self.index.d, "coarse_dim": self.index.coarse_dim, "coarse_dtype": self.index.coarse_dtype,
                            "ntotal": int(self.ntotal_global), "world": self.world, "shards": sorted(info, key=lambda e: e["row0"])}, f, indent=1)
             with open(os.path.join(dir_path, "index_meta.faiss"), mode='wb') as f:
                 pickle.dump(self.index_id_to_db_id, f)
@@ -421,6 +462,26 @@ def read_faiss_flat_ip(path: str, device: Optional[int] = None, coarse_dtype: st
 #   f32 [rows, d]   master rows ; u16 [rows, coarse_dim]  scan copy
 # ---------------------------------------------------------------------------------------------------------
 SHARD_MANIFEST = "kirag_shards.json"
+
+
+def _ids_crc32(ids) -> int:
+    import zlib
+    return int(zlib.crc32(np.ascontiguousarray(np.asarray(ids, dtype=np.int64)).tobytes()) & 0xFFFFFFFF)
+
+
+def _manifest_matches(manifest_path: str, id_map) -> bool:
+    """The native shards belong to the ``index_meta.faiss`` next to them: same row count and (manifests written since round 3) the same CRC-32 of
+    the id map.  A directory later rewritten with the reference-format files fails this and is loaded from ``index.faiss``."""
+    import json
+    try:
+        with open(manifest_path) as f:
+            man = json.load(f)
+    except Exception:
+        return False
+    if int(man.get("ntotal", -1)) != len(id_map):
+        return False
+    crc = man.get("meta_crc32")
+    return crc is None or int(crc) == _ids_crc32(id_map)
 _SHARD_MAGIC = b"KRSHARD1"
 _SHARD_HEADER = struct.Struct("<8siiiiqqqff")
 
@@ -458,6 +519,7 @@ def read_native_shards(dir_path: str, device: Optional[int] = None, coarse_dtype
     index = FlatIPIndex(d, device=device, coarse_dtype=coarse_dtype)
     index.reserve(b - a)
     raw = man["coarse_dtype"] == coarse_dtype
+    want_code = {"bf16": 0, "f16": 1}[coarse_dtype]
     covered = a
     for sh in man["shards"]:
         r0, rows = int(sh["row0"]), int(sh["rows"])
@@ -476,7 +538,7 @@ def read_native_shards(dir_path: str, device: Optional[int] = None, coarse_dtype
                 m = min(_IO_CHUNK_ROWS, hi - s0)
                 f.seek(base_f + (s0 - r0) * d * 4)
                 xf = np.frombuffer(f.read(m * d * 4), dtype=np.float32).reshape(m, d)
-                if raw and fdc == index.coarse_dim:
+                if raw and fdc == index.coarse_dim and fct == want_code:     # the FILE's own dtype code, not only the manifest's word
                     f.seek(base_c + (s0 - r0) * fdc * 2)
                     xc = np.frombuffer(f.read(m * fdc * 2), dtype=np.uint16).reshape(m, fdc)
                     index.add_raw(xf, xc, np.array([b0, b1], np.float32))

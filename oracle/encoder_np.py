@@ -190,6 +190,29 @@ def synth_weights(H=1024, L=24, FF=4096, vocab=30522, max_pos=512, seed=0, nontr
     return out
 
 
+def synth_weights_outlier(H=1024, L=24, FF=4096, vocab=30522, max_pos=512, seed=7, n_outlier=6, gamma_lo=30.0, gamma_hi=60.0):
+    """``synth_weights`` plus the statistics real BERT-family checkpoints show and N(0, 0.02) weights do not: a handful of
+    "outlier" hidden channels, the same in every layer, whose LayerNorm gamma is 30-60x the others (either sign) with an O(1) beta,
+    word / position embedding columns 8x larger in those channels, and biases an order of magnitude larger than the benign recipe's
+    (N(0, 0.2) for the linear layers).  The LayerNorm outputs then carry +-30...+-150 in those channels against O(1) elsewhere, which is the
+    regime where 16-bit GEMM operands and a 16-bit residual stream lose the most.  Seeded; regenerated on both sides, never stored."""
+    out = synth_weights(H, L, FF, vocab, max_pos, seed=seed, nontrivial=True)
+    rng = np.random.Generator(np.random.PCG64(seed + 10_000))
+    ch = np.sort(rng.choice(H, size=n_outlier, replace=False))
+    for name in list(out):
+        w = out[name]
+        if name.endswith("LayerNorm.weight"):
+            w[ch] = rng.uniform(gamma_lo, gamma_hi, size=n_outlier) * rng.choice([-1.0, 1.0], size=n_outlier)
+        elif name.endswith("LayerNorm.bias"):
+            w[ch] = rng.standard_normal(n_outlier)
+        elif name.endswith(".bias"):
+            w *= 10.0
+        elif name in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"):
+            w[:, ch] *= 8.0
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out
+
+
 def synth_tokens(n: int, S: int, seed: int, ragged: bool = False, vocab_lo=1000, vocab_hi=30000, min_len=16):
     """ids uniform in [vocab_lo, vocab_hi), ids[:,0]=101, last real token 102,
     right-padded with 0; lengths fixed S, or ragged clip(N(0.86 S, 0.2 S), min_len, S)."""

@@ -15,6 +15,7 @@ What is captured:
   G6  InBatchRetriever.forward single process (loss, scores)                        retrievers.py:133-150
   G7  E5Collator / BGECollator on a synthetic WordPiece vocab                       collators.py:59-89,132-156
   G8  DenseRetriever.calculate_*_embeddings batching                                retrievers.py:194-232
+  G10 E5Encoder / BGEEncoder at the full shape: S = 256 / 512, B = 64, left padding, OUTLIER-channel weights (outputs only)
 
 ``retriever/retrievers.py`` imports ``retriever/index.py`` which imports ``faiss`` at module scope
 (index.py:6,12-15).  faiss is not installed and cannot be: an EMPTY placeholder module (three attribute
@@ -35,7 +36,7 @@ REF = "/root/reference"
 if REF not in sys.path:
     sys.path.insert(1, REF)
 
-from oracle.encoder_np import synth_tokens, synth_weights  # noqa: E402
+from oracle.encoder_np import synth_tokens, synth_weights, synth_weights_outlier  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -45,13 +46,13 @@ from transformers import BertConfig  # noqa: E402
 from retriever.encoders import BGEEncoder, E5Encoder, average_pool  # noqa: E402
 
 
-def build(cls, cfgd, seed):
+def build(cls, cfgd, seed, weights=None):
     cfg = BertConfig(vocab_size=cfgd["vocab"], hidden_size=cfgd["H"], num_hidden_layers=cfgd["L"],
                      num_attention_heads=cfgd["heads"], intermediate_size=cfgd["FF"],
                      max_position_embeddings=cfgd["max_pos"], type_vocab_size=2, layer_norm_eps=1e-12,
                      hidden_act="gelu")
     m = cls(cfg, add_pooling_layer=False).eval()
-    w = synth_weights(cfgd["H"], cfgd["L"], cfgd["FF"], cfgd["vocab"], cfgd["max_pos"], seed=seed)
+    w = weights if weights is not None else synth_weights(cfgd["H"], cfgd["L"], cfgd["FF"], cfgd["vocab"], cfgd["max_pos"], seed=seed)
     missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
     assert not unexpected, unexpected
     assert all("position_ids" in k or "pooler" in k for k in missing), missing
@@ -111,6 +112,39 @@ def g2():
     print("G2 done")
 
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import g10_spec  # noqa: E402  (tables of weights / cases / token layouts shared with tests/test_gpu_encoder.py)
+
+
+def g10():
+    """Full e5-large / bge-large shape beyond G2: S = 256 / 512, a 64-sequence batch, left padding, and weights with OUTLIER channels
+    (oracle.encoder_np.synth_weights_outlier: LayerNorm gamma 8-16x / 30-60x in six hidden channels, matching embedding columns, large biases)
+    — the regime where 16-bit operands / a 16-bit residual stream lose the most.  Outputs + per-case hidden-state magnitudes only."""
+    cfgd = dict(g10_spec.CFG)
+    out = {"cfg": np.array([cfgd[k] for k in ("H", "L", "heads", "FF", "vocab", "max_pos")])}
+    for wname in g10_spec.WEIGHTS:
+        w = g10_spec.weights(wname)
+        for cls, tag in ((E5Encoder, "e5"), (BGEEncoder, "bge")):
+            m = build(cls, cfgd, None, weights=w)
+            for ci, (B, S, layout, seed) in enumerate(g10_spec.CASES[wname][tag]):
+                ids, mask = g10_spec.tokens(B, S, layout, seed)
+                from transformers import BertModel
+                with torch.no_grad():
+                    o = m(torch.from_numpy(ids), torch.from_numpy(mask))
+                    hs = BertModel.forward(m, input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                                           output_hidden_states=True, return_dict=True).hidden_states if ci == 0 else None
+                key = f"{wname}.{tag}.c{ci}"
+                out[key + ".out"] = o.numpy()
+                if hs is not None:          # statistics of the residual stream of the first sequence: documents how hard the recipe is
+                    out[key + ".absmax"] = np.array([float(h[0].abs().max()) for h in hs], np.float32)
+                    out[key + ".absmed"] = np.array([float(h[0].abs().median()) for h in hs], np.float32)
+                print("G10", key, (B, S, layout), "done", flush=True)
+            del m
+        del w
+    np.savez_compressed(os.path.join(OUT, "g10_encoder_large_ext.npz"), **out)
+    print("G10 done")
+
+
 def g3():
     rng = np.random.Generator(np.random.PCG64(3))
     lh = rng.standard_normal((4, 6, 16)).astype(np.float32)
@@ -149,14 +183,14 @@ def _synthetic_vocab():
 def g4_to_g8():
     rr = _import_retrievers()
     from dataset.collators import BGECollator, E5Collator
-    from transformers import BertTokenizerFast
+    from kirag_amd.bench_support import wordpiece_tokenizer
     cfgd = dict(TINY["t128"]); vocab = _synthetic_vocab(); cfgd["vocab"] = len(vocab)
     out = {"vocab": np.array(vocab), "cfg": np.array([cfgd[k] for k in ("H", "L", "heads", "FF", "vocab", "max_pos")]),
            "weight_seed": np.array(21)}
     with tempfile.TemporaryDirectory() as td:
         with open(os.path.join(td, "vocab.txt"), "w") as f:
             f.write("\n".join(vocab) + "\n")
-        tok = BertTokenizerFast(vocab_file=os.path.join(td, "vocab.txt"), do_lower_case=True)
+        tok = wordpiece_tokenizer(os.path.join(td, "vocab.txt"))
         _save_tiny_model(E5Encoder, cfgd, 21, td)
         ret = rr.InBatchRetriever("E5Retriever", td, temperature=0.01).eval()
         # G4
@@ -214,3 +248,4 @@ if __name__ == "__main__":
     if "g3" in which: g3()
     if "g48" in which: g4_to_g8()
     if "g2" in which: g2()
+    if "g10" in which: g10()

@@ -112,12 +112,12 @@ def test_pool_map_tokenizer_worker_processes_keep_order_and_match_in_process_col
     import numpy as np
     import pytest
     import torch
-    from transformers import BertTokenizerFast
+    from kirag_amd.bench_support import wordpiece_tokenizer
     from kirag_amd import compute_corpus_embeddings as CC
     from kirag_amd.collators import E5Collator
     with open(tmp_path / "vocab.txt", "w") as f:
         f.write("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "passage", ":", "hello", "world", "foo", "bar", "##s"]) + "\n")
-    tok = BertTokenizerFast(vocab_file=str(tmp_path / "vocab.txt"), do_lower_case=True)
+    tok = wordpiece_tokenizer(str(tmp_path / "vocab.txt"))
     col = E5Collator(tokenizer=tok, query_maxlength=16, doc_maxlength=12)
     texts = [" ".join(np.random.default_rng(i).choice(["hello", "world", "foo", "bars", "bar"], 1 + i % 14)) for i in range(103)]
 

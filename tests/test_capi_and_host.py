@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.kr_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.kr_abi_version() == _lib.ABI_VERSION == 3
 
 
 @pytest.mark.skipif(not NO_GPU, reason="checks the no-GPU failure mode")
@@ -107,13 +107,13 @@ def _tiny_model_dir(td, golden):
 
 
 def test_collators_match_reference_golden(golden):
-    from transformers import BertTokenizerFast
+    from kirag_amd.bench_support import wordpiece_tokenizer
     from kirag_amd.collators import COLLATOR_MAP, BGECollator, E5Collator
     g = golden("g4_g8_retriever.npz")
     with tempfile.TemporaryDirectory() as td:
         with open(os.path.join(td, "vocab.txt"), "w") as f:
             f.write("\n".join(str(v) for v in g["vocab"]) + "\n")
-        tok = BertTokenizerFast(vocab_file=os.path.join(td, "vocab.txt"), do_lower_case=True)
+        tok = wordpiece_tokenizer(os.path.join(td, "vocab.txt"))
     queries = [str(v) for v in g["g7.queries"]]; docs = [str(v) for v in g["g7.docs"]]
     for nm, col in (("e5", E5Collator(tok, 16, 24)), ("bge", BGECollator(tok, 24, 24))):
         qa, da, q8 = col.encode_query(queries), col.encode_doc(docs), col.encode_query(queries, max_length=8)

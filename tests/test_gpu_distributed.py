@@ -114,6 +114,24 @@ def _worker_indexer(rank, world, port, folder, ret):
                     assert [str(full.index_id_to_db_id[j]) for j in i1[r]] == eids and np.array_equal(s1[r].view(np.uint32), np.asarray(esc).view(np.uint32))
             third = read_native_shards(nat, device=0, row_range=(1, 3))            # rank 1 of 3: rows [1001, 2002) straddle the two files
             assert third.row_offset == 1001 and third.ntotal == 1001 and np.array_equal(third.reconstruct_n(0, 1001), x[1001:2002])
+        # streamed build in which ONE rank's share is empty: sync_shards' dirty decision must be collective, otherwise rank 1 returns
+        # early while rank 0 waits in the gather.  Rank 0 indexes everything, rank 1 nothing; both search.
+        sh4 = ShardedIndexer(64)
+        if rank == 0:
+            sh4.index_data([str(v) for v in full.index_id_to_db_id], x)
+        got4 = sh4.search_knn(q, 25, verbose=False)
+        assert sh4.ntotal_global == 3001 and sh4.index.ntotal == (3001 if rank == 0 else 0)
+        for (ids, sc), (eids, esc) in zip(got4, expected):
+            assert ids == eids and np.array_equal(np.asarray(sc).view(np.uint32), np.asarray(esc).view(np.uint32))
+        got4b = sh4.search_knn(q[:3], 5, verbose=False)              # nothing dirty on any rank: no gather, same answer
+        assert [ids for ids, _ in got4b] == [eids[:5] for eids, _ in expected[:3]]
+        # a directory rewritten with the reference-format files must not load the stale native shards next to them
+        if rank == 0:
+            other = Indexer(64); other.index_data([str(7 * i) for i in range(500)], x[:500]); other.serialize(nat)
+            assert not os.path.exists(os.path.join(nat, "kirag_shards.json"))
+        dist.barrier()
+        sh5 = ShardedIndexer(64); sh5.deserialize_from(nat)
+        assert sh5.ntotal_global == 500 and sh5.index.ntotal == 250
         ret[rank] = "ok"
     except Exception:
         import traceback

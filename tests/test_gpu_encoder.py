@@ -97,6 +97,57 @@ def test_g2_full_size_e5_and_bge(golden, residual_lo, monkeypatch):
     assert np.abs(s_hip - s_ref).max() <= 1e-3, float(np.abs(s_hip - s_ref).max())
 
 
+def _g10_spec():
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("g10_spec", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_spec.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+G10_RESULTS = {}
+
+
+@pytest.mark.parametrize("residual_lo", ["0", "1"])
+@pytest.mark.parametrize("wname", ["benign", "out16", "out60"])
+def test_g10_full_size_long_sequences_big_batch_left_padding_and_outlier_weights(golden, wname, residual_lo, monkeypatch):
+    """Golden set G10 (generated by importing the reference's E5Encoder / BGEEncoder, tests/golden/make_golden.py g10): the full 24-layer shape at
+    S = 256 / 512 (the reference's doc_maxlength default, compute_corpus_embeddings.py:32-33), a 64-sequence batch, left padding — and weights with
+    OUTLIER channels (six hidden channels with LayerNorm gamma 8-16x / 30-60x the rest, 8x embedding columns, 10x biases: residual-stream magnitudes
+    up to ~400 / ~1600 against a median of 0.34, i.e. harsher than real e5 / bge checkpoints' two orders of magnitude).  Both residual-stream modes
+    run; the bars are north_star's: cosine to the reference >= 1 - 5e-5 and query x passage scores within 1e-3."""
+    monkeypatch.setenv("KIRAG_AMD_RESIDUAL_LO", residual_lo)
+    spec = _g10_spec()
+    g = golden("g10_encoder_large_ext.npz")
+    cfg = _cfg(g["cfg"])
+    h = _hip(cfg, spec.weights(wname))
+    outs, refs = {}, {}
+    worst_err, worst_cos = 0.0, 0.0
+    for tag, pool in (("e5", 0), ("bge", 1)):
+        for ci, (B, S, layout, seed) in enumerate(spec.CASES[wname][tag]):
+            ids, mask = spec.tokens(B, S, layout, seed)
+            key = f"{wname}.{tag}.c{ci}"
+            out = h.forward_np(ids, mask, pool)
+            ref = g[key + ".out"]
+            assert out.shape == ref.shape and np.isfinite(out).all(), key
+            cos = (out * ref).sum(1) / (np.linalg.norm(out, axis=1) * np.linalg.norm(ref, axis=1))
+            err = float(np.abs(out - ref).max())
+            worst_err = max(worst_err, err); worst_cos = max(worst_cos, float((1 - cos).max()))
+            print(f"[{key} B{B} S{S} {layout} lo={residual_lo}] max abs err {err:.2e}  1-cos {float((1 - cos).max()):.2e}")
+            np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
+            outs[key] = out; refs[key] = ref
+    # every e5 case against every other e5 case as (query, passage) sets: |q.d - reference q.d| <= 1e-3   (north_star)
+    keys = [k for k in outs if ".e5." in k]
+    worst_score = 0.0
+    for a in keys:
+        for b in keys:
+            worst_score = max(worst_score, float(np.abs(outs[a] @ outs[b].T - refs[a] @ refs[b].T).max()))
+    print(f"[{wname} lo={residual_lo}] worst |q.d - ref| = {worst_score:.2e}, worst abs err {worst_err:.2e}, worst 1-cos {worst_cos:.2e}")
+    G10_RESULTS[(wname, residual_lo)] = (worst_score, worst_err, worst_cos)
+    assert worst_score <= 1e-3, worst_score                    # north_star's tolerance
+    assert worst_cos <= 5e-5, worst_cos
+    assert worst_err <= 3e-3, worst_err
+
+
 def test_batch_invariance_and_padding_layouts(golden):
     """Same sequences alone / in a batch / left-padded / with interior mask holes give the oracle's answer."""
     g = golden("g1_encoder_tiny.npz")

@@ -162,3 +162,107 @@ def test_large_index_destroyed_and_recreated_sees_its_own_rows():
         s300, i300 = ix.search(x[1000:1300].clone(), 1)
         assert np.array_equal(i300[:, 0], np.arange(1000, 1300))
         assert np.array_equal(ix.reconstruct_n(n - 5, 5), x[n - 5:].cpu().numpy())
+
+
+def test_adds_on_a_side_stream_then_grow_and_read_back():
+    """kr_index_add from a device source only records an event; grow() (blocking copies on the NULL stream), reconstruct_n, coarse_rows and
+    bounds() must wait for it even when the adds were enqueued on a non-blocking side stream — otherwise a second add that grows copies rows whose
+    quantisation kernel has not run, and the reads return stale bytes."""
+    from kirag_amd.retriever.index import FlatIPIndex
+    d = 256
+    side = torch.cuda.Stream()
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    x1 = torch.nn.functional.normalize(torch.randn(30_000, d, generator=g, device="cuda"), dim=1)
+    x2 = torch.nn.functional.normalize(torch.randn(90_000, d, generator=g, device="cuda"), dim=1)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        ix = FlatIPIndex(d)
+        with torch.cuda.stream(side):
+            big = torch.empty(64 << 20, device="cuda").normal_()     # keeps `side` busy so that the adds below are still pending when grow() runs
+            for _ in range(4):
+                big = big * 1.0001 + 1.0
+            ix.add(x1)                                               # asynchronous: event only
+            ix.add(x2)                                               # grows (copy-on-grow of the 30k rows just enqueued)
+            rows = ix.reconstruct_n(0, 30_000)                       # read back on the default stream argument (None)
+            tail = ix.reconstruct_n(30_000, 90_000)
+            b = ix.bounds()
+            c = ix.coarse_rows(29_990, 20)
+        assert np.array_equal(rows, x1.cpu().numpy()) and np.array_equal(tail, x2.cpu().numpy())
+        ref = FlatIPIndex(d); ref.add(torch.cat([x1, x2]))
+        assert np.array_equal(b, ref.bounds()) and np.array_equal(c, ref.coarse_rows(29_990, 20))
+        q = torch.cat([x1[:5], x2[-5:]]).clone()
+        s, i = ix.search(q, 3)
+        assert i[:, 0].tolist() == [0, 1, 2, 3, 4, 119_995, 119_996, 119_997, 119_998, 119_999]
+        del ix, ref, big
+
+
+def test_search_async_then_finish_equals_blocking_search():
+    """kr_index_search_async + kr_index_search_finish: pass 1 of EVERY block is enqueued without a host round trip; finish() re-answers the queries pass 1
+    flags (here: a cluster of near-duplicate rows below the bf16 resolution in the second and third 1024-query blocks, which also exercises the
+    workspace restore of multi-block calls) — bit-identical to the blocking search and to the oracle."""
+    from kirag_amd.retriever.index import FlatIPIndex
+    rng = np.random.default_rng(8)
+    n, d, k = 30_000, 128, 10
+    x = rng.standard_normal((n, d)).astype(np.float32); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    base = x[77].copy()
+    for j in range(400):                                             # 400 rows within ~1e-5 of one direction: pass 1 cannot separate them
+        v = base + 1e-5 * rng.standard_normal(d).astype(np.float32); x[1000 + 50 * j] = v / np.linalg.norm(v)
+    q = x[rng.choice(n, 2500)] + 0.05 * rng.standard_normal((2500, d)).astype(np.float32)
+    q[1500] = base; q[1501] = base * 0.999 + 1e-6; q[2300] = x[1000]     # queries aimed at the cluster
+    q = np.ascontiguousarray(q / np.linalg.norm(q, axis=1, keepdims=True), dtype=np.float32)
+    ix = FlatIPIndex(d); ix.add(x)
+    s_ref, i_ref = ix.search(q, k)
+    st0 = ix.stats(reset=True)
+    so, io = S.search_canonical(q, x, k)
+    assert np.array_equal(i_ref, io) and np.array_equal(s_ref.view(np.uint32), so.view(np.uint32))
+    qd = torch.from_numpy(q).cuda()
+    sc = torch.empty((2500, k), dtype=torch.float32, device="cuda"); rows = torch.empty((2500, k), dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ix.search_async(qd, k, sc, rows)
+        ix.finish()
+        side.synchronize()
+    st = ix.stats()
+    assert st["queries"] == 2500 and st["fallback"] >= 3 and st["fallback"] == st0["fallback"], (st, st0)
+    assert np.array_equal(rows.cpu().numpy(), io) and np.array_equal(sc.cpu().numpy().view(np.uint32), so.view(np.uint32))
+    # a second asynchronous search issued while one is pending finishes the first one; add() does too
+    ix.search_async(qd[:100].contiguous(), k, sc[:100], rows[:100])
+    ix.add(x[:10])
+    assert ix.ntotal == n + 10
+
+
+def test_address_budget_fallback_and_move_to_a_larger_reservation():
+    """The large-index path reserves max(16 GiB, 8 x rows) of virtual addresses per index and never reuses a retired range.  (a) once the
+    process-wide budget of retired addresses is spent (test hook), a new large index falls back to hipMalloc + copy-on-grow and still works;
+    (b) an index that outgrows its reservation (test hook: 512 MiB minimum) moves ONCE into a larger one with every row intact."""
+    from kirag_amd import _lib
+    from kirag_amd.retriever.index import FlatIPIndex
+    lib = _lib.load()
+    d = 1024
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    x = torch.nn.functional.normalize(torch.randn(60_000, d, generator=g, device="cuda"), dim=1)      # 60k rows x 6 KiB = 352 MiB >= 256 MiB
+    try:
+        _lib.check(lib.kr_set_option(b"debug_va_retired_tib", 48))
+        ix = FlatIPIndex(d); ix.add(x)
+        assert ix.stats()["grow_mode"] == 0 and ix.stats()["va_retired_bytes"] >= 48 << 40
+        ix.add(x[:20_000])                                           # copy-on-grow
+        s, i = ix.search(x[:4].clone(), 2)
+        assert i[:, 0].tolist() == [0, 1, 2, 3] and np.array_equal(ix.reconstruct_n(60_000, 5), x[:5].cpu().numpy())
+        del ix
+    finally:
+        _lib.check(lib.kr_set_option(b"debug_va_retired_tib", 0))
+    try:
+        _lib.check(lib.kr_set_option(b"debug_vmm_min_reserve_mib", 512))
+        ix = FlatIPIndex(d); ix.add(x)                               # reservation: max(512 MiB, 8 x 60k rows) = 480k rows
+        assert ix.stats()["grow_mode"] == 1
+        retired0 = ix.stats()["va_retired_bytes"]
+        for rep in range(8):                                         # 60k + 8 x 60k = 540k rows > 480k: one move on the way
+            ix.add(x)
+        assert ix.stats()["grow_mode"] == 1 and ix.stats()["va_retired_bytes"] > retired0
+        for rep in (0, 3, 8):
+            assert np.array_equal(ix.reconstruct_n(rep * 60_000 + 100, 50), x[100:150].cpu().numpy())
+        s, i = ix.search(x[:4].clone(), 9)
+        assert sorted(i[0].tolist()) == [60_000 * r for r in range(9)]
+        del ix
+    finally:
+        _lib.check(lib.kr_set_option(b"debug_vmm_min_reserve_mib", 0))

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _setup(td, golden):
-    from transformers import BertConfig, BertTokenizerFast
+    from transformers import BertConfig
+    from kirag_amd.bench_support import wordpiece_tokenizer
     from kirag_amd.retriever.encoders import E5Encoder
     g = golden("g4_g8_retriever.npz")
     H, L, heads, FF, vocab, max_pos = [int(v) for v in g["cfg"]]
@@ -28,7 +29,7 @@ def _setup(td, golden):
     m.save_pretrained(td)
     with open(os.path.join(td, "vocab.txt"), "w") as f:
         f.write("\n".join(str(v) for v in g["vocab"]) + "\n")
-    tok = BertTokenizerFast(vocab_file=os.path.join(td, "vocab.txt"), do_lower_case=True)
+    tok = wordpiece_tokenizer(os.path.join(td, "vocab.txt"))
     return g, tok, w, heads
 
 
@@ -222,7 +223,8 @@ def test_config4_flow_streamed_bge_encode_into_resident_shard_then_search(golden
     same passages (batch invariance) == the numpy oracle's BGE forward (<= 4e-3), search results == the C oracle on the stored rows, native
     shard round trip; both tokenisation feeds (prefetch thread, worker processes) give identical rows."""
     import time
-    from transformers import BertConfig, BertTokenizerFast
+    from transformers import BertConfig
+    from kirag_amd.bench_support import wordpiece_tokenizer
     from kirag_amd import compute_corpus_embeddings as CC
     from kirag_amd.collators import BGECollator
     from kirag_amd.retriever.encoders import BGEEncoder
@@ -238,7 +240,7 @@ def test_config4_flow_streamed_bge_encode_into_resident_shard_then_search(golden
         m.save_pretrained(td)
         with open(os.path.join(td, "vocab.txt"), "w") as f:
             f.write("\n".join(str(v) for v in g["vocab"]) + "\n")
-        tok = BertTokenizerFast(vocab_file=os.path.join(td, "vocab.txt"), do_lower_case=True)
+        tok = wordpiece_tokenizer(os.path.join(td, "vocab.txt"))
         ret = InBatchRetriever("BGERetriever", td, temperature=0.01)
         col = BGECollator(tokenizer=tok, query_maxlength=32, doc_maxlength=32)
         rng = np.random.default_rng(5)

@@ -33,8 +33,8 @@ texts = [passage() for _ in range(n)]
 
 def tok_rate(parallel, label):
     os.environ["TOKENIZERS_PARALLELISM"] = "true" if parallel else "false"
-    from transformers import BertTokenizerFast
-    tok = BertTokenizerFast(vocab_file=os.path.join(td, "vocab.txt"), do_lower_case=True)
+    from kirag_amd.bench_support import wordpiece_tokenizer
+    tok = wordpiece_tokenizer(os.path.join(td, "vocab.txt"))
     tok(["passage: " + t for t in texts[:512]], max_length=128, padding=True, truncation=True, return_tensors="pt")
     t0 = time.perf_counter(); ntok = 0
     for s in range(0, n, 512):
