@@ -44,8 +44,12 @@ def parse():
     ap.add_argument("--passage-tokens", type=int, default=128)
     ap.add_argument("--coarse-dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-encoder", action="store_true", help="search-only step (query vectors pre-computed)")
+    ap.add_argument("--encoder-dtype", default=None, choices=["bf16", "f16"], help="16-bit operand type of the encoder (default: the library's, f16)")
+    ap.add_argument("--residual-lo", default=None, type=int, choices=[0, 1], help="encoder residual stream with / without its low half (default: the library's, 1)")
+    ap.add_argument("--sync-search", action="store_true", help="one GPU: use the blocking kr_index_search per step instead of search_async + finish")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000, help="corpus rows of the CPU search baseline (BASELINE.md: the 1M point)")
+    ap.add_argument("--cpu-full-corpus", action="store_true", help="CPU search baseline over ALL corpus rows (the 5M point: ~20 GB of host memory, minutes)")
     ap.add_argument("--cpu-sample-queries", type=int, default=32)
     ap.add_argument("--corpus-dist", default="gaussian", choices=["gaussian", "e5like", "mixed", "neardup"],
                     help="synthetic corpus: iid Gaussian directions (SURVEY 8d) or e5like (shared mean direction + anisotropic remainder: scores in a "
@@ -73,32 +77,46 @@ def launch_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(args, q_host, with_encoder, dist_kind):
-    """faiss.IndexFlatIP stand-in (oracle.search_np.search_sgemm: fp32 BLAS sgemm + argpartition, 1024-query blocks as
-    retriever/index.py:39-47) on a bounded row sample of the same synthetic corpus distribution, scaled linearly to the full corpus, and the
-    HF BertModel fp32 query encoder (oracle/encoder_torch.py).  Protocol: one warm-up, median of 5 timed runs each."""
+def cpu_baseline(args, q_host, with_encoder, dist_kind, index):
+    """faiss.IndexFlatIP stand-in (oracle.search_np.search_sgemm: fp32 BLAS sgemm + argpartition, 1024-query blocks as retriever/index.py:39-47)
+    timed on the REAL rows of the benchmark corpus (1M and 5M x 1024 fp32, 1000 queries, top-100): by default the first
+    1,000,000 rows of the resident index are copied to the host and searched (one warm-up, median of 3 passes of ~4 s on this box class); the 5M-row
+    figure reported next to it is that pass time x (total_rows / 1M) unless --cpu-full-corpus measures it directly (20 GB of host rows, ~2 minutes;
+    the committed profiles/r03/cpu_baseline_5M.json is such a run).  Encoder: the HF BertModel fp32 query loop (oracle/encoder_torch.py),
+    one warm-up, median of 5."""
     import torch
     from oracle import search_np as S
-    from kirag_amd.bench_support import CorpusDist
-    rows = min(args.cpu_sample_rows, args.total_rows)
-    cd = CorpusDist(dist_kind, args.dim, torch.device("cpu"))
-    g = torch.Generator(); g.manual_seed(3)
-    xs = cd.rows(rows, g).numpy()
+    rows = args.total_rows if args.cpu_full_corpus else min(args.cpu_sample_rows, args.total_rows)
+    xs = np.empty((rows, args.dim), np.float32)
+    for s0 in range(0, rows, 250_000):                                 # the same fp32 rows the GPU path searches
+        m = min(250_000, rows - s0)
+        xs[s0:s0 + m] = index.reconstruct_n(s0, m)
+    reps = 3
     S.search_sgemm(q_host, xs, args.topk)                             # warm-up (BLAS threads, page faults)
     ts = []
-    for _ in range(5):
+    for _ in range(reps):
         t0 = time.perf_counter()
         S.search_sgemm(q_host, xs, args.topk)
         ts.append(time.perf_counter() - t0)
     ts.sort()
-    dt = ts[2]
+    dt = ts[reps // 2]
     scale = args.total_rows / rows
     search_qps = len(q_host) / (dt * scale)
     out = {"unit": "queries/s", "cores": int(torch.get_num_threads()), "kind": "port", "nproc": os.cpu_count(),
-           "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "protocol": "1 warm-up, median of 5",
+           "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "protocol": f"1 warm-up, median of {reps} (search) / 5 (encode)",
            "search_only_qps": search_qps, "search_runs_s": [round(t, 4) for t in ts],
-           "sample": f"search: {len(q_host)} queries x {rows} of {args.total_rows} rows ({dist_kind}) fp32 sgemm+argpartition top-{args.topk}, "
-                     f"median {dt:.3f}s per pass, time scaled x{scale:.0f} to the full corpus"}
+           "search_points": {f"{rows}_rows_measured_qps": len(q_host) / dt},
+           "sample": f"search: {len(q_host)} queries x the first {rows} of the {args.total_rows} corpus rows ({dist_kind}, copied from the resident index) fp32 "
+                     f"sgemm+argpartition top-{args.topk}, median {dt:.3f}s per pass"
+                     + (f", time scaled x{scale:g} to the full corpus" if scale != 1 else " (the full corpus: measured, not scaled)")}
+    del xs
+    import glob
+    for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "cpu_baseline_5M.json")), reverse=True):   # a committed full-corpus measurement
+        with open(cand) as f:
+            cj = json.load(f)
+        out["search_points"]["5000000_rows_measured_qps_committed_run"] = {"qps": cj.get("search_only_qps"), "source": os.path.relpath(cand, REPO),
+                                                                            "cores": cj.get("cores")}
+        break
     if with_encoder:
         from oracle import encoder_torch as ET
         enc_qps, enc_dt, enc_ts = ET.time_encode(args.cpu_sample_queries, args.query_tokens, batch=8, repeats=5)
@@ -196,12 +214,35 @@ def main():
     q_lo, q_hi = (rank * nq) // world, ((rank + 1) * nq) // world      # this rank's slice of the query batch
     if not args.no_encoder:
         from kirag_amd import bench_support as BS
-        encoder = BS.make_hip_encoder(dev)
+        encoder = BS.make_hip_encoder(dev, operand_dtype=args.encoder_dtype, residual_lo=None if args.residual_lo is None else bool(args.residual_lo))
         tok_ids, tok_mask = BS.synthetic_tokens(dev, nq, args.query_tokens, seed=2)
         pas_ids, pas_mask = BS.synthetic_tokens(dev, args.passages, args.passage_tokens, seed=1)
     searcher = ShardedSearcher(index, row_offset=row0, world=world)
     q_all = torch.empty((nq, d), dtype=torch.float32, device=dev)
     counts = [((r + 1) * nq) // world - (r * nq) // world for r in range(world)]
+
+    # one GPU: the step is enqueue-only (encoder forward -> kr_index_search_async into device buffers -> D2H of the results into pinned memory);
+    # the host finishes step i (certificate flags; passes 2 / 3 if any query was flagged) after it has enqueued the encode of step i + 1
+    res_s = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(2)]
+    res_i = [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(2)]
+    pin_s = [torch.empty((nq, k), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+    pin_i = [torch.empty((nq, k), dtype=torch.int64, pin_memory=True) for _ in range(2)]
+    inflight, coarse_log = [], []
+
+    def drain():
+        if inflight:
+            j = inflight.pop()
+            index.finish()
+            coarse_log.append(index.stats()["last_coarse_ms"])                           # HIP events around the coarse rounds of the finished step
+            pin_s[j].copy_(res_s[j], non_blocking=True); pin_i[j].copy_(res_i[j], non_blocking=True)
+
+    def step_async(i):
+        qv = q_vec if encoder is None else encoder.forward(tok_ids, tok_mask, 0)       # [nq, d] fp32 on the device, enqueued
+        drain()
+        j = i & 1
+        index.search_async(qv, k, res_s[j], res_i[j])
+        inflight.append(j)
+        step_async.keep = qv                                                          # the queries stay alive until finish()
 
     def step():
         if encoder is None:
@@ -217,17 +258,28 @@ def main():
             qv = q_all
         return searcher.search(qv, k)
 
-    for _ in range(args.warmup):
-        step()
+    use_async = world == 1 and not args.sync_search
+    for i in range(args.warmup):
+        step_async(i) if use_async else step()
+    drain()
+    torch.cuda.synchronize()
     index.stats(reset=True)
     coarse_ms = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        coarse_ms.append(index.stats()["last_coarse_ms"])
+    coarse_log.clear()
+    for i in range(args.steps):
+        if use_async:
+            step_async(i)
+        else:
+            step()
+            coarse_ms.append(index.stats()["last_coarse_ms"])
+    if use_async:
+        drain()
+        coarse_ms = list(coarse_log)
+        assert len(coarse_ms) == args.steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -254,7 +306,7 @@ def main():
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
         te = float(te.item())
         fl = BS.encoder_flops(encoder.cfg, pas_mask.sum(1))
-        enc_info = {"passages_per_s": args.passages * world * args.steps / te, "batch": args.passages, "tokens": args.passage_tokens,
+        enc_info = {"operand_dtype": encoder.operand_dtype, "residual_lo": encoder.residual_lo, "passages_per_s": args.passages * world * args.steps / te, "batch": args.passages, "tokens": args.passage_tokens,
                     "tflops_per_gpu": fl * args.steps / te / 1e12, "frac_of_mfma_peak": fl * args.steps / te / PEAK_MFMA_DENSE_16BIT,
                     "algorithmic_gflop_per_passage": fl / args.passages / 1e9}
         # same batch with ragged lengths (clip(N(0.86 S, 0.2 S), 16, S)): the encoder packs attended tokens, padding costs no FLOPs
@@ -290,7 +342,8 @@ def main():
             "metric": f"queries/sec ({'encode + ' if encoder is not None else 'search only: '}exact top-{k} search), e5-large-v2 shape, {total / 1e6:g}M x {d} corpus",
             "value": nq * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": args.coarse_dtype + " MFMA coarse scan / fp64 exact re-rank",
+            "dtype": (f"encoder: {encoder.operand_dtype} MFMA operands, fp32 accumulate" + (" + residual low half" if encoder.residual_lo else "") + "; search: "
+                      if encoder is not None else "") + args.coarse_dtype + " MFMA coarse scan / fp64 exact re-rank",
             "data": "synthetic",
             "config": {"workload": f"BASELINE metric config: {total}x{d} {args.coarse_dtype}+fp32 corpus ({args.corpus_dist}) resident in HBM (row-sharded over "
                                    f"{world} GPU(s)), {nq}-query batch ({args.query_tokens} tokens) encoded then searched, brute-force top-{k}",
@@ -309,7 +362,7 @@ def main():
             "search_stats": {kk: st[kk] for kk in ("queries", "certified", "fallback", "fine", "exact", "overflow", "reranked_rows", "coarse_rounds", "fine_rounds", "marked_passes", "marked_rows")},
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
-            out["cpu_baseline"] = cpu_baseline(args, q_vec.cpu().numpy(), encoder is not None, args.corpus_dist)
+            out["cpu_baseline"] = cpu_baseline(args, q_vec.cpu().numpy(), encoder is not None, args.corpus_dist, index)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

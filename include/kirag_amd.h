@@ -154,7 +154,20 @@ typedef struct {
 #define KR_POOL_MEAN 0 /* E5: average_pool (encoders.py:56-58) then F.normalize */
 #define KR_POOL_CLS 1  /* BGE: last_hidden[:,0] (encoders.py:116) then F.normalize */
 
-int kr_encoder_create(const kr_bert_cfg* cfg, int device, kr_encoder** out);
+/* 16-bit type of the MFMA operands and of every stored activation (weights, residual stream, q / k / v, P, ctx, h); accumulation is fp32 and the
+ * LayerNorms run in fp32 either way.  f16 has 11 significand bits (|x| <= 65504), bf16 8: with outlier hidden channels (what real BERT-family
+ * checkpoints have) only f16 + the residual low half stays inside the 1e-3 score tolerance with margin (tests/golden G10). */
+#define KR_ENC_BF16 0
+#define KR_ENC_F16 1
+#define KR_ENC_DEFAULT_DTYPE KR_ENC_F16
+#define KR_ENC_DEFAULT_RESIDUAL_LO 1
+int kr_encoder_create(const kr_bert_cfg* cfg, int device, kr_encoder** out);   /* = kr_encoder_create_ex(cfg, device, -1, -1, out) */
+/* operand_dtype: KR_ENC_BF16 / KR_ENC_F16 / -1 = default (environment KIRAG_AMD_ENCODER_DTYPE=bf16|f16, else KR_ENC_DEFAULT_DTYPE);
+ * residual_lo: 1 = the residual stream between layers keeps a second 16-bit word (the remainder: 16+ significand bits together), 0 = one word,
+ * -1 = default (environment KIRAG_AMD_RESIDUAL_LO=0|1, else KR_ENC_DEFAULT_RESIDUAL_LO). */
+int kr_encoder_create_ex(const kr_bert_cfg* cfg, int device, int operand_dtype, int residual_lo, kr_encoder** out);
+int kr_encoder_operand_dtype(const kr_encoder* enc);   /* what the handle was created with */
+int kr_encoder_residual_lo(const kr_encoder* enc);
 void kr_encoder_destroy(kr_encoder* enc);
 /* one call per HF state_dict tensor of BertModel ("embeddings.word_embeddings.weight",
  * "encoder.layer.3.attention.self.query.bias", ...), fp32, numel checked; "pooler.*" / "*position_ids" ignored. */

@@ -61,6 +61,9 @@ SIGNATURES = {
     "kr_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "kr_topk_merge_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kr_encoder_create": (C.c_int, [C.POINTER(BertCfg), C.c_int, C.POINTER(C.c_void_p)]),
+    "kr_encoder_create_ex": (C.c_int, [C.POINTER(BertCfg), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "kr_encoder_operand_dtype": (C.c_int, [C.c_void_p]),
+    "kr_encoder_residual_lo": (C.c_int, [C.c_void_p]),
     "kr_encoder_destroy": (None, [C.c_void_p]),
     "kr_encoder_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "kr_encoder_finalize": (C.c_int, [C.c_void_p]),

@@ -41,10 +41,10 @@ def synthetic_state(cfg: SimpleNamespace, device, seed: int = 0):
         yield p + "output.LayerNorm.bias", torch.zeros(H, device=device)
 
 
-def make_hip_encoder(device, cfg_dict=None, seed: int = 0) -> HipBertForward:
+def make_hip_encoder(device, cfg_dict=None, seed: int = 0, operand_dtype=None, residual_lo=None) -> HipBertForward:
     cfg = SimpleNamespace(**(cfg_dict or E5_LARGE))
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    enc = HipBertForward(cfg, idx)
+    enc = HipBertForward(cfg, idx, operand_dtype=operand_dtype, residual_lo=residual_lo)
     enc.load_state(dict(synthetic_state(cfg, device, seed)))
     enc.cfg = cfg
     return enc

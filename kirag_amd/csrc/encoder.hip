@@ -28,7 +28,24 @@
 #include <mutex>
 #include <vector>
 
+// This file is compiled TWICE (kirag_amd/csrc/Makefile): once per 16-bit operand type of the MFMAs and of every stored activation —
+//   bf16 (8 significand bits, fp32 range)  and  f16 (11 significand bits, |x| <= 65504; -DKR_ENC_F16)
+// — into the namespaces kr::enc_bf16 / kr::enc_f16; encoder_api.hip holds the C entry points and picks one per handle (kr_encoder_create_ex).
+// Why both exist: DESIGN.md section 4.2 "operand precision" (weights with outlier channels need the 11 bits to stay within the 1e-3 score tolerance).
+#ifdef KR_ENC_BUILD_F16
+#define KR_ENC_NS enc_f16
+#else
+#define KR_ENC_NS enc_bf16
+#endif
+
 namespace kr {
+namespace KR_ENC_NS {
+
+#ifdef KR_ENC_BUILD_F16
+using ET = F16;
+#else
+using ET = BF16;
+#endif
 
 using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LDS, one block per CU: best main loop (long-K GEMMs)
 // Four main loops, one per launch size (launch_proj picks; all give bit-identical rows):
@@ -43,8 +60,8 @@ using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB ring
 template <class ShapeE, int STAGES, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_main(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb, int64_t N,
                                           int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
-    if constexpr (ShapeE::BM == 256 && ShapeE::BN == 256) gemm_nt_pingpong<BF16, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
-    else gemm_nt_stream<BF16, ShapeE, STAGES, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
+    if constexpr (ShapeE::BM == 256 && ShapeE::BN == 256) gemm_nt_pingpong<ET, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
+    else gemm_nt_stream<ET, ShapeE, STAGES, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
 }
 
 struct LayerW {
@@ -94,7 +111,7 @@ static void drop_graphs(Encoder* e) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ void k_f32_to_bf16(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = BF16::from_f32(src[i] * scale);
+    if (i < n) dst[i] = ET::from_f32(src[i] * scale);
 }
 __global__ void k_scale_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,7 +123,7 @@ __global__ void k_fold_vbias(const uint16_t* __restrict__ wo, const float* __res
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= H) return;
     float s = 0.f;
-    for (int j = 0; j < H; ++j) s += BF16::to_f32(wo[(int64_t)i * H + j]) * bv[j];
+    for (int j = 0; j < H; ++j) s += ET::to_f32(wo[(int64_t)i * H + j]) * bv[j];
     out[i] = bo[i] + s;
 }
 
@@ -202,9 +219,9 @@ __device__ __forceinline__ void ln_row_store(float4 (&v)[8], int H, int lane, co
             o.z = (v[j].z - mu) * rstd * gg.z + bb.z; o.w = (v[j].w - mu) * rstd * gg.w + bb.w;
             // o = hi + lo with hi = bf16(o), lo = bf16(o - hi): |o - (hi + lo)| <= 2^-18 |o|
             ushort4 ob, ol;
-            ob.x = BF16::from_f32(o.x); ob.y = BF16::from_f32(o.y); ob.z = BF16::from_f32(o.z); ob.w = BF16::from_f32(o.w);
-            ol.x = BF16::from_f32(o.x - BF16::to_f32(ob.x)); ol.y = BF16::from_f32(o.y - BF16::to_f32(ob.y));
-            ol.z = BF16::from_f32(o.z - BF16::to_f32(ob.z)); ol.w = BF16::from_f32(o.w - BF16::to_f32(ob.w));
+            ob.x = ET::from_f32(o.x); ob.y = ET::from_f32(o.y); ob.z = ET::from_f32(o.z); ob.w = ET::from_f32(o.w);
+            ol.x = ET::from_f32(o.x - ET::to_f32(ob.x)); ol.y = ET::from_f32(o.y - ET::to_f32(ob.y));
+            ol.z = ET::from_f32(o.z - ET::to_f32(ob.z)); ol.w = ET::from_f32(o.w - ET::to_f32(ob.w));
             *reinterpret_cast<ushort4*>(xb_row + i) = ob;
             if (xlo_row) *reinterpret_cast<ushort4*>(xlo_row + i) = ol;      // optional low half (kernel-uniform branch)
         }
@@ -241,11 +258,11 @@ __device__ __forceinline__ void ln_row_store_regs(float4 (&v)[NCH], int H, int l
             o.x = (v[j].x - mu) * rstd * gg.x + bb.x; o.y = (v[j].y - mu) * rstd * gg.y + bb.y;
             o.z = (v[j].z - mu) * rstd * gg.z + bb.z; o.w = (v[j].w - mu) * rstd * gg.w + bb.w;
             ushort4 ob, ol;
-            ob.x = BF16::from_f32(o.x); ob.y = BF16::from_f32(o.y); ob.z = BF16::from_f32(o.z); ob.w = BF16::from_f32(o.w);
+            ob.x = ET::from_f32(o.x); ob.y = ET::from_f32(o.y); ob.z = ET::from_f32(o.z); ob.w = ET::from_f32(o.w);
             *reinterpret_cast<ushort4*>(xb_row + i) = ob;
             if (xlo_row) {   // optional low half: o = hi + lo with lo = bf16(o - hi), |o - (hi + lo)| <= 2^-18 |o|
-                ol.x = BF16::from_f32(o.x - BF16::to_f32(ob.x)); ol.y = BF16::from_f32(o.y - BF16::to_f32(ob.y));
-                ol.z = BF16::from_f32(o.z - BF16::to_f32(ob.z)); ol.w = BF16::from_f32(o.w - BF16::to_f32(ob.w));
+                ol.x = ET::from_f32(o.x - ET::to_f32(ob.x)); ol.y = ET::from_f32(o.y - ET::to_f32(ob.y));
+                ol.z = ET::from_f32(o.z - ET::to_f32(ob.z)); ol.w = ET::from_f32(o.w - ET::to_f32(ob.w));
                 *reinterpret_cast<ushort4*>(xlo_row + i) = ol;
             }
         }
@@ -316,8 +333,8 @@ __global__ __launch_bounds__(256) void k_ln(const uint16_t* __restrict__ y, cons
         float4 v[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
-            v[j] = make_float4((BF16::to_f32(a[j].x) + yb[j].x) + (BF16::to_f32(rh[j].x) + BF16::to_f32(rl[j].x)), (BF16::to_f32(a[j].y) + yb[j].y) + (BF16::to_f32(rh[j].y) + BF16::to_f32(rl[j].y)),
-                               (BF16::to_f32(a[j].z) + yb[j].z) + (BF16::to_f32(rh[j].z) + BF16::to_f32(rl[j].z)), (BF16::to_f32(a[j].w) + yb[j].w) + (BF16::to_f32(rh[j].w) + BF16::to_f32(rl[j].w)));
+            v[j] = make_float4((ET::to_f32(a[j].x) + yb[j].x) + (ET::to_f32(rh[j].x) + ET::to_f32(rl[j].x)), (ET::to_f32(a[j].y) + yb[j].y) + (ET::to_f32(rh[j].y) + ET::to_f32(rl[j].y)),
+                               (ET::to_f32(a[j].z) + yb[j].z) + (ET::to_f32(rh[j].z) + ET::to_f32(rl[j].z)), (ET::to_f32(a[j].w) + yb[j].w) + (ET::to_f32(rh[j].w) + ET::to_f32(rl[j].w)));
         load_row(t + step);                                   // next row's loads in flight while this one is reduced and stored
         ln_row_store_regs<NCH>(v, H, lane, gg, bb, eps, xlo ? xlo + t * H : nullptr, xb + t * H);
     }
@@ -325,9 +342,29 @@ __global__ __launch_bounds__(256) void k_ln(const uint16_t* __restrict__ y, cons
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-// two floats -> packed bf16 pair (lo in bits 0..15): ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+// two floats -> packed 16-bit pair (lo in bits 0..15), round-to-nearest-even, NaN stays NaN: ONE v_cvt_pk_bf16_f32 / the f16 conversions of the target
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#ifdef KR_ENC_BUILD_F16
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2_t));
+#else
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
+#endif
+}
+// the two halves of a packed pair as fp32
+__device__ __forceinline__ float unpack_lo16(unsigned int w) {
+#ifdef KR_ENC_BUILD_F16
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+#else
+    return __builtin_bit_cast(float, w << 16);
+#endif
+}
+__device__ __forceinline__ float unpack_hi16(unsigned int w) {
+#ifdef KR_ENC_BUILD_F16
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+#else
+    return __builtin_bit_cast(float, w & 0xffff0000u);
+#endif
 }
 
 // k_ln with 16-byte accesses: a lane owns 8 consecutive elements per 512-element step (one global_load_dwordx4 per tensor and step instead of two
@@ -370,8 +407,8 @@ __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, co
             }
         }
     };
-    auto lo16 = [](unsigned int w) { return __builtin_bit_cast(float, w << 16); };
-    auto hi16 = [](unsigned int w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
+    auto lo16 = [](unsigned int w) { return unpack_lo16(w); };
+    auto hi16 = [](unsigned int w) { return unpack_hi16(w); };
     load_row(t);
     for (; t < T; t += step) {
         float v[NS][8];
@@ -529,7 +566,7 @@ __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char*
         for (int ni = 0; ni < Shape::TN; ++ni) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                *reinterpret_cast<uint16_t*>(stage + ((r & 3) + 8 * (r >> 2) + 4 * h) * 80 + c * 2) = BF16::from_f32(acc.v[mi][ni][r]);
+                *reinterpret_cast<uint16_t*>(stage + ((r & 3) + 8 * (r >> 2) + 4 * h) * 80 + c * 2) = ET::from_f32(acc.v[mi][ni][r]);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int fl = p * 16 + (acc.lane >> 2), ch = acc.lane & 3;
@@ -604,7 +641,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_proj_split(ProjArgs a) {
     const int T = *a.Tp;
     const int64_t tm_count = (T + 127) / 128, tn_count = (a.F + 127) / 128;
     char* stage = smem + SPLIT_RING * ShapeSplit::STAGE_BYTES + ((threadIdx.x >> 6) & 3) * EPI_STAGE_BYTES;
-    gemm_nt_split<BF16, true>(
+    gemm_nt_split<ET, true>(
         a.X, a.ldx, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             int64_t tm, tn;
@@ -623,7 +660,7 @@ __global__ __launch_bounds__(SKINNY_THREADS) void k_proj_skinny(ProjArgs a) {
     const int T = *a.Tp;
     const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
     if (m0 >= T) return;                                  // block-uniform, before any barrier
-    gemm_nt_skinny<BF16, RING, true>(a.X, a.ldx, T, m0, a.W, a.K, a.F, n0, a.K, smem, [&](AccTile<ShapeSkinny>& acc, int64_t t0, int64_t f0) {
+    gemm_nt_skinny<ET, RING, true>(a.X, a.ldx, T, m0, a.W, a.K, a.F, n0, a.K, smem, [&](AccTile<ShapeSkinny>& acc, int64_t t0, int64_t f0) {
         const int c = acc.lane & 31, h = acc.lane >> 5;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -633,7 +670,7 @@ __global__ __launch_bounds__(SKINNY_THREADS) void k_proj_skinny(ProjArgs a) {
                 const int region = (int)f0 / a.H;
                 if (region == 2) {                        // V^T [feature, token]; its bias lives in bo_eff
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) a.outT[(int64_t)(f - 2 * a.H + j) * a.ldT + t0 + c] = BF16::from_f32(v[j]);
+                    for (int j = 0; j < 4; ++j) a.outT[(int64_t)(f - 2 * a.H + j) * a.ldT + t0 + c] = ET::from_f32(v[j]);
                     continue;
                 }
                 v = v + *reinterpret_cast<const f32x4*>(a.bias + f);
@@ -788,7 +825,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const uint4 kf = *reinterpret_cast<const uint4*>(krow + (((2 * s + hf) ^ swz) << 4));
-                    st = BF16::mfma(kf, qf[s], st);
+                    st = ET::mfma(kf, qf[s], st);
                 }
             }
             // register r of this lane is key kc0 + k0 + (r&3) + 8 (r>>2) + 4 hf, query q0 + c
@@ -824,8 +861,8 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
                 const char* v1 = v0 + 32 * vpitch;
                 const uint2 a0 = *reinterpret_cast<const uint2*>(v0), a1 = *reinterpret_cast<const uint2*>(v0 + 16);
                 const uint2 b0 = *reinterpret_cast<const uint2*>(v1), b1 = *reinterpret_cast<const uint2*>(v1 + 16);
-                o0 = BF16::mfma(make_uint4(a0.x, a0.y, a1.x, a1.y), pf, o0);
-                o1 = BF16::mfma(make_uint4(b0.x, b0.y, b1.x, b1.y), pf, o1);
+                o0 = ET::mfma(make_uint4(a0.x, a0.y, a1.x, a1.y), pf, o0);
+                o1 = ET::mfma(make_uint4(b0.x, b0.y, b1.x, b1.y), pf, o1);
             }
         }
     }
@@ -884,8 +921,8 @@ __global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, c
             for (int j = 0; j < 8; ++j) {
                 const int i = lane * 4 + j * 256;
                 if (i < H && t + 4 * u < t_end) {
-                    acc[j].x += BF16::to_f32(hi[u][j].x) + BF16::to_f32(lo[u][j].x); acc[j].y += BF16::to_f32(hi[u][j].y) + BF16::to_f32(lo[u][j].y);
-                    acc[j].z += BF16::to_f32(hi[u][j].z) + BF16::to_f32(lo[u][j].z); acc[j].w += BF16::to_f32(hi[u][j].w) + BF16::to_f32(lo[u][j].w);
+                    acc[j].x += ET::to_f32(hi[u][j].x) + ET::to_f32(lo[u][j].x); acc[j].y += ET::to_f32(hi[u][j].y) + ET::to_f32(lo[u][j].y);
+                    acc[j].z += ET::to_f32(hi[u][j].z) + ET::to_f32(lo[u][j].z); acc[j].w += ET::to_f32(hi[u][j].w) + ET::to_f32(lo[u][j].w);
                 }
             }
     }
@@ -1120,13 +1157,12 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int nu
     return launch_proj_shape<ShapeSmall, 2>(epi, a, 2 * num_cu, device, st);
 }
 
-}  // namespace kr
+// ---------------------------------------------------------------------------------------------------------
+// entry points of this operand type (C linkage lives in encoder_api.hip, which dispatches on the handle's type)
+// ---------------------------------------------------------------------------------------------------------
+void enc_destroy(void* h);
 
-using namespace kr;
-
-extern "C" {
-
-int kr_encoder_create(const kr_bert_cfg* cfg, int device, kr_encoder** out) {
+int enc_create(const kr_bert_cfg* cfg, int device, int residual_lo, void** out) {
     if (!out || !cfg) return fail(KR_EINVAL, "NULL argument");
     *out = nullptr;
     if (cfg->hidden <= 0 || cfg->hidden % 128 != 0 || cfg->hidden > 2048) return fail(KR_EINVAL, "hidden=%d unsupported (multiple of 128, <= 2048)", cfg->hidden);
@@ -1136,7 +1172,7 @@ int kr_encoder_create(const kr_bert_cfg* cfg, int device, kr_encoder** out) {
     KR_TRY(select_device(device));
     Encoder* e = new Encoder();
     e->cfg = *cfg; e->device = device;
-    { const char* v = getenv("KIRAG_AMD_RESIDUAL_LO"); e->use_lo = v && atoi(v) != 0; }
+    e->use_lo = residual_lo != 0;
     { const char* v = getenv("KIRAG_AMD_GRAPH"); e->graphs_off = !(v && atoi(v) != 0); }   // opt-in: measured SLOWER than eager launches on ROCm 7.2 (see run_forward)
     { const char* v = getenv("KIRAG_AMD_HPAD"); e->h_pad = v ? (atoi(v) / 8) * 8 : 0; }   // diagnostic (tools/stamp_hpad.py): a row pitch of h that is not a power of two made no difference
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) e->num_cu = (p.multiProcessorCount / 8) * 8; }
@@ -1152,12 +1188,12 @@ int kr_encoder_create(const kr_bert_cfg* cfg, int device, kr_encoder** out) {
         A(&l.bqkv, 3 * H * 4); A(&l.bo, H * 4); A(&l.bo_eff, H * 4); A(&l.b1, FF * 4); A(&l.b2, H * 4);
         A(&l.ln1g, H * 4); A(&l.ln1b, H * 4); A(&l.ln2g, H * 4); A(&l.ln2b, H * 4);
     }
-    if (rc) { kr_encoder_destroy(reinterpret_cast<kr_encoder*>(e)); return rc; }
-    *out = reinterpret_cast<kr_encoder*>(e);
+    if (rc) { enc_destroy(e); return rc; }
+    *out = e;
     return 0;
 }
 
-void kr_encoder_destroy(kr_encoder* h) {
+void enc_destroy(void* h) {
     if (!h) return;
     Encoder* e = reinterpret_cast<Encoder*>(h);
     (void)hipSetDevice(e->device);
@@ -1176,7 +1212,7 @@ void kr_encoder_destroy(kr_encoder* h) {
     delete e;
 }
 
-int kr_encoder_load_weight(kr_encoder* h, const char* hf_name, const float* data, int64_t numel) {
+int enc_load_weight(void* h, const char* hf_name, const float* data, int64_t numel) {
     if (!h || !hf_name || !data) return fail(KR_EINVAL, "NULL argument");
     Encoder* e = reinterpret_cast<Encoder*>(h);
     KR_TRY(select_device(e->device));
@@ -1227,7 +1263,7 @@ int kr_encoder_load_weight(kr_encoder* h, const char* hf_name, const float* data
     return 0;
 }
 
-int kr_encoder_finalize(kr_encoder* h) {
+int enc_finalize(void* h) {
     if (!h) return fail(KR_EINVAL, "NULL argument");
     Encoder* e = reinterpret_cast<Encoder*>(h);
     for (size_t i = 0; i < e->got.size(); ++i)
@@ -1343,7 +1379,7 @@ static int report_token_error(Encoder* e, hipStream_t st) {
     return fail(KR_EINVAL, "input_ids contain a token id outside [0, %d)", e->cfg.vocab);
 }
 
-int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* attention_mask, int B, int S, int pool, float* out, void* stream) {
+int enc_forward(void* h, const int64_t* input_ids, const int64_t* attention_mask, int B, int S, int pool, float* out, void* stream) {
     if (!h) return fail(KR_EINVAL, "encoder is NULL");
     Encoder* e = reinterpret_cast<Encoder*>(h);
     if (!e->ready) return fail(KR_ESTATE, "encoder weights incomplete: call kr_encoder_finalize after loading every tensor");
@@ -1381,7 +1417,7 @@ int kr_encoder_forward(kr_encoder* h, const int64_t* input_ids, const int64_t* a
     return report_token_error(e, st);
 }
 
-int kr_encoder_check(kr_encoder* h) {
+int enc_check(void* h) {
     if (!h) return fail(KR_EINVAL, "encoder is NULL");
     Encoder* e = reinterpret_cast<Encoder*>(h);
     if (!e->pending) return 0;
@@ -1391,7 +1427,11 @@ int kr_encoder_check(kr_encoder* h) {
     return report_token_error(e, e->last_stream);
 }
 
-#ifdef KR_STAMP
+#if defined(KR_STAMP) && !defined(KR_ENC_BUILD_F16)
+}  // namespace KR_ENC_NS
+}  // namespace kr
+extern "C" {
+using namespace kr;
 int kr_debug_read_fine_enc(unsigned long long* out128) {
     if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(kr_stamp_fine), 128 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long z[128] = {};
@@ -1403,10 +1443,13 @@ int kr_debug_read_stamps_enc(unsigned long long* out256) {
     unsigned long long z[256] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(kr_stamp_buf), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
+}  // extern "C"
+namespace kr {
+namespace KR_ENC_NS {
 #endif
 
 // last_hidden_state of the previous forward, un-packed to [B,S,H]; rows of non-attended positions are zero
-int kr_encoder_last_hidden(kr_encoder* h, float* out, int B, int S) {
+int enc_last_hidden(void* h, float* out, int B, int S) {
     if (!h || !out) return fail(KR_EINVAL, "NULL argument");
     Encoder* e = reinterpret_cast<Encoder*>(h);
     if (B != e->lastB || S != e->lastS || B == 0) return fail(KR_ESTATE, "no forward of shape [%d,%d] to read back", B, S);
@@ -1425,7 +1468,11 @@ int kr_encoder_last_hidden(kr_encoder* h, float* out, int B, int S) {
         std::vector<uint16_t> hi((size_t)T * H), lo((size_t)T * H);
         KR_HIP(hipMemcpy(hi.data(), e->xb, hi.size() * 2, hipMemcpyDeviceToHost));
         KR_HIP(hipMemcpy(lo.data(), e->xlo, lo.size() * 2, hipMemcpyDeviceToHost));
+#ifdef KR_ENC_BUILD_F16
+        auto f = [](uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); };
+#else
         auto f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float v; std::memcpy(&v, &u, 4); return v; };
+#endif
         for (size_t i = 0; i < x.size(); ++i) x[i] = f(hi[i]) + f(lo[i]);
     }
     std::vector<float> full((size_t)B * S * H, 0.f);
@@ -1436,4 +1483,5 @@ int kr_encoder_last_hidden(kr_encoder* h, float* out, int B, int S) {
     return 0;
 }
 
-}  // extern "C"
+}  // namespace KR_ENC_NS
+}  // namespace kr

@@ -38,7 +38,9 @@ def average_pool(last_hidden_states: Tensor, attention_mask: Tensor) -> Tensor:
 class HipBertForward:
     """Owns a ``kr_encoder`` handle and keeps its weight copy in sync with an ``nn.Module``'s parameters."""
 
-    def __init__(self, config, device_index: int):
+    def __init__(self, config, device_index: int, operand_dtype: Optional[str] = None, residual_lo: Optional[bool] = None):
+        """``operand_dtype``: "f16" / "bf16" = 16-bit type of the MFMA operands and stored activations, ``residual_lo``: keep the residual stream's
+        low half; ``None`` = the library default (f16 + low half; environment ``KIRAG_AMD_ENCODER_DTYPE`` / ``KIRAG_AMD_RESIDUAL_LO`` override it)."""
         lib = _lib.load()
         if getattr(config, "hidden_act", "gelu") != "gelu":
             raise NotImplementedError(f"hidden_act={config.hidden_act!r}: the HIP encoder implements erf-GELU only")
@@ -47,8 +49,12 @@ class HipBertForward:
         cfg = _lib.BertCfg(config.hidden_size, config.num_hidden_layers, config.num_attention_heads, config.intermediate_size,
                            config.vocab_size, config.max_position_embeddings, config.type_vocab_size, float(config.layer_norm_eps))
         h = C.c_void_p()
-        _lib.check(lib.kr_encoder_create(C.byref(cfg), device_index, C.byref(h)))
+        dt = -1 if operand_dtype is None else {"bf16": 0, "f16": 1}[operand_dtype]
+        lo = -1 if residual_lo is None else int(bool(residual_lo))
+        _lib.check(lib.kr_encoder_create_ex(C.byref(cfg), device_index, dt, lo, C.byref(h)))
         self._lib, self._h, self.device_index = lib, h, device_index
+        self.operand_dtype = ("bf16", "f16")[lib.kr_encoder_operand_dtype(h)]
+        self.residual_lo = bool(lib.kr_encoder_residual_lo(h))
         self.hidden = config.hidden_size
         self.fingerprint = None
 

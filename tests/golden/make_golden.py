@@ -122,7 +122,14 @@ def g10():
     — the regime where 16-bit operands / a 16-bit residual stream lose the most.  Outputs + per-case hidden-state magnitudes only."""
     cfgd = dict(g10_spec.CFG)
     out = {"cfg": np.array([cfgd[k] for k in ("H", "L", "heads", "FF", "vocab", "max_pos")])}
+    only = [w for w in os.environ.get("G10_ONLY", "").split(",") if w]      # regenerate / add only these weight sets, keep the rest of the file
+    path = os.path.join(OUT, "g10_encoder_large_ext.npz")
+    if only and os.path.exists(path):
+        old = np.load(path)
+        out.update({k: old[k] for k in old.files if k.split(".")[0] not in only})
     for wname in g10_spec.WEIGHTS:
+        if only and wname not in only:
+            continue
         w = g10_spec.weights(wname)
         for cls, tag in ((E5Encoder, "e5"), (BGEEncoder, "bge")):
             m = build(cls, cfgd, None, weights=w)

@@ -563,10 +563,12 @@ def test_pass2_prescan_marks_only_the_slots_that_matter():
     assert st["fine"] >= 24 and st["exact"] == 0 and st["marked_passes"] >= 1 and st["certified"] >= 30, st
     assert 5000 <= st["marked_rows"] / st["marked_passes"] <= 5600, st          # the cluster and little else
     assert set(i[0].tolist()) <= set(where.tolist())                         # a cluster query's top-100 are cluster rows
-    os.environ["KIRAG_AMD_NO_MARK"] = "1"
+    os.environ["KIRAG_AMD_NO_MARK"] = "1"                                   # the switches are read once, when an index is created
     try:
-        s2, i2 = ix.index.search(q, 100)
+        ix2 = _mk(d, x)
     finally:
         del os.environ["KIRAG_AMD_NO_MARK"]
+    s2, i2 = ix2.index.search(q, 100)
     assert np.array_equal(i2, io) and np.array_equal(s2.view(np.uint32), so.view(np.uint32))
-    assert ix.index.stats()["marked_passes"] == st["marked_passes"]
+    st2 = ix2.index.stats()
+    assert st2["marked_passes"] == 0 and st2["fine"] == st["fine"], st2

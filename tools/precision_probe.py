@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Design tool: which operand precision does the encoder need?  A torch emulation of the HIP forward's ROUNDING POINTS (16-bit MFMA operands, fp32
+accumulation, 16-bit stored activations, optional (hi, lo) residual stream) run against the reference-generated goldens G10 — so that a precision
+decision (bf16 vs f16 operands, residual low half) can be taken from numbers before any kernel is touched.  Runs on CPU or GPU.
+Usage: python tools/precision_probe.py [weights: benign|out16|out60|...] [cases e.g. e5.c0,e5.c3]"""
+import os, sys, math
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+import numpy as np, torch
+import g10_spec
+
+dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def rnd(t, mode):
+    if mode == "bf16": return t.to(torch.bfloat16).float()
+    if mode == "f16": return t.to(torch.float16).float()
+    return t
+
+
+def forward(W, ids, mask, heads, op, resid_lo, y16=True, pool="mean"):
+    """op: 'bf16' | 'f16' | 'f32' = precision of every MFMA operand and of every stored activation."""
+    B, S = ids.shape
+    H = W["embeddings.word_embeddings.weight"].shape[1]; dh = H // heads
+    def ln(x, g, b): return torch.nn.functional.layer_norm(x, (H,), g, b, 1e-12)
+    def stream(x):     # what the next GEMM reads (hi) and what the residual add sees (hi [+ lo])
+        hi = rnd(x, op)
+        return hi, (hi + rnd(x - hi, op) if resid_lo else hi)
+    x = W["embeddings.word_embeddings.weight"][ids] + W["embeddings.position_embeddings.weight"][:S][None] + W["embeddings.token_type_embeddings.weight"][0]
+    x = ln(x, W["embeddings.LayerNorm.weight"], W["embeddings.LayerNorm.bias"])
+    xh, xr = stream(x)
+    keep = mask.bool()[:, None, None, :]
+    L = 0
+    while f"encoder.layer.{L}.attention.self.query.weight" in W: L += 1
+    for l in range(L):
+        p = f"encoder.layer.{l}."
+        def lin(t, name): return t @ rnd(W[p + name + ".weight"], op).T + W[p + name + ".bias"]
+        q = rnd(lin(xh, "attention.self.query") / math.sqrt(dh), op).view(B, S, heads, dh).transpose(1, 2)
+        k = rnd(lin(xh, "attention.self.key"), op).view(B, S, heads, dh).transpose(1, 2)
+        v = rnd(lin(xh, "attention.self.value"), op).view(B, S, heads, dh).transpose(1, 2)
+        s = (q @ k.transpose(-1, -2)).masked_fill(~keep, float("-inf"))
+        pr = torch.softmax(s, -1)
+        m = s.max(-1, keepdim=True).values
+        e = rnd(torch.exp(s - m), op)                       # P is fed to the MFMA as 16-bit, the row sum is kept in fp32
+        ctx = rnd(((e @ v) / torch.exp(s - m).sum(-1, keepdim=True)), op).transpose(1, 2).reshape(B, S, H)
+        y = ctx @ rnd(W[p + "attention.output.dense.weight"], op).T
+        y = rnd(y, op) if y16 else y
+        x = ln(y + W[p + "attention.output.dense.bias"] + xr, W[p + "attention.output.LayerNorm.weight"], W[p + "attention.output.LayerNorm.bias"])
+        xh, xr = stream(x)
+        h = rnd(torch.nn.functional.gelu(lin(xh, "intermediate.dense")), op)
+        y = h @ rnd(W[p + "output.dense.weight"], op).T
+        y = rnd(y, op) if y16 else y
+        x = ln(y + W[p + "output.dense.bias"] + xr, W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"])
+        if l + 1 < L: xh, xr = stream(x)
+    if pool == "mean":
+        mm = mask[..., None].float()
+        emb = (x * mm).sum(1) / mm.sum(1)
+    else:
+        emb = x[:, 0]
+    return torch.nn.functional.normalize(emb, dim=1)
+
+
+if __name__ == "__main__":
+    wname = sys.argv[1] if len(sys.argv) > 1 else "out16"
+    cases = sys.argv[2].split(",") if len(sys.argv) > 2 else ["e5.c0", "e5.c3"]
+    g = np.load(os.path.join(REPO, "tests", "golden", "g10_encoder_large_ext.npz"))
+    W = {k: torch.from_numpy(v).to(dev) for k, v in g10_spec.weights(wname).items()}
+    outs = {}
+    modes = [("f32", False, False), ("bf16", False, True), ("bf16", True, True), ("f16", False, True), ("f16", True, True), ("f16", True, False)]
+    for case in cases:
+        tag, ci = case.split(".c"); ci = int(ci)
+        B, S, layout, seed = g10_spec.CASES[wname][tag][ci]
+        ids, mask = g10_spec.tokens(B, S, layout, seed)
+        ref = g[f"{wname}.{case}.out"]
+        for op, lo, y16 in modes:
+            with torch.no_grad():
+                out = forward(W, torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev), 16, op, lo, y16, "mean" if tag == "e5" else "cls").cpu().numpy()
+            cos = (out * ref).sum(1)
+            outs[(case, op, lo, y16)] = out
+            print(f"{wname}.{case} B{B} S{S}  operands {op:4s} resid_lo={int(lo)} y16={int(y16)}: max abs err {np.abs(out - ref).max():.2e}  1-cos {float((1 - cos).max()):.2e}", flush=True)
+    if len(cases) >= 2:
+        a, b = cases[0], cases[1]
+        ra, rb = g[f"{wname}.{a}.out"], g[f"{wname}.{b}.out"]
+        for op, lo, y16 in modes:
+            print(f"scores {a} x {b}  operands {op:4s} resid_lo={int(lo)} y16={int(y16)}: max |q.d - ref| = {np.abs(outs[(a, op, lo, y16)] @ outs[(b, op, lo, y16)].T - ra @ rb.T).max():.2e}")

@@ -3,7 +3,7 @@
 # bench, and two separate PMC passes (FETCH_SIZE, WRITE_SIZE) of the search-only bench.  Summaries -> gpurun_out/<tag>/ (copy into profiles/).
 # The program after `--` is python3 itself (never env / bash -c: the profiler's preloaded library has initialised the GPU).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -18,6 +18,18 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 echo "pmc fetch done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-encoder --no-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 echo "pmc write done"
+# MFMA-pipe utilisation (north_star): counters in their own passes, program directly after `--`
+rocprofv3 -L > $OUT/counters_list.txt 2>&1 || true
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err || echo "pmc mfma pass failed"
+echo "pmc mfma done"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err || echo "pmc sq pass failed"
+echo "pmc sq done"
+# HBM traffic of the encoder kernels (k_attn_lds, k_ln16, k_proj): FETCH / WRITE passes of the full step
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_enc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch_enc.json 2> $OUT/pmc_fetch_enc.err || echo "pmc fetch enc failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_enc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write_enc.json 2> $OUT/pmc_write_enc.err || echo "pmc write enc failed"
+echo "pmc encoder traffic done"
+python3 $R/tools/pmc_mfma.py $OUT/pmc_mfma k_coarse=4.1945e13 > $OUT/mfma_busy.json || true
+python3 $R/tools/pmc_mfma.py $OUT/pmc_sq > $OUT/sq_wave_breakdown.json || true
 python3 $R/tools/pmc_summary.py $OUT > $OUT/search_pmc_fetch_write.json
 python3 $R/tools/pmc_summary.py $OUT --traffic 4 > $OUT/traffic.json
 python3 $R/tools/trace_breakdown.py $OUT/kt > $OUT/encoder_forward_breakdown.txt
