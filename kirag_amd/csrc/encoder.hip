@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void k_seq_len(const int64_t* __restrict__ mask
 }
 
 // one wave: nq = nk (+1 query-only row for position 0 when CLS pooling needs it), offsets = exclusive scan of round_up(nq,4)
-__global__ __launch_bounds__(64) void k_seq_scan(const int* __restrict__ nk, const int* __restrict__ has0, int B, int pool, int* __restrict__ nq,
+__global__ __launch_bounds__(64) void k_seq_scan(const int* __restrict__ nk, const int* __restrict__ has0, int B, int pool, int align, int* __restrict__ nq,
                                                  int* __restrict__ off, int* __restrict__ cls, int* __restrict__ T, int* __restrict__ err) {
     const int lane = threadIdx.x;
     int carry = 0;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void k_seq_scan(const int* __restrict__ nk, con
             nq[b] = n;
             cls[b] = has0[b] ? 0 : nk[b];
         }
-        const int padded = (n + 3) & ~3;
+        const int padded = (n + align - 1) & ~(align - 1);   // align = 4, or 8 when the long-sequence attention kernel stages V^T by 16-byte LDS-DMA
         int incl = padded;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void k_seq_scan(const int* __restrict__ nk, con
 }
 
 // one wave per sequence: packed token list (attended positions in order; the optional query-only row for position 0 last)
-__global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int S, int vocab,
+__global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int S, int vocab, int align,
                                                     const int* __restrict__ off, const int* __restrict__ nk, const int* __restrict__ nq,
                                                     int* __restrict__ tok_id, int* __restrict__ tok_pos, int* __restrict__ err) {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ 
         if (id < 0 || id >= vocab) { *err = 1; id = 0; }
         tok_id[o + nk[b]] = (int)id; tok_pos[o + nk[b]] = 0;
     }
-    const int padded = (n + 3) & ~3;
+    const int padded = (n + align - 1) & ~(align - 1);
     if (lane < padded - n) { tok_id[o + n + lane] = 0; tok_pos[o + n + lane] = 0; }
 }
 
@@ -690,19 +690,153 @@ __global__ __launch_bounds__(SKINNY_THREADS) void k_proj_skinny(ProjArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// attention, LDS-staged: one block (4 waves) per (sequence, group of HPB heads, group of 4 / HPB q-tiles).  K [keys][64] and V^T [64][keys] of
-// the block's heads are staged in LDS in chunks of (at most) 128 keys — 49 KiB per block for any sequence length, three blocks per CU; the
-// online-softmax state of a wave's q-tile lives in registers across the chunks:
-//   K image   128-B rows, 16-B chunk index XOR ((key >> 1) & 7): the ds_read_b128 of an MFMA A fragment (lane -> key l&31,
-//             d-chunk 2s + (l>>5)) is bank-conflict free (same image as the GEMM ring);
-//   V^T image row pitch 2*cap + 8 bytes (pitch / 8 odd): the two ds_read_b64 of a P.V A fragment (lane -> d = l&31) hit 32
-//             distinct 8-B bank pairs; keys >= nk are stored as zero (no 0 * NaN from rows of other sequences).
-// Each wave takes (head, 32-query tile) items: S^T = K.Q^T (keys on accumulator rows, so the softmax row reductions are in-lane +
-// one shfl_xor 32), online softmax, P^T straight from the accumulator into the V^T.P^T MFMA with the matching permuted key order.
+// attention.  Two kernels share ONE arithmetic (attn_step64: the same MFMAs, the same softmax operations in the same order), so a sequence's context
+// rows are bit-identical whichever kernel its batch selects (the embedding cache and batch invariance rely on it):
+//   k_attn_lds  sequences of at most 128 tokens: K / V^T of the block's heads staged through registers, one block per (sequence, HPB heads, 4 / HPB q-tiles)
+//   k_attn_dma  longer sequences: K / V^T chunks of 64 keys stream through a 3-stage LDS ring by LDS-DMA (two chunks in flight behind the one being
+//               multiplied, one barrier per chunk), one block per (sequence, head, 8 q-tiles): two q-tiles per wave share every staged chunk
+// Common scheme per wave and 32-query tile: S^T = K.Q^T (keys on accumulator rows, so the softmax row reductions are in-lane + one shfl_xor 32), online
+// softmax over 64-key steps, P^T fed from the accumulator straight into the V^T.P^T MFMA.  The key that sits on A-tile row i of a 32-key tile is
+// perm(i) = i with bits 2 and 3 exchanged: a lane's registers 8a .. 8a+7 then hold 8 CONSECUTIVE keys (16 a + 8 hf .. + 7), i.e. the P^T fragment of a
+// k-step matches one contiguous 16-byte run of a V^T row (without the permutation a lane owns keys {0..3, 8..11} + 4 hf: two 8-byte reads per fragment).
+// The permutation maps each ds_read_b128 lane group onto itself, so the K reads stay bank-conflict free.
+//   K image   128-B rows, 16-B chunk index XOR ((key >> 1) & 7) (same image as the GEMM ring)
+//   V^T image k_attn_lds: row pitch 2 * cap + 8 bytes (pitch / 8 odd: conflict-free ds_read_b64), keys >= nk stored as zero;
+//             k_attn_dma: [64 d][128 B] per chunk, chunk index XOR ((d >> 1) & 7) like the K image (one ds_read_b128 per fragment), columns >= nk of
+//             the last chunk zeroed in LDS after they landed (no 0 * NaN from rows of other sequences).
 // The O tile is staged through a wave-private 4-KiB LDS block and stored as whole 128-B rows of ctx.
-// HPB = heads per block: 1 when a sequence has >= 3 q-tiles, 2 / 4 for short sequences so that all four waves have work.
 // ---------------------------------------------------------------------------------------------------------
-// __launch_bounds__(256, 2): at most 256 registers per lane, which makes hipcc keep the MFMA accumulators in VGPRs; with the default bound it put
+struct AttnState {
+    f32x16 o0, o1;
+    float mref, l;      // reference maximum (log2 units) the accumulated o / l are scaled by; running denominator
+};
+
+__device__ __forceinline__ void attn_init(AttnState& s) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s.o0[r] = 0.f; s.o1[r] = 0.f; }
+    s.mref = -INFINITY; s.l = 0.f;
+}
+
+__device__ __forceinline__ int attn_perm(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+// One 64-key step of a wave's 32-query tile.  Kst: K image (128-B rows, swizzled), k0 = row of the step's first key in it; nvalid = keys of the
+// step that exist (MASKED instantiation: < 64; <= 32: the second 32-key tile is skipped — it would only add exact zeros); vfrag(dh, ks) returns the
+// V^T A-fragment of d rows 32 dh .. + 31, keys k0 + 16 ks + 8 hf .. + 7.
+// Scores are in log2 units (log2(e) / sqrt(d_h) is folded into W_q at load time), so P = exp2(s - mref) is one subtraction and one v_exp_f32 per
+// element.  The reference maximum mref of a query is only raised — with the o / l rescale of the online softmax — when a step's maximum exceeds it by
+// more than ATTN_RESCALE_THR (2^8: P stays far inside the 16-bit range, and o / l are fp32); any mref gives the same result up to rounding because it
+// cancels in o / l.  The slow path is taken by the whole wave (wave-uniform branch), so a tile's P.V is never split.  (Feeding -mref to the S^T MFMAs
+// as their C operand would save the subtraction too, but costs 16 more live registers per tile: measured as spills at three blocks per CU.)
+constexpr float ATTN_RESCALE_THR = 8.0f;
+// first half of a step: the shifted-score tiles S^T = K . Q^T (st1 = -inf when the second 32-key tile does not exist)
+template <bool MASKED>
+__device__ __forceinline__ void attn_scores(f32x16& st0, f32x16& st1, const uint4 (&qf)[4], const char* Kst, int k0, int nvalid, int c, int hf) {
+    const bool two = !MASKED || nvalid > 32;              // wave-uniform
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+        const int key = k0 + attn_perm(c);
+        const char* krow = Kst + key * 128;
+        const int swz = (key >> 1) & 7;
+        st0 = ET::mfma(*reinterpret_cast<const uint4*>(krow + (((0 + hf) ^ swz) << 4)), qf[0], zero);
+#pragma unroll
+        for (int sk = 1; sk < 4; ++sk) st0 = ET::mfma(*reinterpret_cast<const uint4*>(krow + (((2 * sk + hf) ^ swz) << 4)), qf[sk], st0);
+        if (two) {
+            const char* krow1 = krow + 32 * 128;          // (key + 32) >> 1 & 7 == swz
+            st1 = ET::mfma(*reinterpret_cast<const uint4*>(krow1 + (((0 + hf) ^ swz) << 4)), qf[0], zero);
+#pragma unroll
+            for (int sk = 1; sk < 4; ++sk) st1 = ET::mfma(*reinterpret_cast<const uint4*>(krow1 + (((2 * sk + hf) ^ swz) << 4)), qf[sk], st1);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st1[r] = -INFINITY;
+        }
+    }
+    // register r of this lane: key k0 + 16 (r >> 3) + 8 hf + (r & 7) (+ 32 for st1), query c
+    if constexpr (MASKED) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = 16 * (r >> 3) + 8 * hf + (r & 7);
+            st0[r] = (kk < nvalid) ? st0[r] : -INFINITY;
+            st1[r] = (kk + 32 < nvalid) ? st1[r] : -INFINITY;
+        }
+    }
+}
+
+// second half: online softmax and O^T += V^T . P^T
+template <bool MASKED, class VFrag>
+__device__ __forceinline__ void attn_softmax_pv(AttnState& s, const f32x16& st0, const f32x16& st1, int nvalid, VFrag&& vfrag) {
+    const bool two = !MASKED || nvalid > 32;              // wave-uniform
+    float tmax = fmaxf(fmaxf(st0[0], st0[1]), st0[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, st0[r]), st0[r + 1]);   // v_max3_f32
+    tmax = fmaxf(tmax, st0[15]);
+    if (two) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, st1[r]), st1[r + 1]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const bool fresh = s.mref == -INFINITY;               // nothing accumulated for this query yet
+    if (__builtin_amdgcn_ballot_w64(fresh || tmax > s.mref + ATTN_RESCALE_THR) != 0ull) {
+        // raise the reference (never lower it)
+        const float mnew = fmaxf(s.mref, tmax);
+        const float alpha = fresh ? 1.f : __builtin_amdgcn_exp2f(s.mref - mnew);   // fresh: o = l = 0 (and mref - mnew is -inf - x)
+        s.l *= alpha;
+        s.o0 *= alpha; s.o1 *= alpha;
+        s.mref = mnew;
+    }
+    const float mshift = (s.mref == -INFINITY) ? 0.f : s.mref;   // still -inf: no valid key so far, every score is -inf and stays so
+    // P = exp2(s - mref) and O^T += V^T . P^T, one k-step (8 keys per lane: registers 8 a .. 8 a + 7 = keys 16 a + 8 hf .. + 7 of the tile) at a time: the
+    // exp2 / pack of a k-step sit between the MFMAs of the previous one, and at most 8 probabilities are live next to the scores
+    float psum = 0.f;
+    auto pv = [&](const f32x16& stx, int ks0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float e[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { e[i] = __builtin_amdgcn_exp2f(stx[8 * a + i] - mshift); psum += e[i]; }
+            uint4 pf;
+            pf.x = pack_bf16x2(e[0], e[1]); pf.y = pack_bf16x2(e[2], e[3]); pf.z = pack_bf16x2(e[4], e[5]); pf.w = pack_bf16x2(e[6], e[7]);
+            s.o0 = ET::mfma(vfrag(0, ks0 + a), pf, s.o0);
+            s.o1 = ET::mfma(vfrag(1, ks0 + a), pf, s.o1);
+        }
+    };
+    pv(st0, 0);
+    if (two) pv(st1, 2);
+    psum += __shfl_xor(psum, 32, 64);
+    s.l += psum;
+}
+
+template <bool MASKED, class VFrag>
+__device__ __forceinline__ void attn_step64(AttnState& s, const uint4 (&qf)[4], const char* Kst, int k0, int nvalid, int c, int hf, VFrag&& vfrag) {
+    f32x16 st0, st1;
+    attn_scores<MASKED>(st0, st1, qf, Kst, k0, nvalid, c, hf);
+    attn_softmax_pv<MASKED>(s, st0, st1, nvalid, vfrag);
+}
+
+// normalise a finished 32-query tile and store it as whole 128-B rows of ctx through the wave-private 4-KiB LDS block Os
+__device__ __forceinline__ void attn_store_tile(const AttnState& s, char* Os, uint16_t* __restrict__ ctx, int64_t off, int q0, int nq, int H, int head, int lane) {
+    const int c = lane & 31, hf = lane >> 5;
+    // a query with no attendable key (all-masked sequence) is 0/0 = NaN, as under HF's -inf masking
+    const float inv = 1.0f / s.l;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        uint2 w0, w1;
+        w0.x = pack_bf16x2(s.o0[4 * gq + 0] * inv, s.o0[4 * gq + 1] * inv); w0.y = pack_bf16x2(s.o0[4 * gq + 2] * inv, s.o0[4 * gq + 3] * inv);
+        w1.x = pack_bf16x2(s.o1[4 * gq + 0] * inv, s.o1[4 * gq + 1] * inv); w1.y = pack_bf16x2(s.o1[4 * gq + 2] * inv, s.o1[4 * gq + 3] * inv);
+        const int j8 = 2 * gq + hf;     // 8-byte chunk (4 features) of the 128-B row of query c
+        *reinterpret_cast<uint2*>(Os + c * 128 + ((j8 ^ (c & 15)) << 3)) = w0;
+        *reinterpret_cast<uint2*>(Os + c * 128 + (((8 + j8) ^ (c & 15)) << 3)) = w1;
+    }
+#pragma unroll
+    for (int p4 = 0; p4 < 4; ++p4) {
+        const int rq = p4 * 8 + (lane >> 3), ch = lane & 7;
+        const uint2 lo = *reinterpret_cast<const uint2*>(Os + rq * 128 + (((2 * ch) ^ (rq & 15)) << 3));
+        const uint2 hi = *reinterpret_cast<const uint2*>(Os + rq * 128 + (((2 * ch + 1) ^ (rq & 15)) << 3));
+        if (q0 + rq < nq) *reinterpret_cast<uint4*>(ctx + (off + q0 + rq) * H + head * 64 + ch * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
+
+// HPB = heads per block: 1 when a sequence has >= 3 q-tiles, 2 / 4 for short sequences so that all four waves have work.
+// __launch_bounds__(256, 3): at most 168 registers per lane, which makes hipcc keep the MFMA accumulators in VGPRs; with the default bound it put
 // them in AGPRs and spent 112 of the 276 VALU instructions of a key tile on v_accvgpr_read / _write around the softmax rescale
 template <int HPB>
 __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vT, int64_t ldv,
@@ -727,7 +861,6 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
     const char* Kh = Ks + (size_t)hs * kchunk * 128;
     const char* Vh = Vs + (size_t)hs * 64 * vpitch;
     const int c = lane & 31, hf = lane >> 5;
-    const float LOG2E = 1.4426950408889634f;
     // Q^T as the B operand: lane (c, hf) holds Q[q0 + c][16 s + 8 hf .. +7], s = 0..3
     uint4 qf[4] = {};
     if (active) {
@@ -736,10 +869,8 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(qrow + 16 * s + 8 * hf);
     }
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m = -INFINITY, l = 0.f;
+    AttnState st;
+    attn_init(st);
     constexpr int NB = HPB == 1 ? 4 : 2;                  // loads in flight per thread, head and batch (register budget: 3 blocks per CU = 168 VGPRs; HPB = 4 means <= 32 keys: 2 cover a head)
     for (int kc0 = 0; kc0 < nk; kc0 += kchunk) {
         // ---- stage keys [kc0, kc0 + kchunk) of the block's heads: every global load of a batch is issued before the first LDS store
@@ -814,77 +945,130 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
         }
         __syncthreads();
         if (!active) continue;
-        for (int k0 = 0; k0 < nkc; k0 += 32) {            // k0: key offset inside the chunk
-            f32x16 st;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = 0.f;
-            {
-                const int key = k0 + c;
-                const char* krow = Kh + key * 128;
-                const int swz = (key >> 1) & 7;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const uint4 kf = *reinterpret_cast<const uint4*>(krow + (((2 * s + hf) ^ swz) << 4));
-                    st = ET::mfma(kf, qf[s], st);
-                }
-            }
-            // register r of this lane is key kc0 + k0 + (r&3) + 8 (r>>2) + 4 hf, query q0 + c
-            if (k0 + 32 > nkc) {   // only the last key tile can hold keys >= nk
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[r] = (k0 + (r & 3) + 8 * (r >> 2) + 4 * hf < nkc) ? st[r] : -INFINITY;
-            }
-            float tmax = fmaxf(fmaxf(st[0], st[1]), st[2]);
-#pragma unroll
-            for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, st[r]), st[r + 1]);   // v_max3_f32
-            tmax = fmaxf(tmax, st[15]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float mnew = fmaxf(m, tmax);
-            const float mL = ((mnew == -INFINITY) ? 0.f : mnew) * LOG2E;
-            const float alpha = __builtin_amdgcn_exp2f(fmaf(m, LOG2E, -mL));        // arguments <= 0: no overflow; exp2(-inf) = 0
-            float psum = 0.f;
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(st[r], LOG2E, -mL)); psum += p[r]; }
-            psum += __shfl_xor(psum, 32, 64);
-            l = l * alpha + psum;
-            m = mnew;
-            o0 *= alpha; o1 *= alpha;
-            // O^T += V^T . P^T : P^T from the accumulator (k-step s2 = registers 8 s2 .. 8 s2 + 7, element j = key 16 s2 + 8 (j>>2) + 4 hf + (j&3));
-            // the V^T fragment uses the same key order: elements 0..3 = keys kb .. kb+3, 4..7 = keys kb+8 .. kb+11, kb = k0 + 16 s2 + 4 hf
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                uint4 pf;
-                pf.x = pack_bf16x2(p[8 * s2 + 0], p[8 * s2 + 1]); pf.y = pack_bf16x2(p[8 * s2 + 2], p[8 * s2 + 3]);
-                pf.z = pack_bf16x2(p[8 * s2 + 4], p[8 * s2 + 5]); pf.w = pack_bf16x2(p[8 * s2 + 6], p[8 * s2 + 7]);
-                const int kb = k0 + 16 * s2 + 4 * hf;
-                const char* v0 = Vh + c * vpitch + kb * 2;
-                const char* v1 = v0 + 32 * vpitch;
-                const uint2 a0 = *reinterpret_cast<const uint2*>(v0), a1 = *reinterpret_cast<const uint2*>(v0 + 16);
-                const uint2 b0 = *reinterpret_cast<const uint2*>(v1), b1 = *reinterpret_cast<const uint2*>(v1 + 16);
-                o0 = ET::mfma(make_uint4(a0.x, a0.y, a1.x, a1.y), pf, o0);
-                o1 = ET::mfma(make_uint4(b0.x, b0.y, b1.x, b1.y), pf, o1);
-            }
+        for (int k0 = 0; k0 < nkc; k0 += 64) {            // k0: key offset inside the chunk
+            auto vfrag = [&](int dh, int ks) {
+                const char* v = Vh + (c + 32 * dh) * vpitch + (k0 + 16 * ks + 8 * hf) * 2;
+                const uint2 a0 = *reinterpret_cast<const uint2*>(v), a1 = *reinterpret_cast<const uint2*>(v + 8);
+                return make_uint4(a0.x, a0.y, a1.x, a1.y);
+            };
+            if (nkc - k0 < 64) attn_step64<true>(st, qf, Kh, k0, nkc - k0, c, hf, vfrag);
+            else attn_step64<false>(st, qf, Kh, k0, 64, c, hf, vfrag);
         }
     }
     if (!active) return;
-    // a query with no attendable key (all-masked sequence) is 0/0 = NaN, as under HF's -inf masking
-    const float inv = 1.0f / l;
+    attn_store_tile(st, Os, ctx, off, q0, nq, H, head, lane);
+}
+
+// ---- long sequences: LDS-DMA ring ------------------------------------------------------------------------------------------------------------
+constexpr int ADMA_STAGE = 16384;                          // per 64-key chunk: K [64 keys][128 B] + V^T [64 d][128 B]
+constexpr int ADMA_RING = 3;
+constexpr int ADMA_LDS = ADMA_RING * ADMA_STAGE;           // 48 KiB; the O staging (4 waves x 4 KiB) re-uses the ring after the last chunk
+constexpr int ADMA_WAVES = 4;
+constexpr int ADMA_THREADS = ADMA_WAVES * 64;
+constexpr int ADMA_QT = 2 * ADMA_WAVES;                    // q-tiles per block: TWO per wave (w and w + 4), so every staged chunk serves 256 queries
+constexpr int ADMA_PIECES = 8 / ADMA_WAVES;                // K pieces (and V^T pieces) of 1 KiB a wave issues per chunk
+
+// Measured at 128 x 512 tokens (us per layer; the register-staged kernel: 344): two q-tiles per wave one after the other 253; one q-tile per wave with
+// four waves per block and three waves per SIMD 285 (every chunk then serves 128 queries and the block meets a barrier per step: its waves run in
+// lockstep); eight waves x one q-tile at <= 128 registers spills the Q fragments (scratch reloads are VMEM operations: they drain the DMA ring).
+// Interleaving a wave's two q-tiles by halves (scores(0), scores(1), softmax + P.V(0), softmax + P.V(1): tile 1's S^T MFMAs under tile 0's softmax)
+// needs both score tiles live: 42 spilled registers at the 256-register limit, two of them reloaded per chunk (VMEM: the DMA ring drains) — not kept.
+// (the body is a function with __restrict__ K / V^T pointers on purpose: after inlining the LDS-DMA carries their alias scope and the ring's ds_reads are
+// marked as not aliasing it, which lets the compiler's waitcnt pass leave the COUNTED vmcnt waits alone; see coarse_q32_body in search.hip)
+__device__ __forceinline__ void attn_dma_body(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vT, int64_t ldv,
+                                              int64_t off, int nk, int nq, int H, int head, int qg, int64_t capT, uint16_t* __restrict__ ctx, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hf = lane >> 5;
+    const int nchunks = (nk + 63) >> 6;
+    // DMA of one chunk: 16 pieces of 1 KiB (8 K pieces = 8 keys x 128 B each, 8 V^T pieces = 8 d rows x 128 B each); wave w issues pieces
+    // w * ADMA_PIECES .. + ADMA_PIECES - 1 of both.  lane -> row 8 p + (lane >> 3), 16-B chunk (lane & 7) ^ swizzle(row) of that row (the LDS destination is
+    // lane-linear: the swizzle sits on the source)
+    const char* kbase = reinterpret_cast<const char*>(k) + (int64_t)head * 128;
+    const char* vbase = reinterpret_cast<const char*>(vT) + ((int64_t)head * 64) * ldv * 2 + off * 2;
+    auto issue = [&](int cidx) {
+        char* stg = smem + (cidx % ADMA_RING) * ADMA_STAGE;
+        const int kc0 = cidx * 64;
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        uint2 w0, w1;
-        w0.x = pack_bf16x2(o0[4 * gq + 0] * inv, o0[4 * gq + 1] * inv); w0.y = pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
-        w1.x = pack_bf16x2(o1[4 * gq + 0] * inv, o1[4 * gq + 1] * inv); w1.y = pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
-        const int j8 = 2 * gq + hf;     // 8-byte chunk (4 features) of the 128-B row of query c
-        *reinterpret_cast<uint2*>(Os + c * 128 + ((j8 ^ (c & 15)) << 3)) = w0;
-        *reinterpret_cast<uint2*>(Os + c * 128 + (((8 + j8) ^ (c & 15)) << 3)) = w1;
-    }
+        for (int pp = 0; pp < ADMA_PIECES; ++pp) {
+            const int p = wave * ADMA_PIECES + pp;
+            const int row = 8 * p + (lane >> 3);           // key inside the chunk / d row
+            const int sw = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
+            int64_t trow = off + kc0 + row;                // rows past the sequence (last chunk) are read and masked; past the buffer they are clamped
+            if (trow >= capT) trow = capT - 1;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + trow * H * 2 + sw), (lds_void*)(stg + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + (int64_t)row * ldv * 2 + kc0 * 2 + sw), (lds_void*)(stg + 8192 + p * 1024), 16, 0, 0);
+        }
+    };
+    issue(0);
+    if (nchunks > 1) issue(1);
+    // The Q fragments are loaded behind the first two chunks' DMA and waited for HERE with a wait the compiler sees (a builtin, not inline asm):
+    // otherwise its waitcnt pass keeps them "possibly pending" around the loop's back edge and puts s_waitcnt vmcnt(0) in front of the first MFMA of
+    // every chunk, which drains the DMA ring (one memory round trip per chunk, as without a ring)
+    int q0[2]; bool act[2];
+    uint4 qf[2][4] = {};
+    AttnState st[2];
 #pragma unroll
-    for (int p4 = 0; p4 < 4; ++p4) {
-        const int rq = p4 * 8 + (lane >> 3), ch = lane & 7;
-        const uint2 lo = *reinterpret_cast<const uint2*>(Os + rq * 128 + (((2 * ch) ^ (rq & 15)) << 3));
-        const uint2 hi = *reinterpret_cast<const uint2*>(Os + rq * 128 + (((2 * ch + 1) ^ (rq & 15)) << 3));
-        if (q0 + rq < nq) *reinterpret_cast<uint4*>(ctx + (off + q0 + rq) * H + head * 64 + ch * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    for (int j = 0; j < 2; ++j) {
+        q0[j] = (qg * ADMA_QT + wave + ADMA_WAVES * j) * 32;
+        act[j] = q0[j] < nq;                               // wave-uniform; act[1] implies act[0]
+        if (act[j]) {
+            const int qi = (q0[j] + c < nq) ? (q0[j] + c) : (nq - 1);
+            const uint16_t* qrow = q + (off + qi) * H + head * 64;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[j][s] = *reinterpret_cast<const uint4*>(qrow + 16 * s + 8 * hf);
+        }
+        attn_init(st[j]);
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): Q fragments (and chunks 0, 1) have landed
+    for (int ci = 0; ci < nchunks; ++ci) {
+        if (ci + 1 < nchunks) wait_vmcnt<2 * ADMA_PIECES>(); else wait_vmcnt<0>();   // this wave's pieces of chunk ci have landed; chunk ci + 1 may be in flight
+        __builtin_amdgcn_s_barrier();                      // everybody's pieces of chunk ci landed, everybody is done reading chunk ci - 1
+        if (ci + 2 < nchunks) issue(ci + 2);               // into the stage of chunk ci - 1
+        char* stg = smem + (ci % ADMA_RING) * ADMA_STAGE;
+        const int nkc = min(nk - ci * 64, 64);
+        auto vfrag = [&](int dh, int ks) {
+            const int d = c + 32 * dh;
+            return *reinterpret_cast<const uint4*>(stg + 8192 + d * 128 + (((2 * ks + hf) ^ ((d >> 1) & 7)) << 4));
+        };
+        if (nkc < 64) {
+            // V^T columns >= nkc of the last chunk hold other sequences' values (or padding): zero them, so that P = 0 meets 0 and not a possible NaN / Inf
+            for (int i = tid; i < 64 * 8; i += ADMA_THREADS) {
+                const int d = i >> 3, chk = i & 7;         // (d row, 16-B chunk)
+                if (chk * 8 + 8 > nkc) {
+                    uint4* w = reinterpret_cast<uint4*>(stg + 8192 + d * 128 + ((chk ^ ((d >> 1) & 7)) << 4));
+                    uint4 v = *w;
+                    unsigned int* u = reinterpret_cast<unsigned int*>(&v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = chk * 8 + 2 * e;
+                        u[e] &= (key < nkc ? 0xffffu : 0u) | (key + 1 < nkc ? 0xffff0000u : 0u);
+                    }
+                    *w = v;
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!act[j]) continue;
+            if (nkc < 64) attn_step64<true>(st[j], qf[j], stg, 0, nkc, c, hf, vfrag);
+            else attn_step64<false>(st[j], qf[j], stg, 0, 64, c, hf, vfrag);
+        }
+    }
+    __syncthreads();                                       // the ring is free: re-use it for the O staging
+    char* Os = smem + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (act[j]) attn_store_tile(st[j], Os, ctx, off, q0[j], nq, H, head, lane);
+}
+
+__global__ __launch_bounds__(ADMA_THREADS, 2) void k_attn_dma(const uint16_t* q, const uint16_t* k, const uint16_t* vT, int64_t ldv, const int* __restrict__ seq_off,
+                                                             const int* __restrict__ seq_nk, const int* __restrict__ seq_nq, int H, int64_t capT, uint16_t* ctx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int head = blockIdx.x, b = blockIdx.y, qg = blockIdx.z;   // heads fastest: the heads of one sequence (same 2-KiB q / k rows) run together
+    const int nq = seq_nq[b];
+    if (qg * ADMA_QT * 32 >= nq) return;                   // block-uniform (nq == 0 included)
+    attn_dma_body(q, k, vT, ldv, seq_off[b], seq_nk[b], nq, H, head, qg, capT, ctx, smem);
 }
 
 // pooling + L2 normalisation: one block per sequence.  Mean pooling: wave w sums the tokens t = w, w+4, ... (8-byte loads of the (hi, lo)
@@ -977,7 +1161,7 @@ static void free_ws(Encoder* e) {
 }
 
 static int ensure_ws(Encoder* e, int B, int S) {
-    const int64_t maxT = (int64_t)B * (S + 4);
+    const int64_t maxT = (int64_t)B * (S + 8);
     const int H = e->cfg.hidden, FF = e->cfg.intermediate;
     if (!e->d_T) {
         KR_TRY(dmalloc(&e->d_T, sizeof(int))); KR_TRY(dmalloc(&e->d_err, sizeof(int)));
@@ -1063,6 +1247,13 @@ static int launch_attn(const Encoder* e, int B, int cap, int nqt, hipStream_t st
     const int qgroups = (nqt + (4 / HPB) - 1) / (4 / HPB);   // blocks per (sequence, head group): 4 / HPB q-tiles each
     hipLaunchKernelGGL((k_attn_lds<HPB>), dim3((unsigned)((heads + HPB - 1) / HPB), (unsigned)B, (unsigned)qgroups), dim3(256), lds, st, e->q, e->k, e->vT,
                        e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, kchunk, e->ctx);
+    return 0;
+}
+
+static int launch_attn_dma(const Encoder* e, int B, int nqt, hipStream_t st) {
+    const int qgroups = (nqt + ADMA_QT - 1) / ADMA_QT;       // blocks per (sequence, head): 8 q-tiles each
+    hipLaunchKernelGGL(k_attn_dma, dim3((unsigned)e->cfg.heads, (unsigned)B, (unsigned)qgroups), dim3(ADMA_THREADS), ADMA_LDS, st, e->q, e->k, e->vT, e->ldv,
+                       e->seq_off, e->seq_nk, e->seq_nq, e->cfg.hidden, e->capT, e->ctx);
     return 0;
 }
 
@@ -1237,9 +1428,9 @@ int enc_load_weight(void* h, const char* hf_name, const float* data, int64_t num
     } else {
         LayerW& l = e->L[(slot - T_LAYER0) / L_COUNT];
         switch ((slot - T_LAYER0) % L_COUNT) {
-            // 1/sqrt(d_h) = 1/8 is folded into the query projection (exact: power of two)
-            case L_QW: to_bf16(l.wqkv, 0.125f); break;
-            case L_QB: to_f32(l.bqkv, 0.125f); break;
+            // log2(e) / sqrt(d_h) is folded into the query projection: the attention scores come out in log2 units and the softmax is a bare exp2
+            case L_QW: to_bf16(l.wqkv, 0.125f * 1.4426950408889634f); break;
+            case L_QB: to_f32(l.bqkv, 0.125f * 1.4426950408889634f); break;
             case L_KW: to_bf16(l.wqkv + H * H, 1.f); break;
             case L_KB: to_f32(l.bqkv + H, 1.f); break;
             case L_VW: to_bf16(l.wqkv + 2 * H * H, 1.f); break;
@@ -1284,10 +1475,13 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
     const int H = e->cfg.hidden, FF = e->cfg.intermediate;
     const float eps = e->cfg.ln_eps;
     hipLaunchKernelGGL(k_seq_len, dim3(B), dim3(64), 0, st, e->d_mask, B, S, e->seq_nk, e->seq_has0);
-    hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(64), 0, st, e->seq_nk, e->seq_has0, B, pool, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->d_err);
-    hipLaunchKernelGGL(k_fill_tokens, dim3(B), dim3(64), 0, st, e->d_ids, e->d_mask, S, e->cfg.vocab, e->seq_off, e->seq_nk, e->seq_nq, e->tok_id,
+    const int nqt_max = (S + (pool == KR_POOL_CLS ? 1 : 0) + 31) / 32;             // q-tiles of the longest possible sequence
+    const bool long_seq = nqt_max > 4 && !getenv("KIRAG_AMD_ATTN_LDS");            // > 128 tokens: the LDS-DMA attention kernel (KIRAG_AMD_ATTN_LDS=1: A/B against the register-staged one)
+    const int align = long_seq ? 8 : 4;                                            // sequence offsets: multiple of 8 tokens so that V^T chunks start 16-B aligned
+    hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(64), 0, st, e->seq_nk, e->seq_has0, B, pool, align, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->d_err);
+    hipLaunchKernelGGL(k_fill_tokens, dim3(B), dim3(64), 0, st, e->d_ids, e->d_mask, S, e->cfg.vocab, align, e->seq_off, e->seq_nk, e->seq_nq, e->tok_id,
                        e->tok_pos, e->d_err);
-    const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + 3) & ~3);   // upper bound of the packed token count (each sequence is padded to 4)
+    const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + align - 1) & ~(align - 1));   // upper bound of the packed token count (each sequence is padded to `align`)
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
     const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu * 4u);   // k_ln is grid-stride (its parameters stay in registers across rows)
     const char* ln8e = getenv("KIRAG_AMD_LN8"); const bool ln8 = ln8e && atoi(ln8e) != 0;      // A/B knob: the 8-byte-access LayerNorm of round 1
@@ -1304,8 +1498,9 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
         KR_TRY(launch_proj(EPI_QKV, a, maxT, e->num_cu, e->device, st));
         {
             const int cap = (int)round_up(S, 32);
-            const int nqt = (S + (pool == KR_POOL_CLS ? 1 : 0) + 31) / 32;      // q-tiles of the longest possible sequence
-            if (nqt >= 3) KR_TRY(launch_attn<1>(e, B, cap, nqt, st));
+            const int nqt = nqt_max;
+            if (long_seq) KR_TRY(launch_attn_dma(e, B, nqt, st));
+            else if (nqt >= 3) KR_TRY(launch_attn<1>(e, B, cap, nqt, st));
             else if (nqt == 2) KR_TRY(launch_attn<2>(e, B, cap, nqt, st));
             else KR_TRY(launch_attn<4>(e, B, cap, nqt, st));
         }
@@ -1336,7 +1531,7 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
 // which cannot be captured), ordered against the caller's stream by events.  Any failure falls back to eager launches for good.
 constexpr int64_t GRAPH_MAX_TOKENS = 4096;
 static int run_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
-    const int64_t maxT = (int64_t)B * (S + 4);
+    const int64_t maxT = (int64_t)B * (S + 8);
     if (e->graphs_off || maxT > GRAPH_MAX_TOKENS) return enqueue_forward(e, B, S, pool, st);
     const uint64_t key = ((uint64_t)B << 32) | ((uint64_t)S << 8) | (uint64_t)pool;
     GraphEntry* ent = nullptr;

@@ -170,7 +170,7 @@ def test_g10_full_size_long_sequences_big_batch_left_padding_and_outlier_weights
     assert score <= bar and cos <= (5e-5 if wname != "out60" else 5e-4) and err <= (3e-3 if wname != "out60" else 3e-2), (wname, score, err, cos)
     if wname == "benign":                                       # every mode is fine on weights without outlier channels
         for m, (sc, er, co) in res.items():
-            assert sc <= G10_TOL and co <= 5e-5 and er <= 3e-3, (m, sc, er, co)
+            assert sc <= G10_TOL and co <= (5e-5 if m[0] == "f16" else 1e-4) and er <= 3e-3, (m, sc, er, co)   # bf16: 1 - cos ~ 5e-5 (CLS pooling)
     # the default mode is the most accurate one on every weight set (what justifies paying for it)
     assert score <= min(r[0] for r in res.values()) * 1.5 + 1e-5, res
 
