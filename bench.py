@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-encoder", action="store_true", help="search-only step (query vectors pre-computed)")
     ap.add_argument("--encoder-dtype", default=None, choices=["bf16", "f16"], help="16-bit operand type of the encoder (default: the library's, f16)")
     ap.add_argument("--residual-lo", default=None, type=int, choices=[0, 1], help="encoder residual stream with / without its low half (default: the library's, 1)")
+    ap.add_argument("--encode-split", default="batch", choices=["batch", "queries"],
+                    help="N > 1: 'batch' = rank r encodes the whole query batch of every W-th step (one all-gather of W batches per W steps); "
+                         "'queries' = every rank encodes 1/W of every batch (round-2 schedule)")
     ap.add_argument("--sync-search", action="store_true", help="one GPU: use the blocking kr_index_search per step instead of search_async + finish")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000, help="corpus rows of the CPU search baseline (BASELINE.md: the 1M point)")
@@ -244,6 +247,24 @@ def main():
         inflight.append(j)
         step_async.keep = qv                                                          # the queries stay alive until finish()
 
+    # N > 1, default schedule ("batch"): W consecutive steps form a block — rank r ENCODES the whole query batch of step (block * W + r) (the full
+    # 1000-query forward runs at the large-batch MFMA rate; a 1/W slice of 125 queries does not: 715 vs 1030 TFLOP/s), ONE all-gather moves the W
+    # batches' query vectors (W x 4 MB over xGMI), then every rank searches the W batches one after the other on its corpus shard (all-gather of the
+    # per-shard top-k + device merge per batch, as before).  Same total work, same results; what changes is which rank encodes what.
+    # --encode-split queries keeps the round-2 schedule (every rank encodes 1/W of every batch).
+    q_blk = torch.empty((world, nq, d), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def block_of_steps(first, count):
+        """steps [first, first + count), count <= W; returns nothing (results land in the searcher's pinned buffers, as in step())"""
+        if encoder is not None:
+            if rank < count:
+                q_mine = encoder.forward(tok_ids, tok_mask, 0)           # the batch of step first + rank
+            else:
+                q_mine = q_blk[rank]                                      # no batch to encode in a partial last block: contributes its old buffer
+            dist.all_gather_into_tensor(q_blk.view(world * nq, d), q_mine.contiguous())
+        for s_i in range(count):
+            searcher.search(q_blk[s_i] if encoder is not None else q_vec, k)
+
     def step():
         if encoder is None:
             qv = q_vec
@@ -259,8 +280,13 @@ def main():
         return searcher.search(qv, k)
 
     use_async = world == 1 and not args.sync_search
-    for i in range(args.warmup):
-        step_async(i) if use_async else step()
+    use_blocks = world > 1 and args.encode_split == "batch"
+    if use_blocks:
+        for b0 in range(0, args.warmup, world):
+            block_of_steps(b0, min(world, args.warmup - b0))
+    else:
+        for i in range(args.warmup):
+            step_async(i) if use_async else step()
     drain()
     torch.cuda.synchronize()
     index.stats(reset=True)
@@ -270,7 +296,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     coarse_log.clear()
-    for i in range(args.steps):
+    if use_blocks:
+        for b0 in range(0, args.steps, world):
+            block_of_steps(b0, min(world, args.steps - b0))
+            coarse_ms.append(index.stats()["last_coarse_ms"])
+    for i in range(0 if use_blocks else args.steps):
         if use_async:
             step_async(i)
         else:
@@ -349,8 +379,11 @@ def main():
                                    f"{world} GPU(s)), {nq}-query batch ({args.query_tokens} tokens) encoded then searched, brute-force top-{k}",
                        "rows_per_gpu": n, "dim": d, "queries": nq, "topk": k, "total_rows": total, "corpus_dist": args.corpus_dist,
                        "encoder_in_step": encoder is not None,
-                       "parallelism": f"corpus row-sharded x{world}, query batch split x{world} for encoding, all-gather of query vectors and of "
-                                      f"per-shard top-k, device merge"},
+                       "parallelism": (f"corpus row-sharded x{world}; rank r encodes the whole query batch of steps r, r + {world}, ... (one all-gather of {world} "
+                                       f"batches' query vectors per {world} steps); per batch: all-gather of per-shard top-k, device merge"
+                                       if use_blocks else
+                                       f"corpus row-sharded x{world}, query batch split x{world} for encoding, all-gather of query vectors and of "
+                                       f"per-shard top-k, device merge")},
             "roofline": {"bound": "mfma", "achieved": flops / coarse / 1e12, "peak": PEAK_MFMA_DENSE_16BIT / 1e12, "unit": "TFLOP/s",
                          "frac": flops / coarse / PEAK_MFMA_DENSE_16BIT, "traffic": traffic, "traffic_unit": "GB per scan (FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src, "algorithmic_gb": n * d * 2 / 1e9, "kernel": "k_coarse", "rows_scanned": n,

@@ -50,12 +50,18 @@ struct BF16 {
     static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
 };
 struct F16 {
     static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
     static __device__ __forceinline__ float to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
     static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
 

@@ -84,7 +84,7 @@ struct Encoder {
     int *seq_off = nullptr, *seq_nk = nullptr, *seq_nq = nullptr, *seq_cls = nullptr, *seq_has0 = nullptr, *d_T = nullptr, *d_err = nullptr;
     int *tok_id = nullptr, *tok_pos = nullptr;
     float *out = nullptr;
-    uint16_t *xlo = nullptr;   // low half of the residual stream (see file header): written by every LayerNorm with use_lo, else by the last one only
+    uint8_t *xlo = nullptr;    // low half of the residual stream, one byte per element (lo_encode): written by every LayerNorm with use_lo, else by the last one only
     bool use_lo = false;       // KIRAG_AMD_RESIDUAL_LO=1 at kr_encoder_create
     uint16_t *y = nullptr, *xb = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *ctx = nullptr, *h = nullptr;
     int lastB = 0, lastS = 0;
@@ -189,157 +189,6 @@ __global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ 
     if (lane < padded - n) { tok_id[o + n + lane] = 0; tok_pos[o + n + lane] = 0; }
 }
 
-// LayerNorm of one row held as up to 8 float4 per lane (H <= 2048); writes fp32 and bf16 copies
-__device__ __forceinline__ void ln_row_store(float4 (&v)[8], int H, int lane, const float* __restrict__ g, const float* __restrict__ bta, float eps,
-                                             uint16_t* __restrict__ xlo_row, uint16_t* __restrict__ xb_row) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) if (lane * 4 + j * 256 < H) s += v[j].x + v[j].y + v[j].z + v[j].w;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-    const float mu = s / (float)H;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        if (lane * 4 + j * 256 < H) {
-            const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
-            q += a * a + b * b + c * c + d * d;
-        }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
-    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = lane * 4 + j * 256;
-        if (i < H) {
-            const float4 gg = *reinterpret_cast<const float4*>(g + i);
-            const float4 bb = *reinterpret_cast<const float4*>(bta + i);
-            float4 o;
-            o.x = (v[j].x - mu) * rstd * gg.x + bb.x; o.y = (v[j].y - mu) * rstd * gg.y + bb.y;
-            o.z = (v[j].z - mu) * rstd * gg.z + bb.z; o.w = (v[j].w - mu) * rstd * gg.w + bb.w;
-            // o = hi + lo with hi = bf16(o), lo = bf16(o - hi): |o - (hi + lo)| <= 2^-18 |o|
-            ushort4 ob, ol;
-            ob.x = ET::from_f32(o.x); ob.y = ET::from_f32(o.y); ob.z = ET::from_f32(o.z); ob.w = ET::from_f32(o.w);
-            ol.x = ET::from_f32(o.x - ET::to_f32(ob.x)); ol.y = ET::from_f32(o.y - ET::to_f32(ob.y));
-            ol.z = ET::from_f32(o.z - ET::to_f32(ob.z)); ol.w = ET::from_f32(o.w - ET::to_f32(ob.w));
-            *reinterpret_cast<ushort4*>(xb_row + i) = ob;
-            if (xlo_row) *reinterpret_cast<ushort4*>(xlo_row + i) = ol;      // optional low half (kernel-uniform branch)
-        }
-    }
-}
-
-// the same with gamma / beta already in registers (k_ln keeps them across its rows); NCH 256-element steps cover a row (H <= 256 NCH).
-// The reductions add the same values in the same order as the 8-step version (steps beyond H contribute nothing there).
-template <int NCH>
-__device__ __forceinline__ void ln_row_store_regs(float4 (&v)[NCH], int H, int lane, const float4 (&g)[NCH], const float4 (&bta)[NCH], float eps,
-                                                  uint16_t* __restrict__ xlo_row, uint16_t* __restrict__ xb_row) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) if (lane * 4 + j * 256 < H) s += v[j].x + v[j].y + v[j].z + v[j].w;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-    const float mu = s / (float)H;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-        if (lane * 4 + j * 256 < H) {
-            const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
-            q += a * a + b * b + c * c + d * d;
-        }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
-    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int i = lane * 4 + j * 256;
-        if (i < H) {
-            const float4 gg = g[j], bb = bta[j];
-            float4 o;
-            o.x = (v[j].x - mu) * rstd * gg.x + bb.x; o.y = (v[j].y - mu) * rstd * gg.y + bb.y;
-            o.z = (v[j].z - mu) * rstd * gg.z + bb.z; o.w = (v[j].w - mu) * rstd * gg.w + bb.w;
-            ushort4 ob, ol;
-            ob.x = ET::from_f32(o.x); ob.y = ET::from_f32(o.y); ob.z = ET::from_f32(o.z); ob.w = ET::from_f32(o.w);
-            *reinterpret_cast<ushort4*>(xb_row + i) = ob;
-            if (xlo_row) {   // optional low half: o = hi + lo with lo = bf16(o - hi), |o - (hi + lo)| <= 2^-18 |o|
-                ol.x = ET::from_f32(o.x - ET::to_f32(ob.x)); ol.y = ET::from_f32(o.y - ET::to_f32(ob.y));
-                ol.z = ET::from_f32(o.z - ET::to_f32(ob.z)); ol.w = ET::from_f32(o.w - ET::to_f32(ob.w));
-                *reinterpret_cast<ushort4*>(xlo_row + i) = ol;
-            }
-        }
-    }
-}
-
-// embeddings: word[id] + position[pos] + token_type[0] -> LayerNorm       (one wave per token)
-__global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id, const int* __restrict__ tok_pos, const int* __restrict__ Tp,
-                                                  const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
-                                                  const float* __restrict__ g, const float* __restrict__ bta, float eps, int H,
-                                                  uint16_t* __restrict__ xlo, uint16_t* __restrict__ xb) {
-    const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= *Tp) return;
-    const float* w = word + (int64_t)tok_id[t] * H;
-    const float* p = pos + (int64_t)tok_pos[t] * H;
-    float4 v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = lane * 4 + j * 256;
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < H) {
-            const float4 a = *reinterpret_cast<const float4*>(w + i);
-            const float4 b = *reinterpret_cast<const float4*>(p + i);
-            const float4 c = *reinterpret_cast<const float4*>(type + i);
-            v[j] = make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
-        }
-    }
-    ln_row_store(v, H, lane, g, bta, eps, xlo ? xlo + t * H : nullptr, xb + t * H);
-}
-
-// LayerNorm(y + ybias + (xb + xlo)) -> xb (, xlo)     y holds the dense output as bf16, xb (+ xlo) the residual stream, updated in place.
-// One wave per token row, grid-stride: gamma, beta and the dense bias (3 x 4 KiB of fp32 per row if re-read: twice the row's own 6 KiB of HBM
-// traffic through the CU's L1) are loaded ONCE per wave into registers and reused for all its rows, and the next row's loads are issued before the
-// current row is reduced (two rows in flight per wave).
-template <int NCH>
-__global__ __launch_bounds__(256) void k_ln(const uint16_t* __restrict__ y, const float* __restrict__ ybias, const int* __restrict__ Tp, const float* __restrict__ g,
-                                            const float* __restrict__ bta, float eps, int H, const uint16_t* xlo_in, uint16_t* xlo, uint16_t* xb) {
-    const int lane = threadIdx.x & 63;
-    const int T = *Tp;
-    float4 gg[NCH], bb[NCH], yb[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int i = lane * 4 + j * 256;
-        gg[j] = bb[j] = yb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < H) {
-            gg[j] = *reinterpret_cast<const float4*>(g + i); bb[j] = *reinterpret_cast<const float4*>(bta + i);
-            yb[j] = *reinterpret_cast<const float4*>(ybias + i);       // bias of the dense layer that produced y
-        }
-    }
-    const int64_t step = (int64_t)gridDim.x * 4;
-    int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    ushort4 a[NCH], rh[NCH], rl[NCH];
-    auto load_row = [&](int64_t row) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int i = lane * 4 + j * 256;
-            a[j] = rh[j] = rl[j] = make_ushort4(0, 0, 0, 0);
-            if (i < H && row < T) {
-                a[j] = *reinterpret_cast<const ushort4*>(y + row * H + i);
-                rh[j] = *reinterpret_cast<const ushort4*>(xb + row * H + i);
-                if (xlo_in) rl[j] = *reinterpret_cast<const ushort4*>(xlo_in + row * H + i);
-            }
-        }
-    };
-    load_row(t);
-    for (; t < T; t += step) {
-        float4 v[NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j)
-            v[j] = make_float4((ET::to_f32(a[j].x) + yb[j].x) + (ET::to_f32(rh[j].x) + ET::to_f32(rl[j].x)), (ET::to_f32(a[j].y) + yb[j].y) + (ET::to_f32(rh[j].y) + ET::to_f32(rl[j].y)),
-                               (ET::to_f32(a[j].z) + yb[j].z) + (ET::to_f32(rh[j].z) + ET::to_f32(rl[j].z)), (ET::to_f32(a[j].w) + yb[j].w) + (ET::to_f32(rh[j].w) + ET::to_f32(rl[j].w)));
-        load_row(t + step);                                   // next row's loads in flight while this one is reduced and stored
-        ln_row_store_regs<NCH>(v, H, lane, gg, bb, eps, xlo ? xlo + t * H : nullptr, xb + t * H);
-    }
-}
-
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
@@ -367,13 +216,99 @@ __device__ __forceinline__ float unpack_hi16(unsigned int w) {
 #endif
 }
 
+// Low half of the residual stream: x = hi + lo with hi = the 16-bit operand the GEMMs read and lo = (x - hi) in units of ulp(hi) / 256, stored as ONE byte
+// (biased by 128): 19 significand bits with f16 operands, 16 with bf16.  Round 2 kept lo as a second 16-bit word (10 B per element through a LayerNorm
+// instead of 6); the byte makes it 8 B — measured on the emulation of the rounding points (tools/precision_probe.py, G10 out3 / out16) the worst score
+// error is unchanged (9.1e-5 vs 8.6e-5 / 1.2e-3 vs 9.5e-4).
+#ifdef KR_ENC_BUILD_F16
+constexpr int LO_MANT = 10, LO_EMIN = 103;      // f16: 10 stored mantissa bits; values below 2^-24 (fp32 exponent field 103) are treated as that magnitude
+#else
+constexpr int LO_MANT = 7, LO_EMIN = 32;
+#endif
+__device__ __forceinline__ unsigned int lo_exp(float hf) {
+    const unsigned int e = (__builtin_bit_cast(unsigned int, hf) >> 23) & 0xffu;
+    return e < (unsigned)LO_EMIN ? (unsigned)LO_EMIN : e;
+}
+__device__ __forceinline__ unsigned int lo_encode(float o, float hf) {
+    const float scale = __builtin_bit_cast(float, (262u + LO_MANT - lo_exp(hf)) << 23);      // 256 / ulp(hi)
+    const float t = fmaxf(fminf(rintf((o - hf) * scale), 127.f), -128.f);                   // |o - hi| <= ulp / 2; NaN -> 127 (hi is NaN too)
+    return (unsigned int)((int)t + 128) & 0xffu;
+}
+__device__ __forceinline__ float lo_decode(unsigned int byte, float hf) {
+    const float unit = __builtin_bit_cast(float, (lo_exp(hf) - 8u - LO_MANT) << 23);          // ulp(hi) / 256
+    return fmaf((float)(int)byte - 128.f, unit, hf);
+}
+
+// LayerNorm of one row held as up to 8 float4 per lane (H <= 2048); writes fp32 and bf16 copies
+__device__ __forceinline__ void ln_row_store(float4 (&v)[8], int H, int lane, const float* __restrict__ g, const float* __restrict__ bta, float eps,
+                                             uint8_t* __restrict__ xlo_row, uint16_t* __restrict__ xb_row) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (lane * 4 + j * 256 < H) s += v[j].x + v[j].y + v[j].z + v[j].w;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    const float mu = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (lane * 4 + j * 256 < H) {
+            const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+            q += a * a + b * b + c * c + d * d;
+        }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = lane * 4 + j * 256;
+        if (i < H) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + i);
+            const float4 bb = *reinterpret_cast<const float4*>(bta + i);
+            float4 o;
+            o.x = (v[j].x - mu) * rstd * gg.x + bb.x; o.y = (v[j].y - mu) * rstd * gg.y + bb.y;
+            o.z = (v[j].z - mu) * rstd * gg.z + bb.z; o.w = (v[j].w - mu) * rstd * gg.w + bb.w;
+            ushort4 ob;
+            ob.x = ET::from_f32(o.x); ob.y = ET::from_f32(o.y); ob.z = ET::from_f32(o.z); ob.w = ET::from_f32(o.w);
+            *reinterpret_cast<ushort4*>(xb_row + i) = ob;
+            if (xlo_row)                                                      // optional low half (kernel-uniform branch): one byte per element
+                *reinterpret_cast<unsigned int*>(xlo_row + i) = lo_encode(o.x, ET::to_f32(ob.x)) | (lo_encode(o.y, ET::to_f32(ob.y)) << 8) |
+                                                                (lo_encode(o.z, ET::to_f32(ob.z)) << 16) | (lo_encode(o.w, ET::to_f32(ob.w)) << 24);
+        }
+    }
+}
+
+// embeddings: word[id] + position[pos] + token_type[0] -> LayerNorm       (one wave per token)
+__global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id, const int* __restrict__ tok_pos, const int* __restrict__ Tp,
+                                                  const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
+                                                  const float* __restrict__ g, const float* __restrict__ bta, float eps, int H,
+                                                  uint8_t* __restrict__ xlo, uint16_t* __restrict__ xb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= *Tp) return;
+    const float* w = word + (int64_t)tok_id[t] * H;
+    const float* p = pos + (int64_t)tok_pos[t] * H;
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = lane * 4 + j * 256;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < H) {
+            const float4 a = *reinterpret_cast<const float4*>(w + i);
+            const float4 b = *reinterpret_cast<const float4*>(p + i);
+            const float4 c = *reinterpret_cast<const float4*>(type + i);
+            v[j] = make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
+        }
+    }
+    ln_row_store(v, H, lane, g, bta, eps, xlo ? xlo + t * H : nullptr, xb + t * H);
+}
+
 // k_ln with 16-byte accesses: a lane owns 8 consecutive elements per 512-element step (one global_load_dwordx4 per tensor and step instead of two
 // 8-byte ones: 8-byte accesses reach 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md).  NS 512-element steps cover a row (H <= 512 NS, H % 8 == 0).
 // Same arithmetic per element as k_ln; the row sums add the elements in a different lane order (tolerances of DESIGN.md section 2 unaffected; rows stay
 // independent of the batch).  KIRAG_AMD_LN8=1 selects the 8-byte kernel (A/B).
 template <int NS>
 __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, const float* __restrict__ ybias, const int* __restrict__ Tp, const float* __restrict__ g,
-                                              const float* __restrict__ bta, float eps, int H, const uint16_t* xlo_in, uint16_t* xlo, uint16_t* xb) {
+                                              const float* __restrict__ bta, float eps, int H, const uint8_t* xlo_in, uint8_t* xlo, uint16_t* xb) {
     const int lane = threadIdx.x & 63;
     const int T = *Tp;
     float gg[NS][8], bb[NS][8], yb[NS][8];
@@ -394,16 +329,16 @@ __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, co
     }
     const int64_t step = (int64_t)gridDim.x * 4;
     int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    uint4 a[NS], rh[NS], rl[NS];
+    uint4 a[NS], rh[NS]; uint2 rl[NS];
     auto load_row = [&](int64_t row) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int i = lane * 8 + j * 512;
-            a[j] = rh[j] = rl[j] = make_uint4(0u, 0u, 0u, 0u);
+            a[j] = rh[j] = make_uint4(0u, 0u, 0u, 0u); rl[j] = make_uint2(0x80808080u, 0x80808080u);      // byte 128 = a zero low half
             if (i < H && row < T) {
                 a[j] = *reinterpret_cast<const uint4*>(y + row * H + i);
                 rh[j] = *reinterpret_cast<const uint4*>(xb + row * H + i);
-                if (xlo_in) rl[j] = *reinterpret_cast<const uint4*>(xlo_in + row * H + i);
+                if (xlo_in) rl[j] = *reinterpret_cast<const uint2*>(xlo_in + row * H + i);
             }
         }
     };
@@ -414,11 +349,11 @@ __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, co
         float v[NS][8];
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            const unsigned int aw[4] = {a[j].x, a[j].y, a[j].z, a[j].w}, hw[4] = {rh[j].x, rh[j].y, rh[j].z, rh[j].w}, lw[4] = {rl[j].x, rl[j].y, rl[j].z, rl[j].w};
+            const unsigned int aw[4] = {a[j].x, a[j].y, a[j].z, a[j].w}, hw[4] = {rh[j].x, rh[j].y, rh[j].z, rh[j].w}, lw[2] = {rl[j].x, rl[j].y};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                v[j][2 * c] = (lo16(aw[c]) + yb[j][2 * c]) + (lo16(hw[c]) + lo16(lw[c]));
-                v[j][2 * c + 1] = (hi16(aw[c]) + yb[j][2 * c + 1]) + (hi16(hw[c]) + hi16(lw[c]));
+            for (int c = 0; c < 4; ++c) {   // elements 2c, 2c + 1: low-half bytes 2c, 2c + 1 of the 8
+                v[j][2 * c] = (lo16(aw[c]) + yb[j][2 * c]) + lo_decode((lw[c >> 1] >> (16 * (c & 1))) & 0xffu, lo16(hw[c]));
+                v[j][2 * c + 1] = (hi16(aw[c]) + yb[j][2 * c + 1]) + lo_decode((lw[c >> 1] >> (16 * (c & 1) + 8)) & 0xffu, hi16(hw[c]));
             }
         }
         load_row(t + step);                                   // next row's loads in flight while this one is reduced and stored
@@ -441,7 +376,7 @@ __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, co
         for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
         const float rstd = 1.0f / sqrtf(q / (float)H + eps);
         uint16_t* xb_row = xb + t * H;
-        uint16_t* xlo_row = xlo ? xlo + t * H : nullptr;
+        uint8_t* xlo_row = xlo ? xlo + t * H : nullptr;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int i = lane * 8 + j * 512;
@@ -453,10 +388,12 @@ __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, co
 #pragma unroll
                 for (int c = 0; c < 4; ++c) ob[c] = pack_bf16x2(o[2 * c], o[2 * c + 1]);
                 *reinterpret_cast<uint4*>(xb_row + i) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
-                if (xlo_row) {   // optional low half: o = hi + lo with lo = bf16(o - hi)
+                if (xlo_row) {   // optional low half: one byte per element (lo_encode)
+                    ol[0] = ol[1] = 0u;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) ol[c] = pack_bf16x2(o[2 * c] - lo16(ob[c]), o[2 * c + 1] - hi16(ob[c]));
-                    *reinterpret_cast<uint4*>(xlo_row + i) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+                    for (int c = 0; c < 4; ++c)
+                        ol[c >> 1] |= (lo_encode(o[2 * c], lo16(ob[c])) | (lo_encode(o[2 * c + 1], hi16(ob[c])) << 8)) << (16 * (c & 1));
+                    *reinterpret_cast<uint2*>(xlo_row + i) = make_uint2(ol[0], ol[1]);
                 }
             }
         }
@@ -1073,7 +1010,7 @@ __global__ __launch_bounds__(ADMA_THREADS, 2) void k_attn_dma(const uint16_t* q,
 
 // pooling + L2 normalisation: one block per sequence.  Mean pooling: wave w sums the tokens t = w, w+4, ... (8-byte loads of the (hi, lo)
 // stream, 4 columns per lane and step), the four partial sums are combined in a fixed order (w = 0..3), so the result is deterministic.
-__global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, const uint16_t* __restrict__ xlo, const int* __restrict__ seq_off, const int* __restrict__ seq_nk,
+__global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, const uint8_t* __restrict__ xlo, const int* __restrict__ seq_off, const int* __restrict__ seq_nk,
                                               const int* __restrict__ seq_cls, int H, int pool, float* __restrict__ out) {
     __shared__ float part[4][2048];   // H <= 2048
     __shared__ float red[4];
@@ -1088,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, c
     // four of the wave's tokens per step: all their loads are issued before the first add (a long sequence is a chain of memory round trips for its
     // one block); the adds keep the order t, t+4, t+8, ... so the result does not depend on the unrolling
     for (int t = t_begin; t < t_end; t += 16) {
-        ushort4 hi[4][8], lo[4][8];
+        ushort4 hi[4][8]; unsigned int lo[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -1096,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, c
                 const int i = lane * 4 + j * 256;
                 if (i < H && t + 4 * u < t_end) {
                     hi[u][j] = *reinterpret_cast<const ushort4*>(xb + (off + t + 4 * u) * H + i);
-                    lo[u][j] = xlo ? *reinterpret_cast<const ushort4*>(xlo + (off + t + 4 * u) * H + i) : make_ushort4(0, 0, 0, 0);
+                    lo[u][j] = xlo ? *reinterpret_cast<const unsigned int*>(xlo + (off + t + 4 * u) * H + i) : 0x80808080u;
                 }
             }
 #pragma unroll
@@ -1105,8 +1042,8 @@ __global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, c
             for (int j = 0; j < 8; ++j) {
                 const int i = lane * 4 + j * 256;
                 if (i < H && t + 4 * u < t_end) {
-                    acc[j].x += ET::to_f32(hi[u][j].x) + ET::to_f32(lo[u][j].x); acc[j].y += ET::to_f32(hi[u][j].y) + ET::to_f32(lo[u][j].y);
-                    acc[j].z += ET::to_f32(hi[u][j].z) + ET::to_f32(lo[u][j].z); acc[j].w += ET::to_f32(hi[u][j].w) + ET::to_f32(lo[u][j].w);
+                    acc[j].x += lo_decode(lo[u][j] & 0xffu, ET::to_f32(hi[u][j].x)); acc[j].y += lo_decode((lo[u][j] >> 8) & 0xffu, ET::to_f32(hi[u][j].y));
+                    acc[j].z += lo_decode((lo[u][j] >> 16) & 0xffu, ET::to_f32(hi[u][j].z)); acc[j].w += lo_decode(lo[u][j] >> 24, ET::to_f32(hi[u][j].w));
                 }
             }
     }
@@ -1156,7 +1093,7 @@ static void free_ws(Encoder* e) {
                     e->xb, e->q, e->k, e->vT, e->ctx, e->h};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     e->d_ids = e->d_mask = nullptr; e->seq_off = e->seq_nk = e->seq_nq = e->seq_cls = e->seq_has0 = nullptr; e->tok_id = e->tok_pos = nullptr;
-    e->out = nullptr; e->xlo = e->y = e->xb = e->q = e->k = e->vT = e->ctx = e->h = nullptr;
+    e->out = nullptr; e->xlo = nullptr; e->y = e->xb = e->q = e->k = e->vT = e->ctx = e->h = nullptr;
     e->capT = 0; e->capB = 0; e->capBS = 0;
 }
 
@@ -1176,7 +1113,7 @@ static int ensure_ws(Encoder* e, int B, int S) {
     KR_TRY(dmalloc(&e->d_ids, capBS * 8)); KR_TRY(dmalloc(&e->d_mask, capBS * 8));
     KR_TRY(dmalloc(&e->seq_off, capB * 4)); KR_TRY(dmalloc(&e->seq_nk, capB * 4)); KR_TRY(dmalloc(&e->seq_nq, capB * 4)); KR_TRY(dmalloc(&e->seq_cls, capB * 4)); KR_TRY(dmalloc(&e->seq_has0, capB * 4));
     KR_TRY(dmalloc(&e->tok_id, capT * 4)); KR_TRY(dmalloc(&e->tok_pos, capT * 4));
-    KR_TRY(dmalloc(&e->xlo, capT * H * 2)); KR_TRY(dmalloc(&e->y, capT * H * 2)); KR_TRY(dmalloc(&e->out, (size_t)capB * H * 4));
+    KR_TRY(dmalloc(&e->xlo, capT * H)); KR_TRY(dmalloc(&e->y, capT * H * 2)); KR_TRY(dmalloc(&e->out, (size_t)capB * H * 4));
     KR_TRY(dmalloc(&e->xb, capT * H * 2)); KR_TRY(dmalloc(&e->q, capT * H * 2)); KR_TRY(dmalloc(&e->k, capT * H * 2));
     e->ldv = capT + 64;   // slack: the last key tile of the last sequence may read up to 43 columns past T
     KR_TRY(dmalloc(&e->vT, (size_t)H * e->ldv * 2));
@@ -1484,11 +1421,10 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
     const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + align - 1) & ~(align - 1));   // upper bound of the packed token count (each sequence is padded to `align`)
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
     const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu * 4u);   // k_ln is grid-stride (its parameters stay in registers across rows)
-    const char* ln8e = getenv("KIRAG_AMD_LN8"); const bool ln8 = ln8e && atoi(ln8e) != 0;      // A/B knob: the 8-byte-access LayerNorm of round 1
-    auto ln_kernel = ln8 ? (H <= 1024 ? &k_ln<4> : &k_ln<8>) : (H <= 512 ? &k_ln16<1> : H <= 1024 ? &k_ln16<2> : &k_ln16<4>);
+    auto ln_kernel = H <= 512 ? &k_ln16<1> : H <= 1024 ? &k_ln16<2> : &k_ln16<4>;
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->use_lo ? e->xlo : nullptr, e->xb);
-    uint16_t* const lo_rw = e->use_lo ? e->xlo : nullptr;      // low half read / written by the inner LayerNorms
+    uint8_t* const lo_rw = e->use_lo ? e->xlo : nullptr;       // low half read / written by the inner LayerNorms
     for (const LayerW& l : e->L) {
         const bool last = (&l == &e->L.back());
         ProjArgs a{};
@@ -1659,16 +1595,22 @@ int enc_last_hidden(void* h, float* out, int B, int S) {
     std::vector<int> pos(T);
     std::vector<float> x((size_t)T * H);
     KR_HIP(hipMemcpy(pos.data(), e->tok_pos, (size_t)T * 4, hipMemcpyDeviceToHost));
-    {   // the residual stream is stored as a bf16 (hi, lo) pair
-        std::vector<uint16_t> hi((size_t)T * H), lo((size_t)T * H);
+    {   // the final hidden state is stored as (16-bit hi, 8-bit lo in units of ulp(hi) / 256): see lo_encode
+        std::vector<uint16_t> hi((size_t)T * H); std::vector<uint8_t> lo((size_t)T * H);
         KR_HIP(hipMemcpy(hi.data(), e->xb, hi.size() * 2, hipMemcpyDeviceToHost));
-        KR_HIP(hipMemcpy(lo.data(), e->xlo, lo.size() * 2, hipMemcpyDeviceToHost));
+        KR_HIP(hipMemcpy(lo.data(), e->xlo, lo.size(), hipMemcpyDeviceToHost));
 #ifdef KR_ENC_BUILD_F16
         auto f = [](uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); };
 #else
         auto f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float v; std::memcpy(&v, &u, 4); return v; };
 #endif
-        for (size_t i = 0; i < x.size(); ++i) x[i] = f(hi[i]) + f(lo[i]);
+        for (size_t i = 0; i < x.size(); ++i) {
+            const float hf = f(hi[i]);
+            uint32_t bits; std::memcpy(&bits, &hf, 4);
+            uint32_t ex = (bits >> 23) & 0xffu; if (ex < (uint32_t)LO_EMIN) ex = LO_EMIN;
+            const uint32_t ub = (ex - 8u - LO_MANT) << 23; float unit; std::memcpy(&unit, &ub, 4);
+            x[i] = hf + ((float)(int)lo[i] - 128.f) * unit;
+        }
     }
     std::vector<float> full((size_t)B * S * H, 0.f);
     for (int b = 0; b < B; ++b)

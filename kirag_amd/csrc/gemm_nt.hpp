@@ -483,7 +483,11 @@ __device__ __forceinline__ void gemm_nt_skinny(const uint16_t* __restrict__ A, i
 // =====================================================================================================================
 using ShapePP = GemmShape<256, 256, 2, 4>;
 
-template <class T, bool SWAP = false, bool A_NT = false, class Coord, class Epilogue>
+// M16 (experiment, tools/gemm_bench.hip only): the same loop on v_mfma_f32_16x16x32 — one 32-deep k-step per interval, 8 x 4 blocks of 16 x 16 per wave,
+// the same 12 ds_read_b128 and the same matrix-pipe cycles per interval (MI355X_MICROARCH.md, DVFS give-back item 7: the chip may hold a higher clock on
+// this shape).  The accumulators are handed to the epilogue in AccTile's storage with block (mi16, ni16) in v[mi16 >> 1][ni16 >> 1] registers
+// 8 (mi16 & 1) + 4 (ni16 & 1) .. + 3 — a layout no product epilogue understands.
+template <class T, bool SWAP = false, bool A_NT = false, bool M16 = false, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb,
                                                  int64_t N, int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
     using Shape = ShapePP;
@@ -578,11 +582,41 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
         acc.m_wave = grp * 128;
         acc.n_wave = wq * 64;
         acc.lane = lane;
+        f32x4 c16[M16 ? 8 : 1][M16 ? 4 : 1];
         // One interval = L(t,h) (fragments of k-half h, 4 DMA pieces, counted waits) + barrier + M(t,h) (16 MFMAs, nothing else).  The first interval of
         // an output tile is a separate instantiation (FIRST): its first k-step takes the inline constant 0 as the C operand, so the accumulators are never
         // zero-initialised (128 v_mov per wave and tile at the boundary, where nothing overlaps them).
         auto interval = [&](auto first_tag, const char* sa, const char* sb, int h, bool last) {
             constexpr bool FIRST = decltype(first_tag)::value;
+            if constexpr (M16) {
+                uint4 af16[8], bf16v[4];
+                const int r16 = lane & 15;
+                const int coff16 = ((4 * h + (lane >> 4)) ^ ((r16 >> 1) & 7)) << 4;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) bf16v[ni] = *reinterpret_cast<const uint4*>(sb + (wq * 64 + ni * 16 + r16) * 128 + coff16);
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) af16[mi] = *reinterpret_cast<const uint4*>(sa + (grp * 128 + mi * 16 + r16) * 128 + coff16);
+                if (h == 0) issue4(cx, false, xpiece); else issue4(cy, true, ypiece);
+                wait_vmcnt<4>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                        if (FIRST) c16[mi][ni] = SWAP ? T::mfma16(bf16v[ni], af16[mi], zero4) : T::mfma16(af16[mi], bf16v[ni], zero4);
+                        else c16[mi][ni] = SWAP ? T::mfma16(bf16v[ni], af16[mi], c16[mi][ni]) : T::mfma16(af16[mi], bf16v[ni], c16[mi][ni]);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(last && grp)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
             uint4 af[2][4], bf[2][2];
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
@@ -639,6 +673,14 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
         st_loop += st_t2 - st_t1;
         acc.fine_prev = st_t2;
 #endif
+        if constexpr (M16) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc.v[mi >> 1][ni >> 1][8 * (mi & 1) + 4 * (ni & 1) + e] = c16[mi][ni][e];
+        }
         epi(acc, m0, n0, nat);
 #ifdef KR_STAMP
         st_t0 = KR_STAMP_NOW();

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Per-rank work of `bench.py --gpus W` measured on ONE GPU (no collectives): for W in 1, 2, 4, 8 the rank's share of the strong-scaling job
-(5M x 1024 corpus / W rows resident, 1000 / W queries x 32 tokens through the encoder, all 1000 query vectors searched top-100 over the
-local shard, device merge of W lists + D2H of the result).  The sum of the stages bounds the step time of the W-GPU run from below (the two all-gathers, 4 MB of
-query vectors and 1.2 MB of results per rank, come on top).  Usage: python tools/scale_emulate.py [total_rows]"""
+(5M x 1024 corpus / W rows resident, all 1000 query vectors searched top-100 over the local shard, device merge of W lists + D2H of the result) under the
+two encode schedules of bench.py:
+  queries  every rank encodes 1000 / W queries of every batch (round 2)
+  batch    rank r encodes the WHOLE batch of every W-th step (default since round 3): per block of W steps one full-batch encode + W searches
+The two all-gathers cannot be measured on a one-GPU box; they are ESTIMATED (marked est.) as a ring all-gather at 100 GB/s per direction of the
+7 x 153 GB/s xGMI links plus 20 us of latency per collective: per step  queries: 4 MB of query vectors + 1.2 MB x W of results;  batch: 4 MB (its share
+of the W x 4 MB block gather) + 1.2 MB x W.  Usage: python tools/scale_emulate.py [total_rows]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -58,9 +62,17 @@ for world in (1, 2, 4, 8):
         torch.cuda.current_stream().synchronize()
         return pin_s.numpy().copy(), pin_i.numpy().copy()
     ms_m = timed(merge)[0] if world > 1 else 0.0
-    tot = ms_e + ms_s + ms_m
-    base = base or tot
-    print(f"W={world}: encode {mine} queries {ms_e:.2f} ms | search 1000 x {n} rows {ms_s:.2f} ms (coarse {coarse:.2f}) | device merge + D2H of the result {ms_m:.2f} ms | "
-          f"sum {tot:.2f} ms -> {nq / tot * 1e3:.0f} q/s, x{base / tot:.2f} vs W=1", flush=True)
+    if world == 1:
+        ms_full = ms_e                                         # the full-batch encode: what a rank pays once per W steps under the batch schedule
+    gather = lambda mb: 0.0 if world == 1 else (0.02 + mb * (world - 1) / world / 100.0)      # ms: ring all-gather of `mb` MB in total at 100 GB/s + 20 us
+    coll_q = gather(4.0) + gather(1.2 * world)                  # queries schedule, per step
+    coll_b = gather(4.0 * world) / world + gather(1.2 * world)  # batch schedule, per step
+    tot_q = ms_e + ms_s + ms_m
+    tot_b = ms_full / world + ms_s + ms_m
+    base = base or tot_q
+    print(f"W={world}: encode {mine} queries {ms_e:.2f} ms | search 1000 x {n} rows {ms_s:.2f} ms (coarse {coarse:.2f}) | device merge + D2H of the result {ms_m:.2f} ms\n"
+          f"      queries schedule: {tot_q:.2f} ms per step (x{base / tot_q:.2f}); with est. collectives {tot_q + coll_q:.2f} ms (x{base / (tot_q + coll_q):.2f})\n"
+          f"      batch schedule:   full-batch encode {ms_full:.2f} ms per {world} steps -> {tot_b:.2f} ms per step (x{base / tot_b:.2f}); "
+          f"with est. collectives {tot_b + coll_b:.2f} ms (x{base / (tot_b + coll_b):.2f})", flush=True)
     del ix
     torch.cuda.empty_cache()
