@@ -365,6 +365,16 @@ def main():
                 traffic = tj["hbm_bytes_per_scan"] / 1e9
                 traffic_src = os.path.relpath(cand, REPO)
                 break
+        # MFMA-pipe utilisation of the same kernel from the committed counter pass (tools/profile_round.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES
+        # GRBM_GUI_ACTIVE; tools/pmc_mfma.py): busy cycles of the matrix pipes / (kernel cycles x 1024 SIMDs)
+        mfma_busy, mfma_src = None, None
+        for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "mfma_busy.json")), reverse=True):
+            with open(cand) as f:
+                mj = json.load(f)
+            ent = [v for kname, v in mj.items() if "k_coarse" in kname and "false, false" in kname and "mfma_busy" in v]
+            if ent:
+                mfma_busy, mfma_src = ent[0]["mfma_busy"], os.path.relpath(cand, REPO)
+                break
         ms_step = dt / args.steps * 1e3
         coarse = float(np.mean(coarse_ms)) * 1e-3           # seconds per coarse scan (sum of its round launches)
         flops = 2.0 * nq * n * d                             # algorithmic: every query against every row of the shard
@@ -386,7 +396,8 @@ def main():
                                        f"per-shard top-k, device merge")},
             "roofline": {"bound": "mfma", "achieved": flops / coarse / 1e12, "peak": PEAK_MFMA_DENSE_16BIT / 1e12, "unit": "TFLOP/s",
                          "frac": flops / coarse / PEAK_MFMA_DENSE_16BIT, "traffic": traffic, "traffic_unit": "GB per scan (FETCH_SIZE x2 + WRITE_SIZE)",
-                         "traffic_source": traffic_src, "algorithmic_gb": n * d * 2 / 1e9, "kernel": "k_coarse", "rows_scanned": n,
+                         "traffic_source": traffic_src, "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src,
+                         "algorithmic_gb": n * d * 2 / 1e9, "kernel": "k_coarse", "rows_scanned": n,
                          "launch_ms": coarse * 1e3,
                          "note": "one 'launch' = one coarse scan of the shard = the sum of its k_coarse round launches (4 at 5M rows), HIP events "
                                  "around each launch on its stream; algorithmic FLOPs = 2*nq*rows*dim; the bf16 MFMA-only loop measured on this "

@@ -4,13 +4,11 @@
 // Layout.  The [B,S] batch is PACKED on the device: only positions with attention_mask != 0 become token rows
 // (sequence b owns rows [off_b, off_b + nq_b), off_b % 4 == 0; absolute position ids are kept per token), so the
 // projections run on sum(len) rows instead of B*S.  No host round trip: grids are sized for B*(S+4) rows and blocks
-// beyond the device-side total exit.  Residual stream = xb, bf16 (it is also the MFMA operand).  KIRAG_AMD_RESIDUAL_LO=1 adds xlo = bf16 of the
-// remainder (16 mantissa bits together, 4 B per element like fp32, only the hi half is re-read by the GEMMs).  Measured on the full-size goldens
-// (24 layers) the embedding error is set by the bf16 GEMM operands, not by the stream: rms 1.90e-4 with xlo vs 1.94e-4 without (e5 mean pooling), 2.3e-4
-// vs 3.0e-4 (bge CLS), largest cosine-score error among pairs 1.5e-4 vs 3.0e-4 (tolerance 1e-3) — while xlo is 40 % of the LayerNorm kernels' HBM
-// traffic (10 -> 6 B per element), and those are 14 % of the forward.  Default: off (only the last LayerNorm writes xlo, for the pooling and
-// kr_encoder_last_hidden).  MFMA operands bf16 (xb, q, k, vT, ctx, h),
-// fp32 accumulation everywhere.
+// beyond the device-side total exit.  Residual stream = xb, 16-bit (it is also the MFMA operand) + by default xlo, ONE byte per element holding the
+// remainder in units of ulp(hi) / 256 (lo_encode: 19 significand bits with f16 operands).  Operand type (f16 default, bf16) and the low half are fixed
+// per handle at creation (encoder_api.hip: kr_encoder_create_ex); why the defaults are what they are: DESIGN.md sections 2 and 4.2a (golden set G10:
+// with outlier hidden channels two orders above the median only f16 + low half stays inside the 1e-3 score tolerance with margin).  MFMA operands
+// 16-bit (xb, q, k, vT, ctx, h), fp32 accumulation everywhere.
 //
 // Per layer (post-LN BERT):  ONE GEMM [Wq/8|Wk|Wv] x -> q, k (row-major) and v TRANSPOSED [H, T] (so that attention reads
 // V^T fragments contiguously); attention = one block per (sequence, head group) with K and V^T staged once in LDS, swapped QK^T so
@@ -408,6 +406,7 @@ struct ProjArgs {
     const float* bias;
     uint16_t* out0; uint16_t* out1; uint16_t* outT; int64_t ldT;   // QKV: q, k row-major [T,H]; vT [H, ldT].  Others: out0 [T, F]
     int64_t ldx, ldo;   // row pitch (elements) of X and of out0 (EPI_DENSE / EPI_GELU); 0 = K / F
+    int pw;   // feature tiles per XCD patch of the tile walk (patch_coord)
     int nt;   // epilogue stores non-temporal (large launches: the output is consumed from HBM by the next kernel, keep it out of L2) or plain
               // (small launches: the whole output fits in L2 / Infinity Cache, the next kernel reads it from there)
 };
@@ -564,7 +563,7 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
         a.X, a.ldx, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             int64_t tm, tn;
-            patch_coord(nat, tm_count, tn_count, tm, tn);
+            patch_coord(nat, tm_count, tn_count, tm, tn, (uint32_t)a.pw);
             m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
         },
         [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeE, NT>(a, acc, m0, n0, stage); });
@@ -582,7 +581,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_proj_split(ProjArgs a) {
         a.X, a.ldx, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             int64_t tm, tn;
-            patch_coord(nat, tm_count, tn_count, tm, tn);
+            patch_coord(nat, tm_count, tn_count, tm, tn, (uint32_t)a.pw);
             m0 = tm * 128; n0 = tn * 128;
         },
         [&](AccTile<ShapeSplit>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeSplit, false>(a, acc, m0, n0, stage); });
@@ -666,9 +665,11 @@ __device__ __forceinline__ int attn_perm(int i) { return (i & ~12) | ((i & 4) <<
 // as their C operand would save the subtraction too, but costs 16 more live registers per tile: measured as spills at three blocks per CU.)
 constexpr float ATTN_RESCALE_THR = 8.0f;
 // first half of a step: the shifted-score tiles S^T = K . Q^T (st1 = -inf when the second 32-key tile does not exist)
-template <bool MASKED>
+// MODE (wave-uniform, picked from the number of valid keys of the step): 0 = 64, 1 = fewer than 32 (first tile masked, no second tile),
+// 2 = exactly 32 (one full tile: a 32-token sequence), 3 = 33 .. 63 (second tile masked)
+template <int MODE>
 __device__ __forceinline__ void attn_scores(f32x16& st0, f32x16& st1, const uint4 (&qf)[4], const char* Kst, int k0, int nvalid, int c, int hf) {
-    const bool two = !MASKED || nvalid > 32;              // wave-uniform
+    constexpr bool two = MODE == 0 || MODE == 3;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     {
         const int key = k0 + attn_perm(c);
@@ -684,24 +685,25 @@ __device__ __forceinline__ void attn_scores(f32x16& st0, f32x16& st1, const uint
             for (int sk = 1; sk < 4; ++sk) st1 = ET::mfma(*reinterpret_cast<const uint4*>(krow1 + (((2 * sk + hf) ^ swz) << 4)), qf[sk], st1);
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st1[r] = -INFINITY;
+            for (int r = 0; r < 16; ++r) st1[r] = -INFINITY;      // never read (two == false below)
         }
     }
-    // register r of this lane: key k0 + 16 (r >> 3) + 8 hf + (r & 7) (+ 32 for st1), query c
-    if constexpr (MASKED) {
+    // register r of this lane: key k0 + 16 (r >> 3) + 8 hf + (r & 7) (+ 32 for st1), query c.  Only the tile that holds key nvalid is partial (wave-uniform
+    // cases: a 32-token sequence has exactly one full tile and nothing to mask)
+    if constexpr (MODE == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kk = 16 * (r >> 3) + 8 * hf + (r & 7);
-            st0[r] = (kk < nvalid) ? st0[r] : -INFINITY;
-            st1[r] = (kk + 32 < nvalid) ? st1[r] : -INFINITY;
-        }
+        for (int r = 0; r < 16; ++r) st0[r] = (16 * (r >> 3) + 8 * hf + (r & 7) < nvalid) ? st0[r] : -INFINITY;
+    }
+    if constexpr (MODE == 3) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st1[r] = (16 * (r >> 3) + 8 * hf + (r & 7) + 32 < nvalid) ? st1[r] : -INFINITY;
     }
 }
 
 // second half: online softmax and O^T += V^T . P^T
-template <bool MASKED, class VFrag>
-__device__ __forceinline__ void attn_softmax_pv(AttnState& s, const f32x16& st0, const f32x16& st1, int nvalid, VFrag&& vfrag) {
-    const bool two = !MASKED || nvalid > 32;              // wave-uniform
+template <int MODE, class VFrag>
+__device__ __forceinline__ void attn_softmax_pv(AttnState& s, const f32x16& st0, const f32x16& st1, VFrag&& vfrag) {
+    constexpr bool two = MODE == 0 || MODE == 3;
     float tmax = fmaxf(fmaxf(st0[0], st0[1]), st0[2]);
 #pragma unroll
     for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, st0[r]), st0[r + 1]);   // v_max3_f32
@@ -742,11 +744,19 @@ __device__ __forceinline__ void attn_softmax_pv(AttnState& s, const f32x16& st0,
     s.l += psum;
 }
 
+template <int MODE, class VFrag>
+__device__ __forceinline__ void attn_step64m(AttnState& s, const uint4 (&qf)[4], const char* Kst, int k0, int nvalid, int c, int hf, VFrag&& vfrag) {
+    f32x16 st0, st1;
+    attn_scores<MODE>(st0, st1, qf, Kst, k0, nvalid, c, hf);
+    attn_softmax_pv<MODE>(s, st0, st1, vfrag);
+}
+// MASKED = false: 64 valid keys; true: fewer (nvalid says how many)
 template <bool MASKED, class VFrag>
 __device__ __forceinline__ void attn_step64(AttnState& s, const uint4 (&qf)[4], const char* Kst, int k0, int nvalid, int c, int hf, VFrag&& vfrag) {
-    f32x16 st0, st1;
-    attn_scores<MASKED>(st0, st1, qf, Kst, k0, nvalid, c, hf);
-    attn_softmax_pv<MASKED>(s, st0, st1, nvalid, vfrag);
+    if constexpr (!MASKED) attn_step64m<0>(s, qf, Kst, k0, 64, c, hf, vfrag);
+    else if (nvalid == 32) attn_step64m<2>(s, qf, Kst, k0, nvalid, c, hf, vfrag);
+    else if (nvalid < 32) attn_step64m<1>(s, qf, Kst, k0, nvalid, c, hf, vfrag);
+    else attn_step64m<3>(s, qf, Kst, k0, nvalid, c, hf, vfrag);
 }
 
 // normalise a finished 32-query tile and store it as whole 128-B rows of ctx through the wave-private 4-KiB LDS block Os
@@ -1232,6 +1242,7 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int nu
     ProjArgs a = a_in;
     if (a.ldx == 0) a.ldx = a.K;
     if (a.ldo == 0) a.ldo = a.F;
+    { const char* pe = getenv("KIRAG_AMD_PATCH_W"); a.pw = pe ? atoi(pe) : 8; if (a.pw < 1) a.pw = 8; }   // A/B knob (profiles/r03): feature tiles per XCD patch
     {   // store policy by output size (see ProjArgs::nt); KIRAG_AMD_STORE_NT = 0 / 1 forces it (A/B measurements)
         const char* se = getenv("KIRAG_AMD_STORE_NT");
         a.nt = se ? atoi(se) : (max_tokens * (int64_t)a.F * 2 > ((int64_t)96 << 20) ? 1 : 0);

@@ -92,14 +92,14 @@ __device__ __forceinline__ void fast_divmod64(uint64_t n, uint32_t d, uint64_t& 
 
 // natural index -> (tm, tn) such that 8 consecutive tn of one tm-run are adjacent: groups of (up to) 8 tn, tm walks inside a group.
 // Used by the encoder projections only: at most 65535 x 512 tokens = 131k token tiles x 16 feature tiles = 2^21 tiles < 2^24.
-__device__ __forceinline__ void patch_coord(int64_t n, int64_t tm_count, int64_t tn_count, int64_t& tm, int64_t& tn) {
-    uint32_t g, rem, q, r;
-    fast_divmod((uint32_t)n, 8u * (uint32_t)tm_count, g, rem);
-    const uint32_t left = (uint32_t)tn_count - 8u * g;
-    const uint32_t gs = left < 8u ? left : 8u;
+__device__ __forceinline__ void patch_coord(int64_t n, int64_t tm_count, int64_t tn_count, int64_t& tm, int64_t& tn, uint32_t pw = 8u) {
+    uint32_t g, rem, q, r;                      // pw = feature tiles per patch (8: the 32 CUs of an XCD hold 4 token tiles x 8 feature tiles at a time)
+    fast_divmod((uint32_t)n, pw * (uint32_t)tm_count, g, rem);
+    const uint32_t left = (uint32_t)tn_count - pw * g;
+    const uint32_t gs = left < pw ? left : pw;
     fast_divmod(rem, gs, q, r);
     tm = q;
-    tn = 8u * g + r;
+    tn = pw * g + r;
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r02/bench_plain.json, produced by `python bench.py` on an MI355X) carries every field of the driver's
+"""The committed bench line (profiles/r03/bench_plain.json, produced by `python bench.py` on an MI355X) carries every field of the driver's
 contract, with consistent arithmetic.  bench.py itself needs a GPU; this checks the artefact the round ships."""
 import json
 import os
@@ -7,7 +7,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(REPO, "profiles", "r02", "bench_plain.json")))
+    d = json.load(open(os.path.join(REPO, "profiles", "r03", "bench_plain.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
@@ -69,11 +69,13 @@ import pytest
 
 
 @pytest.mark.gpu
-def test_bench_gpus_2_real_step_on_one_box():
-    """The real N = 2 step (row shards, per-rank query-slice encode, all-gather of query vectors and of per-shard top-k, device merge) started by
-    `python bench.py --gpus 2` itself; the two ranks share the box's one GPU, so the collective backend is gloo (RCCL wants one device per rank)."""
-    p, lines = _run_bench(["--gpus", "2", "--total-rows", "300000", "--queries", "256", "--steps", "2", "--warmup", "1", "--passages", "64",
-                           "--no-cpu-baseline"], {"KIRAG_BENCH_BACKEND": "gloo"}, timeout=900)
+@pytest.mark.parametrize("split,steps", [("batch", "3"), ("queries", "2")])
+def test_bench_gpus_2_real_step_on_one_box(split, steps):
+    """The real N = 2 step (row shards, all-gather of query vectors and of per-shard top-k, device merge) started by `python bench.py --gpus 2` itself, under
+    both encode schedules: "batch" (rank r encodes the whole batch of every 2nd step; 3 steps = one full and one partial block) and "queries" (every rank
+    encodes half of every batch).  The two ranks share the box's one GPU, so the collective backend is gloo (RCCL wants one device per rank)."""
+    p, lines = _run_bench(["--gpus", "2", "--total-rows", "300000", "--queries", "256", "--steps", steps, "--warmup", "1", "--passages", "64",
+                           "--no-cpu-baseline", "--encode-split", split], {"KIRAG_BENCH_BACKEND": "gloo"}, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     assert len(lines) == 1
     d = json.loads(lines[0])
