@@ -407,6 +407,7 @@ struct ProjArgs {
     uint16_t* out0; uint16_t* out1; uint16_t* outT; int64_t ldT;   // QKV: q, k row-major [T,H]; vT [H, ldT].  Others: out0 [T, F]
     int64_t ldx, ldo;   // row pitch (elements) of X and of out0 (EPI_DENSE / EPI_GELU); 0 = K / F
     int pw;   // feature tiles per XCD patch of the tile walk (patch_coord)
+    int epi_prio;   // A/B knob, see proj_epilogue
     int nt;   // epilogue stores non-temporal (large launches: the output is consumed from HBM by the next kernel, keep it out of L2) or plain
               // (small launches: the whole output fits in L2 / Infinity Cache, the next kernel reads it from there)
 };
@@ -526,6 +527,9 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>
     const int64_t t0 = m0 + acc.m_wave;
     const int f0 = (int)n0 + acc.n_wave;          // first feature of this wave's 64 columns; F % 64 == 0, so a wave is never partial
     if (f0 >= a.F) return;
+    // A/B knob (KIRAG_AMD_EPI_PRIO, profiles/r03/tried_ab_epi_prio.txt): the two wave groups of the ping-pong loop run their epilogues side by side and the
+    // younger group (tile rows 128 ..) loses the issue arbitration (its epilogue takes ~2x as long): 1 = that group at priority 1, 2 = the older group
+    if (a.epi_prio && ((a.epi_prio == 1) == (acc.m_wave >= 128))) __builtin_amdgcn_s_setprio(1);
     const int h = acc.lane >> 5;
     f32x4 b[2][4];                                // bias of the lane's 32 features: (ni, g) -> features ni*32 + 8g + 4h .. +3
     if constexpr (EPI != EPI_DENSE) {
@@ -551,6 +555,7 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>
             return f32x4{lo.x, lo.y, hi.x, hi.y};
         });
     }
+    if (a.epi_prio) __builtin_amdgcn_s_setprio(0);
 }
 
 template <int EPI, class ShapeE, int STAGES, bool NT>
@@ -1242,7 +1247,8 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int nu
     ProjArgs a = a_in;
     if (a.ldx == 0) a.ldx = a.K;
     if (a.ldo == 0) a.ldo = a.F;
-    { const char* pe = getenv("KIRAG_AMD_PATCH_W"); a.pw = pe ? atoi(pe) : 8; if (a.pw < 1) a.pw = 8; }   // A/B knob (profiles/r03): feature tiles per XCD patch
+    { const char* pe = getenv("KIRAG_AMD_PATCH_W"); a.pw = pe ? atoi(pe) : 8; if (a.pw < 1) a.pw = 8; }
+    { const char* pe = getenv("KIRAG_AMD_EPI_PRIO"); a.epi_prio = pe ? atoi(pe) : 0; }   // A/B knob (profiles/r03): feature tiles per XCD patch
     {   // store policy by output size (see ProjArgs::nt); KIRAG_AMD_STORE_NT = 0 / 1 forces it (A/B measurements)
         const char* se = getenv("KIRAG_AMD_STORE_NT");
         a.nt = se ? atoi(se) : (max_tokens * (int64_t)a.F * 2 > ((int64_t)96 << 20) ? 1 : 0);

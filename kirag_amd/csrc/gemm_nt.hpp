@@ -702,4 +702,123 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
 }
 
 
+// =====================================================================================================================
+// EXPERIMENT (tools/gemm_bench.hip only; not used by the product): ONE wave per SIMD.  256x256x64 tiles, 4 waves of 128x128 (256 accumulator registers
+// of the 512 a lone wave may use), ring of two 64-KiB K-tiles, ONE s_barrier per K-tile: K-tile g+1 is staged (16 LDS-DMA pieces per wave: waves 0, 1
+// the A rows, waves 2, 3 the B rows) while K-tile g is multiplied; the pieces are issued between the MFMAs of the first k-steps.  Purpose: measure what
+// the main loop alone sustains in this structure before building the deferred-store epilogue that is its reason to exist.
+// =====================================================================================================================
+using ShapeSolo = GemmShape<256, 256, 2, 2>;
+
+template <class T, bool SWAP = false, class Coord, class Epilogue>
+__device__ __forceinline__ void gemm_nt_solo(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb,
+                                             int64_t N, int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
+    using Shape = ShapeSolo;
+    constexpr int BK = Shape::BK, STAGE = Shape::STAGE_BYTES, ABYTES = Shape::A_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t G = gridDim.x;
+    const int64_t my = (total_tiles > (int64_t)blockIdx.x) ? (total_tiles - blockIdx.x + G - 1) / G : 0;
+    if (my == 0) return;
+    const int nk = K / BK;
+    const int64_t total_g = my * nk;
+    // ---- DMA cursor: this wave stages 16 pieces (128 rows) of ONE operand per K-tile: waves 0, 1 -> A rows 128 * wave .., waves 2, 3 -> B rows 128 * (wave - 2) ..
+    const bool isA = wave < 2;
+    const int row0 = (wave & 1) * 128;
+    int64_t c_tile = 0; int c_kt = 0;
+    const char* c_base = nullptr;
+    uint32_t c_off[16];
+    auto set_base = [&]() {
+        int64_t m0, n0;
+        coord(xcd_chunk_map((int64_t)blockIdx.x + c_tile * G, total_tiles), m0, n0);
+        const int64_t r0 = isA ? m0 : n0, ld = isA ? lda : ldb, left = (isA ? M : N) - r0;
+        c_base = reinterpret_cast<const char*>((isA ? A : B) + r0 * ld);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            int row = row0 + p * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            if (row >= left) row = (int)left - 1;
+            c_off[p] = (uint32_t)(row * ld * 2 + chunk * 16);
+        }
+    };
+    set_base();
+    auto issue_pieces = [&](int slot, int p_begin, int p_end) {     // pieces [p_begin, p_end) of the cursor's K-tile into ring slot `slot`
+        char* dst = smem + slot * STAGE + (isA ? 0 : ABYTES) + row0 * 128;
+        const char* src = c_base + (int64_t)c_kt * (BK * 2);
+#pragma unroll
+        for (int p = p_begin; p < p_end; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src + c_off[p]), (lds_void*)(dst + p * 1024), 16, 0, 0);
+    };
+    auto advance = [&]() {
+        if (c_kt + 1 < nk) ++c_kt;
+        else if (c_tile + 1 < my) { c_kt = 0; ++c_tile; set_base(); }
+    };
+    issue_pieces(0, 0, 16); advance();
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (total_g > 1) { issue_pieces(1, 0, 16); advance(); }            // K-tile 1 in flight while K-tile 0 is multiplied
+
+    const int frow = lane & 31, fh = lane >> 5;
+    const int fswz = (frow >> 1) & 7;
+    const int a_row_byte = (wm * 128 + frow) * 128;
+    const int b_row_byte = ABYTES + (wn * 128 + frow) * 128;
+    int64_t g = 0;
+    uint4 af[2][4], bf[2][4];
+    auto load_frags = [&](int64_t gg, int ks, int buf) {
+        const char* st = smem + (int)(gg & 1) * STAGE;
+        const int coff = ((2 * ks + fh) ^ fswz) << 4;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[buf][mi] = *reinterpret_cast<const uint4*>(st + a_row_byte + mi * 32 * 128 + coff);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bf[buf][ni] = *reinterpret_cast<const uint4*>(st + b_row_byte + ni * 32 * 128 + coff);
+    };
+    load_frags(0, 0, 0);
+    for (int64_t i = 0; i < my; ++i) {
+        int64_t m0, n0;
+        const int64_t nat = xcd_chunk_map((int64_t)blockIdx.x + i * G, total_tiles);
+        coord(nat, m0, n0);
+        AccTile<Shape> acc;
+        acc.m_wave = wm * 128; acc.n_wave = wn * 128; acc.lane = lane;
+        // Software pipeline per K-tile g (fragments of its k-step 0 are already in buffer 0):
+        //   k-steps 0, 1, 2   MFMAs + the fragment reads of the next k-step
+        //   wait (own DMA pieces of K-tile g + 1 landed, own LDS reads done) + s_barrier: K-tile g + 1 is resident, nobody reads K-tile g any more
+        //   issue the 16 DMA pieces of K-tile g + 2 into K-tile g's slot and read the fragments of (g + 1, k-step 0)  -- under the MFMAs of k-step 3
+        // The first K-tile of an output tile is a separate instantiation (C operand 0 in its first k-step; a run-time branch there costs > 100 spills).
+        auto mfmas = [&](auto first_tag, int ks) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    if constexpr (FIRST) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc.v[mi][ni] = SWAP ? T::mfma(bf[ks & 1][ni], af[ks & 1][mi], zero) : T::mfma(af[ks & 1][mi], bf[ks & 1][ni], zero);
+                    } else {
+                        acc.v[mi][ni] = SWAP ? T::mfma(bf[ks & 1][ni], af[ks & 1][mi], acc.v[mi][ni]) : T::mfma(af[ks & 1][mi], bf[ks & 1][ni], acc.v[mi][ni]);
+                    }
+                }
+        };
+        auto ktile = [&](auto first_tag) {
+            load_frags(g, 1, 1);
+            mfmas(first_tag, 0);
+            load_frags(g, 2, 0);
+            mfmas(std::false_type{}, 1);
+            load_frags(g, 3, 1);
+            mfmas(std::false_type{}, 2);
+            wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (g + 2 < total_g) { issue_pieces((int)(g & 1), 0, 16); advance(); }
+            if (g + 1 < total_g) load_frags(g + 1, 0, 0);
+            mfmas(std::false_type{}, 3);
+            ++g;
+        };
+        ktile(std::true_type{});
+        for (int kt = 1; kt < nk; ++kt) ktile(std::false_type{});
+        epi(acc, m0, n0, nat);
+    }
+}
+
 }  // namespace kr

@@ -195,7 +195,11 @@ class FlatIPIndex:
 
 class Indexer(object):
 
-    def __init__(self, vector_sz, metric="inner_product", n_subquantizers=0, n_bits=8, device=None, coarse_dtype="bf16"):
+    def __init__(self, vector_sz, metric="inner_product", n_subquantizers=0, n_bits=8, device=None, coarse_dtype="bf16", faiss_padding=False):
+        """``faiss_padding=True`` reproduces what the reference does when ``top_docs > ntotal`` instead of raising: faiss pads the result with
+        label -1 and score -FLT_MAX, and ``index.py:49`` maps label -1 through ``index_id_to_db_id[-1]`` to the LAST id — recalled from faiss's
+        documented behaviour (not verifiable here: faiss is absent), so it stays opt-in."""
+        self.faiss_padding = bool(faiss_padding)
         if n_subquantizers > 0:
             raise NotImplementedError("IndexPQ (n_subquantizers > 0) is not part of the MI355X path; no reference caller uses it")
         if metric != "inner_product":
@@ -220,7 +224,15 @@ class Indexer(object):
             start_idx = k * index_batch_size
             end_idx = min((k + 1) * index_batch_size, len(query_vectors))
             q = query_vectors[start_idx: end_idx]
-            scores, indexes = self.index.search(q, top_docs)
+            if self.faiss_padding and top_docs > self.index.ntotal:
+                n = self.index.ntotal
+                scores = np.full((len(q), top_docs), -np.finfo(np.float32).max, np.float32)
+                indexes = np.full((len(q), top_docs), -1, np.int64)
+                if n > 0:
+                    s_, i_ = self.index.search(q, n)
+                    scores[:, :n] = s_; indexes[:, :n] = i_
+            else:
+                scores, indexes = self.index.search(q, top_docs)
             # convert to external ids (vectorised form of index.py:49)
             ext = self.index_id_to_db_id[indexes]
             db_ids = [[str(v) for v in row] for row in ext.tolist()]

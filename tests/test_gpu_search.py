@@ -572,3 +572,21 @@ def test_pass2_prescan_marks_only_the_slots_that_matter():
     assert np.array_equal(i2, io) and np.array_equal(s2.view(np.uint32), so.view(np.uint32))
     st2 = ix2.index.stats()
     assert st2["marked_passes"] == 0 and st2["fine"] == st["fine"], st2
+
+
+def test_faiss_padding_flag_for_k_above_ntotal():
+    """`top_docs > ntotal`: default = ValueError (documented deviation); with faiss_padding=True the reference's behaviour on faiss's padded output:
+    k entries per query, the missing ones with score -FLT_MAX and the id that label -1 maps to through index_id_to_db_id[-1] (index.py:49)."""
+    from kirag_amd.retriever.index import Indexer
+    rng = np.random.default_rng(3)
+    x = _unit(rng, 7, 64); q = _unit(rng, 3, 64)
+    ids = [str(100 + i) for i in range(7)]
+    ix = Indexer(64); ix.index_data(ids, x)
+    with pytest.raises(ValueError):
+        ix.search_knn(q, 10, verbose=False)
+    ixp = Indexer(64, faiss_padding=True); ixp.index_data(ids, x)
+    out = ixp.search_knn(q, 10, verbose=False)
+    so, io = S.search_canonical(q, x, 7)
+    for r, (got_ids, got_s) in enumerate(out):
+        assert got_ids[:7] == [str(100 + j) for j in io[r]] and got_ids[7:] == ["106"] * 3
+        assert np.array_equal(got_s[:7], so[r]) and (got_s[7:] == -np.finfo(np.float32).max).all()

@@ -107,6 +107,28 @@ __global__ __launch_bounds__(512, 2) void k_pp16(const uint16_t* A, const uint16
         });
 }
 
+// EXPERIMENT: one wave per SIMD (gemm_nt_solo), checksum epilogue
+__global__ __launch_bounds__(256, 1) void k_solo(const uint16_t* A, const uint16_t* B, float* out, float* sums, int64_t M, int64_t N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Shape = ShapeSolo;
+    const int64_t tm_count = M / Shape::BM, tn_count = N / Shape::BN;
+    gemm_nt_solo<BF16>(
+        A, K, M, B, K, N, K, tm_count * tn_count, smem,
+        [&](int64_t nat, int64_t& m0, int64_t& n0) { int64_t tm, tn; patch_coord(nat, tm_count, tn_count, tm, tn); m0 = tm * Shape::BM; n0 = tn * Shape::BN; },
+        [&](AccTile<Shape>& acc, int64_t m0, int64_t n0, int64_t) {
+            float s = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < Shape::TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < Shape::TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += acc.v[mi][ni][r];
+            if (s == 12345.678f) out[0] = s;
+            if (threadIdx.x == 0 && m0 == 0 && n0 == 0) out[1] = acc.v[0][0][0];
+            if (sums) sums[((m0 / Shape::BM) * tn_count + n0 / Shape::BN) * Shape::NTHREADS + threadIdx.x] = s;
+        });
+}
+
 // search-like epilogue: compare against a per-column threshold held in LDS, append survivors to a block list through an LDS counter
 template <class Shape, int STAGES>
 __global__ __launch_bounds__(Shape::NTHREADS, (Shape::NTHREADS / 256)) void k_stream_filter(const uint16_t* A, const uint16_t* B, float* out, uint4* lists, int64_t M,
@@ -332,11 +354,17 @@ int main(int argc, char** argv) {
             printf("    pingpong vs stream checksums: %zu / %zu differ %s\n", bad, nsum, bad ? "MISMATCH" : "ok");
         }
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pp16), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        for (int rep = 0; rep < 3; ++rep) {     // interleaved A/B of the two MFMA shapes on the same loop (same device, same data)
+        for (int rep = 0; rep < (getenv("SOLO_ONLY") ? 0 : 3); ++rep) {     // interleaved A/B of the two MFMA shapes on the same loop (same device, same data)
             run("pingpong 256x256 grid 256, 32x32x16 MFMA", [&] { hipLaunchKernelGGL(k_pp, dim3(256), dim3(512), lds, 0, A, B, out, (float*)nullptr, M, N, K); });
             run("pingpong 256x256 grid 256, 16x16x32 MFMA", [&] { hipLaunchKernelGGL(k_pp16, dim3(256), dim3(512), lds, 0, A, B, out, (float*)nullptr, M, N, K); });
         }
         if (getenv("M16_ONLY")) return 0;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solo), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        for (int rep = 0; rep < 3; ++rep) {
+            run("pingpong 256x256 grid 256 (8 waves)", [&] { hipLaunchKernelGGL(k_pp, dim3(256), dim3(512), lds, 0, A, B, out, (float*)nullptr, M, N, K); });
+            run("solo 256x256 grid 256 (4 waves, 1 per SIMD)", [&] { hipLaunchKernelGGL(k_solo, dim3(256), dim3(256), lds, 0, A, B, out, (float*)nullptr, M, N, K); });
+        }
+        if (getenv("SOLO_ONLY")) return 0;
         run("pingpong 256x256 grid 256 (no sums)", [&] { hipLaunchKernelGGL(k_pp, dim3(256), dim3(512), lds, 0, A, B, out, (float*)nullptr, M, N, K); });
         run("stream 256x256 stages 2 (no sums)", [&] { hipLaunchKernelGGL((k_stream<S, 2>), dim3(256), dim3(512), lds, 0, A, B, out, (float*)nullptr, M, N, K); });
         {
