@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-encoder", action="store_true", help="search-only step (query vectors pre-computed)")
     ap.add_argument("--encoder-dtype", default=None, choices=["bf16", "f16"], help="16-bit operand type of the encoder (default: the library's, f16)")
     ap.add_argument("--residual-lo", default=None, type=int, choices=[0, 1], help="encoder residual stream with / without its low half (default: the library's, 1)")
+    ap.add_argument("--collective", default="torch", choices=["torch", "kr_comm"],
+                    help="N > 1: exchange of the per-shard result lists through torch.distributed (default) or the library's own RCCL step (kr_shard_allgather_topk)")
     ap.add_argument("--encode-split", default="batch", choices=["batch", "queries"],
                     help="N > 1: 'batch' = rank r encodes the whole query batch of every W-th step (one all-gather of W batches per W steps); "
                          "'queries' = every rank encodes 1/W of every batch (round-2 schedule)")
@@ -262,8 +264,15 @@ def main():
             else:
                 q_mine = q_blk[rank]                                      # no batch to encode in a partial last block: contributes its old buffer
             dist.all_gather_into_tensor(q_blk.view(world * nq, d), q_mine.contiguous())
+        can_defer = k <= index.ntotal and world * k <= searcher.DEVICE_MERGE_MAX     # (the host-merge fallbacks synchronise anyway)
         for s_i in range(count):
-            searcher.search(q_blk[s_i] if encoder is not None else q_vec, k)
+            qs = q_blk[s_i] if encoder is not None else q_vec
+            if can_defer:
+                searcher.search_deferred(qs, k)                          # enqueue-only: results land in pinned buffers of the searcher's ring
+            else:
+                searcher.search(qs, k)
+        if can_defer:
+            torch.cuda.current_stream().synchronize()                     # ONE host synchronisation per block of W steps
 
     def step():
         if encoder is None:

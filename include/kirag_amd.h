@@ -32,7 +32,7 @@ extern "C" {
 #define KR_EHIP (-5)      /* a HIP runtime call failed; see kr_last_error() */
 #define KR_ESTATE (-1)    /* handle not ready (e.g. encoder weights missing) */
 
-#define KR_ABI_VERSION 3
+#define KR_ABI_VERSION 4
 int kr_abi_version(void);
 const char* kr_last_error(void);
 int kr_device_count(void);
@@ -133,6 +133,24 @@ int kr_topk_merge(const float* scores, const int64_t* ids, int nshards, int nq, 
  *   nshards * k <= 8192.  Result identical to kr_topk_merge (lists sorted by (score desc, id asc), id < 0 = padding at the tail, ids unique). */
 int kr_topk_merge_device(const float* scores, int64_t score_shard_stride, const int64_t* ids, int64_t id_shard_stride, int nshards, int nq, int k,
                          float* out_scores, int64_t* out_ids, int device, void* stream);
+
+/* The exchange step of the row-sharded search for hosts without their own collective library (the reference gathers to rank 0 with
+ * torch.distributed, utils/utils.py:145-155): one process per GPU, every rank holds rows [row_offset, row_offset + ntotal) of the corpus.
+ *   kr_comm_unique_id  rank 0 fills a KR_COMM_ID_BYTES buffer and hands it to the other ranks by any means (file, socket, MPI, torch.distributed ...).
+ *   kr_comm_create     collective: blocks until all `world` ranks (one per GPU of the node) have called it with the same id.  RCCL is loaded at run time
+ *                      (librccl.so.1, override with KIRAG_AMD_RCCL_LIB); KR_ESTATE if it cannot be loaded.
+ *   kr_shard_allgather_topk   collective, enqueue-only on `stream`: all-gather (RCCL over xGMI) of every rank's [nq,k] lists (scores fp32 descending, rows
+ *                      int64 GLOBAL row numbers, (-inf, -1) padding at the tail) + the device merge; every rank gets the global top-k in out_* (device
+ *                      pointers, [nq,k]).  world * k <= 8192.  Same result as kr_topk_merge of the W lists. */
+#define KR_COMM_ID_BYTES 128
+typedef struct kr_comm kr_comm;
+int kr_comm_unique_id(void* id128);
+int kr_comm_create(const void* id128, int rank, int world, int device, kr_comm** out);
+int kr_comm_destroy(kr_comm* c);
+int kr_comm_rank(const kr_comm* c);
+int kr_comm_world(const kr_comm* c);
+int kr_shard_allgather_topk(kr_comm* c, const float* scores_local, const int64_t* rows_local, int nq, int k, float* out_scores, int64_t* out_rows,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * BERT-family sentence encoder — replaces HF BertModel.forward + pooling + F.normalize behind

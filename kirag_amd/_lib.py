@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KIRAG_AMD_LIB") or os.path.join(_HERE, "libkirag_amd.so")   # KIRAG_AMD_LIB: diagnostic builds (tools/stamp_build.sh)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class KiragAmdError(RuntimeError):
@@ -59,6 +59,12 @@ SIGNATURES = {
     "kr_index_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "kr_score_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kr_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "kr_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "kr_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "kr_comm_destroy": (C.c_int, [C.c_void_p]),
+    "kr_comm_rank": (C.c_int, [C.c_void_p]),
+    "kr_comm_world": (C.c_int, [C.c_void_p]),
+    "kr_shard_allgather_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kr_topk_merge_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kr_encoder_create": (C.c_int, [C.POINTER(BertCfg), C.c_int, C.POINTER(C.c_void_p)]),
     "kr_encoder_create_ex": (C.c_int, [C.POINTER(BertCfg), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

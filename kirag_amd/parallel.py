@@ -34,12 +34,59 @@ class ShardedSearcher:
 
     DEVICE_MERGE_MAX = 8192      # kr_topk_merge_device holds nshards * k entries per query in LDS
 
-    def __init__(self, index, row_offset: int = 0, world: Optional[int] = None, group=None):
+    def __init__(self, index, row_offset: int = 0, world: Optional[int] = None, group=None, collective: str = "torch"):
+        """``collective``: "torch" — ``torch.distributed.all_gather_into_tensor`` of the process group + ``kr_topk_merge_device``; "kr_comm" — the
+        library's own exchange step (``kr_shard_allgather_topk``: RCCL all-gather + merge behind the C ABI, include/kirag_amd.h); the process group is
+        then only used once, to hand rank 0's communicator id to the other ranks."""
         import torch.distributed as dist
         self.index = index
         self.row_offset = int(row_offset)
         self.group = group
         self.world = int(world) if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        if collective not in ("torch", "kr_comm"):
+            raise ValueError("collective must be 'torch' or 'kr_comm'")
+        self.collective = collective
+        self._comm = None
+
+    def _kr_comm(self, dev):
+        """the library's communicator, created on first use (a collective call: every rank reaches it in its first search)"""
+        if self._comm is None:
+            import ctypes as C
+            import torch.distributed as dist
+            lib = _lib.load()
+            rank = dist.get_rank(self.group) if self.world > 1 else 0
+            ident = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                _lib.check(lib.kr_comm_unique_id(buf))
+                ident[0] = buf.raw
+            if self.world > 1:
+                dist.broadcast_object_list(ident, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            h = C.c_void_p()
+            _lib.check(lib.kr_comm_create(ident[0], rank, self.world, int(dev.index), C.byref(h)))
+            self._comm = h
+        return self._comm
+
+    def close(self):
+        if self._comm is not None:
+            _lib.load().kr_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search_deferred(self, q, k: int):
+        """GPU ranks with device queries: the same search, but the call returns as soon as everything is ENQUEUED (local search + certificate check,
+        all-gather, device merge, D2H into a pinned buffer of a small ring) — no stream synchronisation.  Returns (scores, rows) as pinned CPU tensors
+        that are valid after the caller has synchronised the stream (e.g. once per block of several searches: ``bench.py --gpus N``);
+        at most ``max(4, world)`` searches may be outstanding (the ring of pinned result buffers)."""
+        import torch
+        k = int(k); kl = min(k, int(self.index.ntotal)); nq = int(q.shape[0])
+        assert torch.is_tensor(q) and q.is_cuda and self.world > 1
+        return self._search_device(q, k, kl, nq, q.device, defer=True)
 
     def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:
         """-> (scores float32 [nq,k], GLOBAL rows int64 [nq,k]) on every rank, ONE contract for every world size: always k columns; a corpus
@@ -78,7 +125,7 @@ class ShardedSearcher:
         dist.all_gather_into_tensor(all_i, ids, group=self.group)
         return merge_topk(all_s.view(self.world, nq, k).numpy(), all_i.view(self.world, nq, k).numpy(), k)
 
-    def _search_device(self, q, k: int, kl: int, nq: int, dev):
+    def _search_device(self, q, k: int, kl: int, nq: int, dev, defer: bool = False):
         """GPU ranks: the local lists are written straight into this rank's block of ONE byte buffer ([ids int64 | scores fp32], so a single
         all-gather moves both), the W lists are merged on the device (``kr_topk_merge_device``) and only the final [nq, k] result crosses
         PCIe (1.2 MB instead of 9.6 MB at 8 x 1000 x 100).  Buffers persist across calls; the returned arrays are fresh copies."""
@@ -94,6 +141,9 @@ class ShardedSearcher:
             self._out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
             self._pin_s = torch.empty((nq, k), dtype=torch.float32, pin_memory=True)
             self._pin_i = torch.empty((nq, k), dtype=torch.int64, pin_memory=True)
+            self._ring = [(torch.empty((nq, k), dtype=torch.float32, pin_memory=True), torch.empty((nq, k), dtype=torch.int64, pin_memory=True))
+                          for _ in range(max(4, W))]                # deferred results: at most max(4, W) searches between two synchronisations
+            self._ring_pos = 0
             self._dev_key = key
         ids = self._mine[:nq * k * 8].view(torch.int64).view(nq, k)
         sc = self._mine[nq * k * 8:nq * k * 12].view(torch.float32).view(nq, k)
@@ -106,6 +156,11 @@ class ShardedSearcher:
                 sc[:, :kl] = torch.from_numpy(np.ascontiguousarray(s)).to(dev); ids[:, :kl] = torch.from_numpy(np.ascontiguousarray(i)).to(dev)
         if self.row_offset and kl > 0:
             (ids if kl == k else ids[:, :kl]).add_(self.row_offset)
+        if self.collective == "kr_comm" and W * k <= self.DEVICE_MERGE_MAX:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(_lib.load().kr_shard_allgather_topk(self._kr_comm(dev), sc.data_ptr(), ids.data_ptr(), nq, k,
+                                                           self._out_s.data_ptr(), self._out_i.data_ptr(), stream))
+            return self._deliver(dev, defer)
         dist.all_gather_into_tensor(self._all, self._mine, group=self.group)
         if W * k > self.DEVICE_MERGE_MAX:
             # beyond the device merge's LDS capacity (kr_topk_merge_device: nshards * k <= 8192, e.g. 16 shards x k = 1024): merge on the host
@@ -117,6 +172,15 @@ class ShardedSearcher:
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(_lib.load().kr_topk_merge_device(base + nq * k * 8, block // 4, base, block // 8, W, nq, k,
                                                     self._out_s.data_ptr(), self._out_i.data_ptr(), dev.index, stream))
+        return self._deliver(dev, defer)
+
+    def _deliver(self, dev, defer: bool):
+        import torch
+        if defer:
+            ps, pi = self._ring[self._ring_pos % len(self._ring)]
+            self._ring_pos += 1
+            ps.copy_(self._out_s, non_blocking=True); pi.copy_(self._out_i, non_blocking=True)
+            return ps, pi
         self._pin_s.copy_(self._out_s, non_blocking=True); self._pin_i.copy_(self._out_i, non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()
         return self._pin_s.numpy().copy(), self._pin_i.numpy().copy()

@@ -37,6 +37,13 @@ def _worker(rank, world, port, ret):
         s, i = ShardedSearcher(ix, row_offset=a, world=world).search(torch.from_numpy(q).cuda(), k)
         so, io = S.search_canonical(q, x, k)
         assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+        # enqueue-only variant (bench.py --gpus N: one host synchronisation per block of W searches): three searches in flight in the pinned ring
+        sr = ShardedSearcher(ix, row_offset=a, world=world)
+        qs = [torch.from_numpy(np.ascontiguousarray(np.roll(q, r, axis=0))).cuda() for r in range(3)]
+        pend = [sr.search_deferred(qq, k) for qq in qs]
+        torch.cuda.current_stream().synchronize()
+        for r, (ps, pi) in enumerate(pend):
+            assert np.array_equal(pi.numpy(), np.roll(io, r, axis=0)) and np.array_equal(ps.numpy().view(np.uint32), np.roll(so, r, axis=0).view(np.uint32))
         # more gathered entries than the device merge holds (16 shards x k = 1024 in production): the host-merge fallback, forced here by a small limit
         searcher = ShardedSearcher(ix, row_offset=a, world=world)
         searcher.DEVICE_MERGE_MAX = 64
@@ -160,3 +167,91 @@ def test_sharded_indexer_equals_unsharded_indexer(tmp_path):
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_worker_indexer, args=(2, port, str(tmp_path), ret), nprocs=2, join=True)
     assert ret.get(0) == "ok" and ret.get(1) == "ok", (ret.get(0), ret.get(1))
+
+
+def test_kr_comm_world1_allgather_is_the_merge_of_one_list():
+    """the C ABI's own exchange step (include/kirag_amd.h: kr_comm_*, kr_shard_allgather_topk) with a one-rank RCCL communicator: the gathered +
+    merged result of one sorted list is that list (padding kept at the tail), enqueue-only on the caller's stream."""
+    import ctypes as C
+    from kirag_amd import _lib
+    from oracle import search_np as S
+    lib = _lib.load()
+    ident = C.create_string_buffer(128)
+    _lib.check(lib.kr_comm_unique_id(ident))
+    assert any(ident.raw)
+    h = C.c_void_p()
+    _lib.check(lib.kr_comm_create(ident, 0, 1, 0, C.byref(h)))
+    try:
+        assert lib.kr_comm_rank(h) == 0 and lib.kr_comm_world(h) == 1
+        rng = np.random.default_rng(0)
+        n, d, nq, k = 3000, 128, 17, 50
+        x = rng.standard_normal((n, d)).astype(np.float32); q = rng.standard_normal((nq, d)).astype(np.float32)
+        so, io = S.search_canonical(q, x, k)
+        so[:, -3:] = -np.inf; io[:, -3:] = -1                                     # a short shard: padded tail
+        sc = torch.from_numpy(so).cuda(); ids = torch.from_numpy(io).cuda()
+        out_s = torch.empty_like(sc); out_i = torch.empty_like(ids)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            _lib.check(lib.kr_shard_allgather_topk(h, sc.data_ptr(), ids.data_ptr(), nq, k, out_s.data_ptr(), out_i.data_ptr(), side.cuda_stream))
+        side.synchronize()
+        assert np.array_equal(out_i.cpu().numpy(), io) and np.array_equal(out_s.cpu().numpy().view(np.uint32), so.view(np.uint32))
+        # argument errors come back as codes, not crashes
+        assert lib.kr_shard_allgather_topk(h, sc.data_ptr(), ids.data_ptr(), nq, 8193, out_s.data_ptr(), out_i.data_ptr(), None) == -22
+        assert lib.kr_shard_allgather_topk(h, so.ctypes.data, ids.data_ptr(), nq, k, out_s.data_ptr(), out_i.data_ptr(), None) == -22   # host pointer
+    finally:
+        _lib.check(lib.kr_comm_destroy(h))
+    assert lib.kr_comm_create(ident, 2, 2, 0, C.byref(h)) == -22 and lib.kr_comm_create(None, 0, 1, 0, C.byref(h)) == -22
+
+
+def _worker_kr_comm(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kirag_amd import _lib
+        from kirag_amd.compute_corpus_embeddings import shard_range
+        from kirag_amd.parallel import ShardedSearcher
+        from kirag_amd.retriever.index import FlatIPIndex
+        from oracle import search_np as S
+        rng = np.random.default_rng(0)
+        n, d, nq, k = 6000, 128, 9, 20
+        x = rng.standard_normal((n, d)).astype(np.float32); q = rng.standard_normal((nq, d)).astype(np.float32)
+        a, b = shard_range(n, rank, world)
+        ix = FlatIPIndex(d, device=0); ix.add(torch.from_numpy(x[a:b]).cuda())
+        sr = ShardedSearcher(ix, row_offset=a, world=world, collective="kr_comm")
+        try:
+            s, i = sr.search(torch.from_numpy(q).cuda(), k)
+        except _lib.KiragAmdError as e:
+            # two ranks on ONE device: RCCL refuses the communicator ("Duplicate GPU detected") — the error must arrive as a clean exception on every rank
+            ret[rank] = "refused: " + str(e)
+            return
+        so, io = S.search_canonical(q, x, k)
+        assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+        sr.close()
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_kr_comm_two_ranks_on_one_device_work_or_are_refused_cleanly():
+    """ShardedSearcher(collective="kr_comm") with world 2.  On a one-GPU box RCCL rejects two ranks on the same device: then both ranks must get a
+    KiragAmdError naming ncclCommInitRank (no hang, no crash).  On a box where it is accepted the result must equal the oracle's."""
+    from oracle import search_np as S
+    S.build()
+    port = _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_kr_comm, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=150)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.terminate(); p.join(10)
+    assert not hung, "kr_comm_create hung"
+    r0, r1 = ret.get(0), ret.get(1)
+    print("[kr_comm world 2 on one device]", (r0 or "")[:160])
+    assert (r0 == "ok" and r1 == "ok") or (str(r0).startswith("refused") and str(r1).startswith("refused") and "ncclCommInitRank" in r0), (r0, r1)
