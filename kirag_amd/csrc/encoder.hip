@@ -672,11 +672,35 @@ constexpr float ATTN_RESCALE_THR = 8.0f;
 // first half of a step: the shifted-score tiles S^T = K . Q^T (st1 = -inf when the second 32-key tile does not exist)
 // MODE (wave-uniform, picked from the number of valid keys of the step): 0 = 64, 1 = fewer than 32 (first tile masked, no second tile),
 // 2 = exactly 32 (one full tile: a 32-token sequence), 3 = 33 .. 63 (second tile masked)
-template <int MODE>
+// PF (k_attn_dma): all K fragments of the step are requested before the first MFMA (counted lgkmcnt waits instead of one exposed LDS round trip per
+// MFMA); same MFMAs in the same order, so the result does not depend on it
+template <int MODE, bool PF = false>
 __device__ __forceinline__ void attn_scores(f32x16& st0, f32x16& st1, const uint4 (&qf)[4], const char* Kst, int k0, int nvalid, int c, int hf) {
     constexpr bool two = MODE == 0 || MODE == 3;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    {
+    if constexpr (PF) {
+        const int key = k0 + attn_perm(c);
+        const char* krow = Kst + key * 128;
+        const int swz = (key >> 1) & 7;
+        uint4 kf[two ? 8 : 4];
+#pragma unroll
+        for (int sk = 0; sk < 4; ++sk) kf[sk] = *reinterpret_cast<const uint4*>(krow + (((2 * sk + hf) ^ swz) << 4));
+        if constexpr (two) {
+#pragma unroll
+            for (int sk = 0; sk < 4; ++sk) kf[4 + sk] = *reinterpret_cast<const uint4*>(krow + 32 * 128 + (((2 * sk + hf) ^ swz) << 4));
+        }
+        st0 = ET::mfma(kf[0], qf[0], zero);
+#pragma unroll
+        for (int sk = 1; sk < 4; ++sk) st0 = ET::mfma(kf[sk], qf[sk], st0);
+        if constexpr (two) {
+            st1 = ET::mfma(kf[4], qf[0], zero);
+#pragma unroll
+            for (int sk = 1; sk < 4; ++sk) st1 = ET::mfma(kf[4 + sk], qf[sk], st1);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st1[r] = -INFINITY;
+        }
+    } else {
         const int key = k0 + attn_perm(c);
         const char* krow = Kst + key * 128;
         const int swz = (key >> 1) & 7;
@@ -706,9 +730,17 @@ __device__ __forceinline__ void attn_scores(f32x16& st0, f32x16& st1, const uint
 }
 
 // second half: online softmax and O^T += V^T . P^T
-template <int MODE, class VFrag>
+template <int MODE, bool PF = false, class VFrag>
 __device__ __forceinline__ void attn_softmax_pv(AttnState& s, const f32x16& st0, const f32x16& st1, VFrag&& vfrag) {
     constexpr bool two = MODE == 0 || MODE == 3;
+    uint4 vpre[PF ? (two ? 8 : 4) : 1];
+    if constexpr (PF) {                                  // the V^T fragments land under the maximum / rescale arithmetic
+#pragma unroll
+        for (int ks = 0; ks < (two ? 4 : 2); ++ks) { vpre[2 * ks] = vfrag(0, ks); vpre[2 * ks + 1] = vfrag(1, ks); }
+    }
+#if defined(ATTN_ABL) && (ATTN_ABL == 2 || ATTN_ABL == 6)     // tools/attn_bench.hip ablation: no maximum
+    float tmax = st0[0];
+#else
     float tmax = fmaxf(fmaxf(st0[0], st0[1]), st0[2]);
 #pragma unroll
     for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, st0[r]), st0[r + 1]);   // v_max3_f32
@@ -718,6 +750,7 @@ __device__ __forceinline__ void attn_softmax_pv(AttnState& s, const f32x16& st0,
         for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, st1[r]), st1[r + 1]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+#endif
     const bool fresh = s.mref == -INFINITY;               // nothing accumulated for this query yet
     if (__builtin_amdgcn_ballot_w64(fresh || tmax > s.mref + ATTN_RESCALE_THR) != 0ull) {
         // raise the reference (never lower it)
@@ -736,29 +769,53 @@ __device__ __forceinline__ void attn_softmax_pv(AttnState& s, const f32x16& st0,
         for (int a = 0; a < 2; ++a) {
             float e[8];
 #pragma unroll
+#if defined(ATTN_ABL) && ATTN_ABL == 6     // ablation: no softmax arithmetic at all (P = S)
+            for (int i = 0; i < 8; ++i) { e[i] = stx[8 * a + i]; }
+            psum = e[0];
+#elif defined(ATTN_ABL) && ATTN_ABL == 1     // ablation: no exponential
+            for (int i = 0; i < 8; ++i) { e[i] = stx[8 * a + i] - mshift; psum += e[i]; }
+#elif defined(ATTN_ABL) && ATTN_ABL == 3   // ablation: no row sum
+            for (int i = 0; i < 8; ++i) { e[i] = __builtin_amdgcn_exp2f(stx[8 * a + i] - mshift); }
+            psum = e[0];
+#else
             for (int i = 0; i < 8; ++i) { e[i] = __builtin_amdgcn_exp2f(stx[8 * a + i] - mshift); psum += e[i]; }
+#endif
             uint4 pf;
             pf.x = pack_bf16x2(e[0], e[1]); pf.y = pack_bf16x2(e[2], e[3]); pf.z = pack_bf16x2(e[4], e[5]); pf.w = pack_bf16x2(e[6], e[7]);
-            s.o0 = ET::mfma(vfrag(0, ks0 + a), pf, s.o0);
-            s.o1 = ET::mfma(vfrag(1, ks0 + a), pf, s.o1);
+#if defined(ATTN_ABL) && ATTN_ABL == 4     // ablation: no P.V MFMAs (P and the V^T fragments stay live)
+            if constexpr (PF) {
+                const uint4 va = vpre[2 * (ks0 + a)], vb = vpre[2 * (ks0 + a) + 1];
+                const unsigned keep = pf.x ^ pf.y ^ pf.z ^ pf.w ^ va.x ^ va.y ^ va.z ^ va.w ^ vb.x ^ vb.y ^ vb.z ^ vb.w;
+                asm volatile("" :: "v"(keep));
+            } else
+#endif
+            if constexpr (PF) {
+                s.o0 = ET::mfma(vpre[2 * (ks0 + a)], pf, s.o0);
+                s.o1 = ET::mfma(vpre[2 * (ks0 + a) + 1], pf, s.o1);
+            } else {
+                s.o0 = ET::mfma(vfrag(0, ks0 + a), pf, s.o0);
+                s.o1 = ET::mfma(vfrag(1, ks0 + a), pf, s.o1);
+            }
         }
     };
     pv(st0, 0);
     if (two) pv(st1, 2);
+#if !(defined(ATTN_ABL) && (ATTN_ABL == 3 || ATTN_ABL == 6))
     psum += __shfl_xor(psum, 32, 64);
+#endif
     s.l += psum;
 }
 
-template <int MODE, class VFrag>
+template <int MODE, bool PF = false, class VFrag>
 __device__ __forceinline__ void attn_step64m(AttnState& s, const uint4 (&qf)[4], const char* Kst, int k0, int nvalid, int c, int hf, VFrag&& vfrag) {
     f32x16 st0, st1;
-    attn_scores<MODE>(st0, st1, qf, Kst, k0, nvalid, c, hf);
-    attn_softmax_pv<MODE>(s, st0, st1, vfrag);
+    attn_scores<MODE, PF>(st0, st1, qf, Kst, k0, nvalid, c, hf);
+    attn_softmax_pv<MODE, PF>(s, st0, st1, vfrag);
 }
 // MASKED = false: 64 valid keys; true: fewer (nvalid says how many)
-template <bool MASKED, class VFrag>
+template <bool MASKED, bool PF = false, class VFrag>
 __device__ __forceinline__ void attn_step64(AttnState& s, const uint4 (&qf)[4], const char* Kst, int k0, int nvalid, int c, int hf, VFrag&& vfrag) {
-    if constexpr (!MASKED) attn_step64m<0>(s, qf, Kst, k0, 64, c, hf, vfrag);
+    if constexpr (!MASKED) attn_step64m<0, PF>(s, qf, Kst, k0, 64, c, hf, vfrag);
     else if (nvalid == 32) attn_step64m<2>(s, qf, Kst, k0, nvalid, c, hf, vfrag);
     else if (nvalid < 32) attn_step64m<1>(s, qf, Kst, k0, nvalid, c, hf, vfrag);
     else attn_step64m<3>(s, qf, Kst, k0, nvalid, c, hf, vfrag);
@@ -787,6 +844,10 @@ __device__ __forceinline__ void attn_store_tile(const AttnState& s, char* Os, ui
     }
 }
 
+#ifndef ALDS_PF_N
+#define ALDS_PF_N 0
+#endif
+constexpr bool ALDS_PF = ALDS_PF_N != 0;                   // fragment prefetch in k_attn_lds (tools: A/B builds)
 // HPB = heads per block: 1 when a sequence has >= 3 q-tiles, 2 / 4 for short sequences so that all four waves have work.
 // __launch_bounds__(256, 3): at most 168 registers per lane, which makes hipcc keep the MFMA accumulators in VGPRs; with the default bound it put
 // them in AGPRs and spent 112 of the 276 VALU instructions of a key tile on v_accvgpr_read / _write around the softmax rescale
@@ -897,14 +958,24 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
         }
         __syncthreads();
         if (!active) continue;
-        for (int k0 = 0; k0 < nkc; k0 += 64) {            // k0: key offset inside the chunk
+        // the full 64-key steps run in a loop of their own: with the masked variants inside the same loop the accumulators went through register
+        // copies at every join (k0: key offset inside the chunk)
+        const int kfull = nkc & ~63;
+        for (int k0 = 0; k0 < kfull; k0 += 64) {
             auto vfrag = [&](int dh, int ks) {
                 const char* v = Vh + (c + 32 * dh) * vpitch + (k0 + 16 * ks + 8 * hf) * 2;
                 const uint2 a0 = *reinterpret_cast<const uint2*>(v), a1 = *reinterpret_cast<const uint2*>(v + 8);
                 return make_uint4(a0.x, a0.y, a1.x, a1.y);
             };
-            if (nkc - k0 < 64) attn_step64<true>(st, qf, Kh, k0, nkc - k0, c, hf, vfrag);
-            else attn_step64<false>(st, qf, Kh, k0, 64, c, hf, vfrag);
+            attn_step64<false, ALDS_PF>(st, qf, Kh, k0, 64, c, hf, vfrag);
+        }
+        if (kfull < nkc) {
+            auto vfrag = [&](int dh, int ks) {
+                const char* v = Vh + (c + 32 * dh) * vpitch + (kfull + 16 * ks + 8 * hf) * 2;
+                const uint2 a0 = *reinterpret_cast<const uint2*>(v), a1 = *reinterpret_cast<const uint2*>(v + 8);
+                return make_uint4(a0.x, a0.y, a1.x, a1.y);
+            };
+            attn_step64<true>(st, qf, Kh, kfull, nkc - kfull, c, hf, vfrag);
         }
     }
     if (!active) return;
@@ -912,12 +983,18 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
 }
 
 // ---- long sequences: LDS-DMA ring ------------------------------------------------------------------------------------------------------------
+#ifdef KR_STAMP_ATTN
+__device__ unsigned long long kr_attn_stamps[8];          // diagnostic build only (tools/attn_bench.hip)
+#endif
 constexpr int ADMA_STAGE = 16384;                          // per 64-key chunk: K [64 keys][128 B] + V^T [64 d][128 B]
 constexpr int ADMA_RING = 3;
 constexpr int ADMA_LDS = ADMA_RING * ADMA_STAGE;           // 48 KiB; the O staging (4 waves x 4 KiB) re-uses the ring after the last chunk
-constexpr int ADMA_WAVES = 4;
+#ifndef ADMA_WAVES_N
+#define ADMA_WAVES_N 4                                     // tools/attn_bench.hip builds the 8-wave variant too (one block per (sequence, head) up to 512 tokens:
+#endif                                                     // 5 % faster at 128 x 512, 10-35 % slower at 64 x 512, 256 x 256 and 341 x 192)
+constexpr int ADMA_WAVES = ADMA_WAVES_N;
 constexpr int ADMA_THREADS = ADMA_WAVES * 64;
-constexpr int ADMA_QT = 2 * ADMA_WAVES;                    // q-tiles per block: TWO per wave (w and w + 4), so every staged chunk serves 256 queries
+constexpr int ADMA_QT = 2 * ADMA_WAVES;                    // q-tiles per block: TWO per wave (w and w + ADMA_WAVES), so every staged chunk serves 256 queries
 constexpr int ADMA_PIECES = 8 / ADMA_WAVES;                // K pieces (and V^T pieces) of 1 KiB a wave issues per chunk
 
 // Measured at 128 x 512 tokens (us per layer; the register-staged kernel: 344): two q-tiles per wave one after the other 253; one q-tile per wave with
@@ -937,18 +1014,25 @@ __device__ __forceinline__ void attn_dma_body(const uint16_t* __restrict__ q, co
     // lane-linear: the swizzle sits on the source)
     const char* kbase = reinterpret_cast<const char*>(k) + (int64_t)head * 128;
     const char* vbase = reinterpret_cast<const char*>(vT) + ((int64_t)head * 64) * ldv * 2 + off * 2;
+    // addresses = a wave-uniform chunk base (scalar registers) + a 32-bit per-lane offset that does not change from chunk to chunk.  Rows past the
+    // sequence (last chunk) are read and masked; the K buffer has 64 rows and V^T 64 columns of slack behind the last token (ensure_capacity)
+    uint32_t klane[ADMA_PIECES], vlane[ADMA_PIECES];
+#pragma unroll
+    for (int pp = 0; pp < ADMA_PIECES; ++pp) {
+        const int row = 8 * (wave * ADMA_PIECES + pp) + (lane >> 3);   // key inside the chunk / d row
+        const int sw = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
+        klane[pp] = (uint32_t)(row * H * 2 + sw);
+        vlane[pp] = (uint32_t)((int64_t)row * ldv * 2 + sw);          // < 2^32: 64 rows x (tokens + 64) x 2 B, tokens <= 2^24 (ensure_ws)
+    }
     auto issue = [&](int cidx) {
         char* stg = smem + (cidx % ADMA_RING) * ADMA_STAGE;
-        const int kc0 = cidx * 64;
+        const char* kc = kbase + (off + (int64_t)cidx * 64) * H * 2;
+        const char* vc = vbase + (int64_t)cidx * 128;
 #pragma unroll
         for (int pp = 0; pp < ADMA_PIECES; ++pp) {
             const int p = wave * ADMA_PIECES + pp;
-            const int row = 8 * p + (lane >> 3);           // key inside the chunk / d row
-            const int sw = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
-            int64_t trow = off + kc0 + row;                // rows past the sequence (last chunk) are read and masked; past the buffer they are clamped
-            if (trow >= capT) trow = capT - 1;
-            __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + trow * H * 2 + sw), (lds_void*)(stg + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + (int64_t)row * ldv * 2 + kc0 * 2 + sw), (lds_void*)(stg + 8192 + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(kc + klane[pp]), (lds_void*)(stg + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(vc + vlane[pp]), (lds_void*)(stg + 8192 + p * 1024), 16, 0, 0);
         }
     };
     issue(0);
@@ -972,10 +1056,45 @@ __device__ __forceinline__ void attn_dma_body(const uint16_t* __restrict__ q, co
         attn_init(st[j]);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): Q fragments (and chunks 0, 1) have landed
-    for (int ci = 0; ci < nchunks; ++ci) {
+#ifdef KR_STAMP_ATTN
+    unsigned long long sa_turn = 0, sa_t0 = 0, sa_t1 = 0, sa_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long sa_begin = sa_prev;
+#define KR_SA(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - sa_prev; sa_prev = now_; } while (0)
+#else
+#define KR_SA(acc) do { } while (0)
+#endif
+    auto turn = [&](int ci) {
         if (ci + 1 < nchunks) wait_vmcnt<2 * ADMA_PIECES>(); else wait_vmcnt<0>();   // this wave's pieces of chunk ci have landed; chunk ci + 1 may be in flight
         __builtin_amdgcn_s_barrier();                      // everybody's pieces of chunk ci landed, everybody is done reading chunk ci - 1
+#if defined(ATTN_ABL) && ATTN_ABL == 5      // tools/attn_bench.hip ablation: no K / V^T traffic after the first two chunks (stale stages are multiplied)
+        (void)ci;
+#else
         if (ci + 2 < nchunks) issue(ci + 2);               // into the stage of chunk ci - 1
+#endif
+    };
+    // The chunks with 64 valid keys run in loops of their own (one per number of active q-tiles) that hold nothing but the unmasked step: with the masked
+    // variants and the act[] tests inside one loop the accumulators of both tiles went through copies at every join (32 v_mov_b64 per step)
+    const int nfull = nk >> 6;
+    auto full_chunk = [&](int ci, auto two_tiles) {
+        turn(ci);
+        KR_SA(sa_turn);
+        char* stg = smem + (ci % ADMA_RING) * ADMA_STAGE;
+        auto vfrag = [&](int dh, int ks) {
+            const int d = c + 32 * dh;
+            return *reinterpret_cast<const uint4*>(stg + 8192 + d * 128 + (((2 * ks + hf) ^ ((d >> 1) & 7)) << 4));
+        };
+        attn_step64<false, true>(st[0], qf[0], stg, 0, 64, c, hf, vfrag);
+        KR_SA(sa_t0);
+        if constexpr (decltype(two_tiles)::value) attn_step64<false, true>(st[1], qf[1], stg, 0, 64, c, hf, vfrag);
+        KR_SA(sa_t1);
+    };
+    if (act[1]) {
+        for (int ci = 0; ci < nfull; ++ci) full_chunk(ci, std::true_type{});
+    } else {
+        for (int ci = 0; ci < nfull; ++ci) full_chunk(ci, std::false_type{});
+    }
+    for (int ci = nfull; ci < nchunks; ++ci) {             // at most one: the partial last chunk
+        turn(ci);
         char* stg = smem + (ci % ADMA_RING) * ADMA_STAGE;
         const int nkc = min(nk - ci * 64, 64);
         auto vfrag = [&](int dh, int ks) {
@@ -1012,9 +1131,16 @@ __device__ __forceinline__ void attn_dma_body(const uint16_t* __restrict__ q, co
 #pragma unroll
     for (int j = 0; j < 2; ++j)
         if (act[j]) attn_store_tile(st[j], Os, ctx, off, q0[j], nq, H, head, lane);
+#ifdef KR_STAMP_ATTN
+    if (lane == 0) {       // [0] barrier / wait / DMA issue, [1] first tile's step, [2] second tile's step, [3] whole lifetime, [4] waves
+        const unsigned long long end = __builtin_amdgcn_s_memtime();
+        atomicAdd(&kr_attn_stamps[0], sa_turn); atomicAdd(&kr_attn_stamps[1], sa_t0); atomicAdd(&kr_attn_stamps[2], sa_t1);
+        atomicAdd(&kr_attn_stamps[3], end - sa_begin); atomicAdd(&kr_attn_stamps[4], 1ull);
+    }
+#endif
 }
 
-__global__ __launch_bounds__(ADMA_THREADS, 2) void k_attn_dma(const uint16_t* q, const uint16_t* k, const uint16_t* vT, int64_t ldv, const int* __restrict__ seq_off,
+__global__ __launch_bounds__(ADMA_THREADS, 512 / ADMA_THREADS) void k_attn_dma(const uint16_t* q, const uint16_t* k, const uint16_t* vT, int64_t ldv, const int* __restrict__ seq_off,
                                                              const int* __restrict__ seq_nk, const int* __restrict__ seq_nq, int H, int64_t capT, uint16_t* ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int head = blockIdx.x, b = blockIdx.y, qg = blockIdx.z;   // heads fastest: the heads of one sequence (same 2-KiB q / k rows) run together
@@ -1123,13 +1249,16 @@ static int ensure_ws(Encoder* e, int B, int S) {
         KR_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
     }
     if (maxT <= e->capT && B <= e->capB && (int64_t)B * S <= e->capBS) return 0;
+    if (maxT > (int64_t)1 << 24) return fail(KR_EINVAL, "batch of %lld tokens: at most 2^24 per forward (32-bit offsets inside the attention kernels)", (long long)maxT);
     free_ws(e);
     const int64_t capT = round_up(maxT, 256), capB = B, capBS = (int64_t)B * S;   // multiple of the 256-token tile: see k_proj
     KR_TRY(dmalloc(&e->d_ids, capBS * 8)); KR_TRY(dmalloc(&e->d_mask, capBS * 8));
     KR_TRY(dmalloc(&e->seq_off, capB * 4)); KR_TRY(dmalloc(&e->seq_nk, capB * 4)); KR_TRY(dmalloc(&e->seq_nq, capB * 4)); KR_TRY(dmalloc(&e->seq_cls, capB * 4)); KR_TRY(dmalloc(&e->seq_has0, capB * 4));
     KR_TRY(dmalloc(&e->tok_id, capT * 4)); KR_TRY(dmalloc(&e->tok_pos, capT * 4));
     KR_TRY(dmalloc(&e->xlo, capT * H)); KR_TRY(dmalloc(&e->y, capT * H * 2)); KR_TRY(dmalloc(&e->out, (size_t)capB * H * 4));
-    KR_TRY(dmalloc(&e->xb, capT * H * 2)); KR_TRY(dmalloc(&e->q, capT * H * 2)); KR_TRY(dmalloc(&e->k, capT * H * 2));
+    KR_TRY(dmalloc(&e->xb, capT * H * 2)); KR_TRY(dmalloc(&e->q, capT * H * 2));
+    KR_TRY(dmalloc(&e->k, (capT + 64) * H * 2));    // 64 rows of slack: k_attn_dma reads whole 64-key chunks (the rows past a sequence are masked)
+    KR_HIP(hipMemset(e->k, 0, (size_t)(capT + 64) * H * 2));
     e->ldv = capT + 64;   // slack: the last key tile of the last sequence may read up to 43 columns past T
     KR_TRY(dmalloc(&e->vT, (size_t)H * e->ldv * 2));
     KR_HIP(hipMemset(e->vT, 0, (size_t)H * e->ldv * 2));
