@@ -683,12 +683,18 @@ __device__ __forceinline__ void attn_scores(f32x16& st0, f32x16& st1, const uint
         const char* krow = Kst + key * 128;
         const int swz = (key >> 1) & 7;
         uint4 kf[two ? 8 : 4];
+#if defined(ATTN_ABL) && ATTN_ABL == 7      // ablation: no LDS fragment reads (fragments = registers)
+#pragma unroll
+        for (int sk = 0; sk < (two ? 8 : 4); ++sk) kf[sk] = qf[sk & 3];
+        (void)krow; (void)swz;
+#else
 #pragma unroll
         for (int sk = 0; sk < 4; ++sk) kf[sk] = *reinterpret_cast<const uint4*>(krow + (((2 * sk + hf) ^ swz) << 4));
         if constexpr (two) {
 #pragma unroll
             for (int sk = 0; sk < 4; ++sk) kf[4 + sk] = *reinterpret_cast<const uint4*>(krow + 32 * 128 + (((2 * sk + hf) ^ swz) << 4));
         }
+#endif
         st0 = ET::mfma(kf[0], qf[0], zero);
 #pragma unroll
         for (int sk = 1; sk < 4; ++sk) st0 = ET::mfma(kf[sk], qf[sk], st0);
@@ -736,9 +742,13 @@ __device__ __forceinline__ void attn_softmax_pv(AttnState& s, const f32x16& st0,
     uint4 vpre[PF ? (two ? 8 : 4) : 1];
     if constexpr (PF) {                                  // the V^T fragments land under the maximum / rescale arithmetic
 #pragma unroll
+#if defined(ATTN_ABL) && ATTN_ABL == 7
+        for (int ks = 0; ks < (two ? 4 : 2); ++ks) { vpre[2 * ks] = make_uint4(__builtin_bit_cast(unsigned, st0[ks]), 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); vpre[2 * ks + 1] = vpre[2 * ks]; }
+#else
         for (int ks = 0; ks < (two ? 4 : 2); ++ks) { vpre[2 * ks] = vfrag(0, ks); vpre[2 * ks + 1] = vfrag(1, ks); }
+#endif
     }
-#if defined(ATTN_ABL) && (ATTN_ABL == 2 || ATTN_ABL == 6)     // tools/attn_bench.hip ablation: no maximum
+#if defined(ATTN_ABL) && (ATTN_ABL == 2 || ATTN_ABL == 6 || ATTN_ABL == 7)     // tools/attn_bench.hip ablation: no maximum
     float tmax = st0[0];
 #else
     float tmax = fmaxf(fmaxf(st0[0], st0[1]), st0[2]);
@@ -769,7 +779,7 @@ __device__ __forceinline__ void attn_softmax_pv(AttnState& s, const f32x16& st0,
         for (int a = 0; a < 2; ++a) {
             float e[8];
 #pragma unroll
-#if defined(ATTN_ABL) && ATTN_ABL == 6     // ablation: no softmax arithmetic at all (P = S)
+#if defined(ATTN_ABL) && (ATTN_ABL == 6 || ATTN_ABL == 7)     // ablation: no softmax arithmetic at all (P = S)
             for (int i = 0; i < 8; ++i) { e[i] = stx[8 * a + i]; }
             psum = e[0];
 #elif defined(ATTN_ABL) && ATTN_ABL == 1     // ablation: no exponential
@@ -800,7 +810,7 @@ __device__ __forceinline__ void attn_softmax_pv(AttnState& s, const f32x16& st0,
     };
     pv(st0, 0);
     if (two) pv(st1, 2);
-#if !(defined(ATTN_ABL) && (ATTN_ABL == 3 || ATTN_ABL == 6))
+#if !(defined(ATTN_ABL) && (ATTN_ABL == 3 || ATTN_ABL == 6 || ATTN_ABL == 7))
     psum += __shfl_xor(psum, 32, 64);
 #endif
     s.l += psum;
