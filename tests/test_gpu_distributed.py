@@ -255,3 +255,57 @@ def test_kr_comm_two_ranks_on_one_device_work_or_are_refused_cleanly():
     r0, r1 = ret.get(0), ret.get(1)
     print("[kr_comm world 2 on one device]", (r0 or "")[:160])
     assert (r0 == "ok" and r1 == "ok") or (str(r0).startswith("refused") and str(r1).startswith("refused") and "ncclCommInitRank" in r0), (r0, r1)
+
+
+def _worker_nccl_one_rank(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        from kirag_amd.parallel import ShardedSearcher
+        from kirag_amd.retriever.index import FlatIPIndex
+        from oracle import search_np as S
+        rng = np.random.default_rng(0)
+        n, d, nq, k = 8000, 128, 21, 50
+        x = rng.standard_normal((n, d)).astype(np.float32); q = rng.standard_normal((nq, d)).astype(np.float32)
+        so, io = S.search_canonical(q, x, k)
+        ix = FlatIPIndex(d, device=0); ix.add(torch.from_numpy(x).cuda())
+        qd = torch.from_numpy(q).cuda()
+        for coll in ("torch", "kr_comm"):
+            sr = ShardedSearcher(ix, row_offset=0, world=1, collective=coll)
+            s, i = sr._search_device(qd, k, k, nq, qd.device)                 # the N > 1 device path with W = 1: RCCL all-gather of the uint8 block / kr_comm
+            assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32)), coll
+            ps, pi = sr._search_device(qd, k, k, nq, qd.device, defer=True)
+            torch.cuda.current_stream().synchronize()
+            assert np.array_equal(pi.numpy(), io) and np.array_equal(ps.numpy().view(np.uint32), so.view(np.uint32)), coll
+            sr.close()
+        # the collectives bench.py --gpus N issues, on the RCCL backend: query-vector all-gather, barrier, max over ranks of the elapsed time
+        blk = torch.empty((1, nq, d), dtype=torch.float32, device="cuda")
+        dist.all_gather_into_tensor(blk.view(nq, d), qd.contiguous())
+        assert torch.equal(blk[0], qd)
+        dist.barrier()
+        t = torch.tensor([1.25], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t) == 1.25
+        ret[0] = "ok"
+    except Exception:
+        import traceback
+        ret[0] = traceback.format_exc()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_runs_the_sharded_device_path():
+    """backend "nccl" (= RCCL) cannot take two ranks on the one GPU of the test box; a ONE-rank group still drives every RCCL call of the N > 1 path with
+    the real buffers (uint8 result block, fp32 query block, kr_comm id broadcast), so dtype / stream / device-pointer mistakes show up here and not first
+    on the 8-GPU node."""
+    from oracle import search_np as S
+    S.build()
+    port = _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_worker_nccl_one_rank, args=(0, 1, port, ret))
+    p.start(); p.join(timeout=200)
+    if p.is_alive():
+        p.terminate(); p.join(10)
+        pytest.fail("one-rank RCCL group hung")
+    assert ret.get(0) == "ok", ret.get(0)
