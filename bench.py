@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--encode-split", default="batch", choices=["batch", "queries"],
                     help="N > 1: 'batch' = rank r encodes the whole query batch of every W-th step (one all-gather of W batches per W steps); "
                          "'queries' = every rank encodes 1/W of every batch (round-2 schedule)")
+    ap.add_argument("--search-stream", action="store_true", help="one GPU experiment: enqueue the search of step i on a second stream (overlaps the encode of step i + 1)")
     ap.add_argument("--sync-search", action="store_true", help="one GPU: use the blocking kr_index_search per step instead of search_async + finish")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000, help="corpus rows of the CPU search baseline (BASELINE.md: the 1M point)")
@@ -241,11 +242,18 @@ def main():
             coarse_log.append(index.stats()["last_coarse_ms"])                           # HIP events around the coarse rounds of the finished step
             pin_s[j].copy_(res_s[j], non_blocking=True); pin_i[j].copy_(res_i[j], non_blocking=True)
 
+    side = torch.cuda.Stream(device=dev) if args.search_stream else None
+
     def step_async(i):
         qv = q_vec if encoder is None else encoder.forward(tok_ids, tok_mask, 0)       # [nq, d] fp32 on the device, enqueued
         drain()
         j = i & 1
-        index.search_async(qv, k, res_s[j], res_i[j])
+        if side is not None:                                                          # experiment: the search of step i on a second stream, under the encode of step i + 1
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                index.search_async(qv, k, res_s[j], res_i[j])
+        else:
+            index.search_async(qv, k, res_s[j], res_i[j])
         inflight.append(j)
         step_async.keep = qv                                                          # the queries stay alive until finish()
 
