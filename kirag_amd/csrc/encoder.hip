@@ -96,6 +96,11 @@ struct Encoder {
     std::vector<GraphEntryT> graphs;   // captured forwards of small batch shapes (run_forward)
     hipStream_t gstream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
     bool graphs_off = false;
+    // CLS pooling: the LAST layer's attention output / FFN only matter for one row per sequence.  Those rows are gathered into compact [B, ...] buffers
+    // after the last attention and the rest of the layer runs on B rows instead of T (KIRAG_AMD_CLS_FULL=1 at kr_encoder_create: all rows, A/B and tests)
+    bool cls_shortcut = true, last_shortcut = false;
+    uint16_t *c_ctx = nullptr, *c_xb = nullptr, *c_y = nullptr, *c_h = nullptr; uint8_t* c_xlo = nullptr;
+    int *c_off = nullptr, *c_nk = nullptr, *c_cls = nullptr, *d_B = nullptr;
 };
 
 typedef Encoder::GraphEntryT GraphEntry;
@@ -1241,8 +1246,9 @@ static int dmalloc(P** p, size_t bytes) {
 static void free_ws(Encoder* e) {
     if (!e->graphs.empty()) { (void)hipDeviceSynchronize(); drop_graphs(e); }   // captured kernels hold workspace pointers
     void* ptrs[] = {e->d_ids, e->d_mask, e->seq_off, e->seq_nk, e->seq_nq, e->seq_cls, e->seq_has0, e->tok_id, e->tok_pos, e->xlo, e->y, e->out,
-                    e->xb, e->q, e->k, e->vT, e->ctx, e->h};
+                    e->xb, e->q, e->k, e->vT, e->ctx, e->h, e->c_ctx, e->c_xb, e->c_y, e->c_h, e->c_xlo, e->c_off, e->c_nk, e->c_cls, e->d_B};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    e->c_ctx = e->c_xb = e->c_y = e->c_h = nullptr; e->c_xlo = nullptr; e->c_off = e->c_nk = e->c_cls = e->d_B = nullptr;
     e->d_ids = e->d_mask = nullptr; e->seq_off = e->seq_nk = e->seq_nq = e->seq_cls = e->seq_has0 = nullptr; e->tok_id = e->tok_pos = nullptr;
     e->out = nullptr; e->xlo = nullptr; e->y = e->xb = e->q = e->k = e->vT = e->ctx = e->h = nullptr;
     e->capT = 0; e->capB = 0; e->capBS = 0;
@@ -1273,6 +1279,13 @@ static int ensure_ws(Encoder* e, int B, int S) {
     KR_TRY(dmalloc(&e->vT, (size_t)H * e->ldv * 2));
     KR_HIP(hipMemset(e->vT, 0, (size_t)H * e->ldv * 2));
     KR_TRY(dmalloc(&e->ctx, capT * H * 2)); KR_TRY(dmalloc(&e->h, capT * (FF + e->h_pad) * 2));
+    if (e->cls_shortcut) {
+        const int64_t capC = round_up(capB, 256);                 // token-indexed buffers come in multiples of the 256-row tile (see k_proj)
+        KR_TRY(dmalloc(&e->c_ctx, capC * H * 2)); KR_TRY(dmalloc(&e->c_xb, capC * H * 2)); KR_TRY(dmalloc(&e->c_y, capC * H * 2)); KR_TRY(dmalloc(&e->c_xlo, capC * H));
+        KR_TRY(dmalloc(&e->c_h, capC * (FF + e->h_pad) * 2));
+        KR_HIP(hipMemset(e->c_ctx, 0, (size_t)capC * H * 2)); KR_HIP(hipMemset(e->c_xb, 0, (size_t)capC * H * 2)); KR_HIP(hipMemset(e->c_xlo, 0x80, (size_t)capC * H));
+        KR_TRY(dmalloc(&e->c_off, capB * 4)); KR_TRY(dmalloc(&e->c_nk, capB * 4)); KR_TRY(dmalloc(&e->c_cls, capB * 4)); KR_TRY(dmalloc(&e->d_B, sizeof(int)));
+    }
     e->capT = capT; e->capB = (int)capB; e->capBS = capBS;
     return 0;
 }
@@ -1457,6 +1470,7 @@ int enc_create(const kr_bert_cfg* cfg, int device, int residual_lo, void** out) 
     Encoder* e = new Encoder();
     e->cfg = *cfg; e->device = device;
     e->use_lo = residual_lo != 0;
+    { const char* v = getenv("KIRAG_AMD_CLS_FULL"); e->cls_shortcut = !(v && atoi(v) != 0); }
     { const char* v = getenv("KIRAG_AMD_GRAPH"); e->graphs_off = !(v && atoi(v) != 0); }   // opt-in: measured SLOWER than eager launches on ROCm 7.2 (see run_forward)
     { const char* v = getenv("KIRAG_AMD_HPAD"); e->h_pad = v ? (atoi(v) / 8) * 8 : 0; }   // diagnostic (tools/stamp_hpad.py): a row pitch of h that is not a power of two made no difference
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) e->num_cu = (p.multiProcessorCount / 8) * 8; }
@@ -1563,6 +1577,25 @@ int enc_finalize(void* h) {
     return 0;
 }
 
+// CLS shortcut: row seq_off[b] + seq_cls[b] of ctx / the residual stream (hi, lo) -> row b of the compact buffers; also the compact "sequence" tables
+// (one token per sequence) and the row count for the B-row kernels that follow
+__global__ __launch_bounds__(256) void k_gather_cls(const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ xb, const uint8_t* __restrict__ xlo,
+                                                    const int* __restrict__ seq_off, const int* __restrict__ seq_cls, int H, uint16_t* __restrict__ c_ctx,
+                                                    uint16_t* __restrict__ c_xb, uint8_t* __restrict__ c_xlo, int* __restrict__ c_off, int* __restrict__ c_nk,
+                                                    int* __restrict__ c_cls, int* __restrict__ d_B) {
+    const int b = blockIdx.x;
+    const int64_t src = (int64_t)seq_off[b] + seq_cls[b];
+    for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+        *reinterpret_cast<uint4*>(c_ctx + (int64_t)b * H + i) = *reinterpret_cast<const uint4*>(ctx + src * H + i);
+        *reinterpret_cast<uint4*>(c_xb + (int64_t)b * H + i) = *reinterpret_cast<const uint4*>(xb + src * H + i);
+        if (xlo) *reinterpret_cast<uint2*>(c_xlo + (int64_t)b * H + i) = *reinterpret_cast<const uint2*>(xlo + src * H + i);
+    }
+    if (threadIdx.x == 0) {
+        c_off[b] = b; c_nk[b] = 1; c_cls[b] = 0;
+        if (b == 0) *d_B = (int)gridDim.x;
+    }
+}
+
 // every kernel of one forward, enqueued on `st` (inputs already in e->d_ids / e->d_mask, result left in e->out)
 static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
     const int H = e->cfg.hidden, FF = e->cfg.intermediate;
@@ -1581,6 +1614,8 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->use_lo ? e->xlo : nullptr, e->xb);
     uint8_t* const lo_rw = e->use_lo ? e->xlo : nullptr;       // low half read / written by the inner LayerNorms
+    const bool shortcut = pool == KR_POOL_CLS && e->cls_shortcut && e->c_ctx != nullptr;
+    e->last_shortcut = shortcut;
     for (const LayerW& l : e->L) {
         const bool last = (&l == &e->L.back());
         ProjArgs a{};
@@ -1595,6 +1630,26 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
             else if (nqt >= 3) KR_TRY(launch_attn<1>(e, B, cap, nqt, st));
             else if (nqt == 2) KR_TRY(launch_attn<2>(e, B, cap, nqt, st));
             else KR_TRY(launch_attn<4>(e, B, cap, nqt, st));
+        }
+        if (last && shortcut) {
+            // only the CLS row of every sequence is read after this layer: gather those rows and finish the layer on B rows (same kernels, same arithmetic per
+            // row: the projection loops are bit-identical for every tiling and LayerNorm is per row, so the embedding does not change by one bit)
+            hipLaunchKernelGGL(k_gather_cls, dim3(B), dim3(256), 0, st, e->ctx, e->xb, lo_rw, e->seq_off, e->seq_cls, H, e->c_ctx, e->c_xb, e->c_xlo, e->c_off,
+                               e->c_nk, e->c_cls, e->d_B);
+            uint8_t* const c_lo = e->use_lo ? e->c_xlo : nullptr;
+            const unsigned c_ln_grid = std::min((unsigned)((B + 3) / 4), (unsigned)e->num_cu * 4u);
+            a.Tp = e->d_B;
+            a.W = l.wo; a.X = e->c_ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->c_y; a.ldx = 0; a.ldo = 0;
+            KR_TRY(launch_proj(EPI_DENSE, a, B, e->num_cu, e->device, st));
+            hipLaunchKernelGGL(ln_kernel, dim3(c_ln_grid), dim3(256), 0, st, e->c_y, l.bo_eff, e->d_B, l.ln1g, l.ln1b, eps, H, c_lo, c_lo, e->c_xb);
+            a.W = l.w1; a.X = e->c_xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->c_h; a.ldx = 0; a.ldo = FF + e->h_pad;
+            KR_TRY(launch_proj(EPI_GELU, a, B, e->num_cu, e->device, st));
+            a.W = l.w2; a.X = e->c_h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->c_y; a.ldx = FF + e->h_pad; a.ldo = 0;
+            KR_TRY(launch_proj(EPI_DENSE, a, B, e->num_cu, e->device, st));
+            hipLaunchKernelGGL(ln_kernel, dim3(c_ln_grid), dim3(256), 0, st, e->c_y, l.b2, e->d_B, l.ln2g, l.ln2b, eps, H, c_lo, e->c_xlo, e->c_xb);
+            hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->c_xb, e->c_xlo, e->c_off, e->c_nk, e->c_cls, H, pool, e->out);
+            KR_HIP(hipGetLastError());
+            return 0;
         }
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y; a.ldx = 0; a.ldo = 0;
@@ -1740,6 +1795,8 @@ int enc_last_hidden(void* h, float* out, int B, int S) {
     if (!h || !out) return fail(KR_EINVAL, "NULL argument");
     Encoder* e = reinterpret_cast<Encoder*>(h);
     if (B != e->lastB || S != e->lastS || B == 0) return fail(KR_ESTATE, "no forward of shape [%d,%d] to read back", B, S);
+    if (e->last_shortcut)
+        return fail(KR_ESTATE, "the last forward pooled the CLS token: its last layer ran on the CLS rows only (create the encoder with KIRAG_AMD_CLS_FULL=1 to keep every row)");
     KR_TRY(select_device(e->device));
     KR_HIP(hipStreamSynchronize(e->last_stream));
     const int H = e->cfg.hidden;

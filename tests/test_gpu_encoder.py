@@ -203,6 +203,46 @@ def test_batch_invariance_and_padding_layouts(golden):
     assert "token id" in str(ei.value)
 
 
+def test_cls_pooling_last_layer_on_cls_rows_only_is_bit_identical(golden, monkeypatch):
+    """BGE pooling reads one row per sequence after the last layer: the default path gathers the CLS rows after the last attention and runs the rest of that
+    layer on B rows.  It must equal the all-rows computation (KIRAG_AMD_CLS_FULL=1 at creation) bit for bit — ragged, left-padded, holes, all-masked, one
+    token, short and long sequences (both attention kernels), many sequences (every projection tiling for B rows) — and mean pooling must not be touched."""
+    g = golden("g1_encoder_tiny.npz")
+    cfg = _cfg(g["cfg.t256"])
+    w = E.synth_weights(cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
+                        seed=int(g["weight_seed"]))
+    rng = np.random.default_rng(3)
+    cases = []
+    for B, S in ((6, 40), (3, 200), (300, 33), (70, 64)):
+        ids = rng.integers(5, cfg.vocab_size, (B, S)); mask = np.ones((B, S), np.int64)
+        lens = rng.integers(1, S + 1, B)
+        for b in range(B):
+            mask[b, lens[b]:] = 0
+        mask[1, :] = 1; mask[1, :S // 3] = 0            # left padded: position 0 masked
+        mask[2, 2:5] = 0                                # holes
+        if B > 4:
+            mask[4, :] = 0                              # nothing attended
+        cases.append((ids, mask))
+    h_short = _hip(cfg, w)
+    monkeypatch.setenv("KIRAG_AMD_CLS_FULL", "1")
+    h_full = _hip(cfg, w)
+    monkeypatch.delenv("KIRAG_AMD_CLS_FULL")
+    for ids, mask in cases:
+        a = h_short.forward_np(ids, mask, 1); b = h_full.forward_np(ids, mask, 1)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), ids.shape
+        ref = E.bge_encode(w, ids, mask, cfg.num_attention_heads)
+        ok = ~np.isnan(ref).any(1)
+        _check(a[ok], ref[ok], 4e-3, f"bge {ids.shape}")
+        assert np.isnan(a[~ok]).all()
+        with pytest.raises(Exception) as ei:
+            h_short.last_hidden(*ids.shape)
+        assert "CLS" in str(ei.value)
+        h_full.last_hidden(*ids.shape)                  # the all-rows encoder still serves the debug read-back
+        m = h_short.forward_np(ids, mask, 0); m2 = h_full.forward_np(ids, mask, 0)
+        assert np.array_equal(m.view(np.uint32), m2.view(np.uint32))
+        h_short.last_hidden(*ids.shape)                 # after a mean-pooled forward every row is final again
+
+
 def test_module_surface_eval_hip_train_torch():
     """E5Encoder/BGEEncoder as nn.Modules: eval -> HIP path, train -> autograd path, CPU eval -> loud failure."""
     import torch
