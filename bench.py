@@ -385,7 +385,7 @@ def main():
         # MFMA-pipe utilisation of the same kernel from the committed counter pass (tools/profile_round.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES
         # GRBM_GUI_ACTIVE; tools/pmc_mfma.py): busy cycles of the matrix pipes / (kernel cycles x 1024 SIMDs)
         mfma_busy, mfma_src = None, None
-        for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "mfma_busy.json")), reverse=True):
+        for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "mfma_busy.json")), reverse=True) if traffic is not None else []:   # same-workload rule as the traffic figure
             with open(cand) as f:
                 mj = json.load(f)
             ent = [v for kname, v in mj.items() if "k_coarse" in kname and "false, false" in kname and "mfma_busy" in v]

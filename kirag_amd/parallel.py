@@ -73,6 +73,9 @@ class ShardedSearcher:
             self._comm = None
 
     def __del__(self):
+        import sys
+        if sys.is_finalizing():          # at interpreter exit RCCL / the HIP runtime may already be gone: leave the communicator to process teardown
+            return
         try:
             self.close()
         except Exception:
