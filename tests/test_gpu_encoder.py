@@ -243,6 +243,38 @@ def test_cls_pooling_last_layer_on_cls_rows_only_is_bit_identical(golden, monkey
         h_short.last_hidden(*ids.shape)                 # after a mean-pooled forward every row is final again
 
 
+def test_both_attention_kernels_give_the_same_bits(golden, monkeypatch):
+    """A sequence's embedding must not depend on which attention kernel its batch selects (the embedding cache and batch invariance rely on it): the same
+    sequences in a batch of width 100 (register-staged kernel) and padded to width 200 (LDS-DMA ring kernel); and long ragged sequences through the ring
+    kernel vs the register-staged one forced by KIRAG_AMD_ATTN_LDS=1 (read per forward)."""
+    g = golden("g1_encoder_tiny.npz")
+    cfg = _cfg(g["cfg.t256"])
+    w = E.synth_weights(cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
+                        seed=int(g["weight_seed"]))
+    h = _hip(cfg, w)
+    rng = np.random.default_rng(7)
+    B = 24
+    ids = rng.integers(5, cfg.vocab_size, (B, 100)); mask = np.zeros((B, 100), np.int64)
+    lens = rng.integers(1, 101, B); lens[0] = 100; lens[1] = 64; lens[2] = 65; lens[3] = 32; lens[4] = 33
+    for b in range(B):
+        mask[b, :lens[b]] = 1
+    wide_ids = np.concatenate([ids, np.zeros((B, 100), np.int64)], 1); wide_mask = np.concatenate([mask, np.zeros((B, 100), np.int64)], 1)
+    for pool in (0, 1):
+        a = h.forward_np(ids, mask, pool); b_ = h.forward_np(wide_ids, wide_mask, pool)
+        assert np.array_equal(a.view(np.uint32), b_.view(np.uint32)), pool
+    for S in (129, 200, 300, 512):
+        ids = rng.integers(5, cfg.vocab_size, (9, S)); mask = np.zeros((9, S), np.int64)
+        lens = rng.integers(1, S + 1, 9); lens[0] = S; lens[1] = 128; lens[2] = 129; lens[3] = 64
+        for b in range(9):
+            if b % 4 == 3: mask[b, S - lens[b]:] = 1
+            else: mask[b, :lens[b]] = 1
+        a = h.forward_np(ids, mask, 0)
+        monkeypatch.setenv("KIRAG_AMD_ATTN_LDS", "1")
+        b_ = h.forward_np(ids, mask, 0)
+        monkeypatch.delenv("KIRAG_AMD_ATTN_LDS")
+        assert np.array_equal(a.view(np.uint32), b_.view(np.uint32)), S
+
+
 def test_module_surface_eval_hip_train_torch():
     """E5Encoder/BGEEncoder as nn.Modules: eval -> HIP path, train -> autograd path, CPU eval -> loud failure."""
     import torch
