@@ -1156,9 +1156,18 @@ __device__ __forceinline__ void attn_dma_body(const uint16_t* __restrict__ q, co
 }
 
 __global__ __launch_bounds__(ADMA_THREADS, 512 / ADMA_THREADS) void k_attn_dma(const uint16_t* q, const uint16_t* k, const uint16_t* vT, int64_t ldv, const int* __restrict__ seq_off,
-                                                             const int* __restrict__ seq_nk, const int* __restrict__ seq_nq, int H, int64_t capT, uint16_t* ctx) {
+                                                             const int* __restrict__ seq_nk, const int* __restrict__ seq_nq, int H, int64_t capT, uint16_t* ctx, int heads, int nseq, int qgroups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int head = blockIdx.x, b = blockIdx.y, qg = blockIdx.z;   // heads fastest: the heads of one sequence (same 2-KiB q / k rows) run together
+    // linear block id -> (pair p = b * heads + head, q-group qg).  Consecutive workgroups go to consecutive XCDs (id mod 8), and each XCD has its own L2:
+    // the q-groups of one (sequence, head) read the same K / V^T stream, so they are placed 8 ids apart — same XCD, dispatched together — and the second
+    // reader finds the chunks in L2 (measured: HBM-side traffic of the kernel 1.6 x -> 1.1 x its algorithmic bytes at 128 x 512 tokens).  Heads fastest
+    // inside a group of 8 pairs: the heads of one sequence share their 2-KiB q / k rows.
+    const int G = qgroups;                                 // q-groups per pair
+    const int L = (int)blockIdx.x;
+    const int grp = L / (8 * G), r = L % (8 * G);
+    const int qg = r >> 3, p = grp * 8 + (r & 7);
+    const int b = p / heads, head = p % heads;
+    if (b >= nseq) return;                                 // the grid is padded to whole groups of 8 pairs
     const int nq = seq_nq[b];
     if (qg * ADMA_QT * 32 >= nq) return;                   // block-uniform (nq == 0 included)
     attn_dma_body(q, k, vT, ldv, seq_off[b], seq_nk[b], nq, H, head, qg, capT, ctx, smem);
@@ -1356,8 +1365,10 @@ static int launch_attn(const Encoder* e, int B, int cap, int nqt, hipStream_t st
 
 static int launch_attn_dma(const Encoder* e, int B, int nqt, hipStream_t st) {
     const int qgroups = (nqt + ADMA_QT - 1) / ADMA_QT;       // blocks per (sequence, head): 8 q-tiles each
-    hipLaunchKernelGGL(k_attn_dma, dim3((unsigned)e->cfg.heads, (unsigned)B, (unsigned)qgroups), dim3(ADMA_THREADS), ADMA_LDS, st, e->q, e->k, e->vT, e->ldv,
-                       e->seq_off, e->seq_nk, e->seq_nq, e->cfg.hidden, e->capT, e->ctx);
+    const int64_t pairs = (int64_t)B * e->cfg.heads;
+    const int64_t blocks = (pairs + 7) / 8 * 8 * qgroups;    // whole groups of 8 pairs (see k_attn_dma)
+    hipLaunchKernelGGL(k_attn_dma, dim3((unsigned)blocks), dim3(ADMA_THREADS), ADMA_LDS, st, e->q, e->k, e->vT, e->ldv,
+                       e->seq_off, e->seq_nk, e->seq_nq, e->cfg.hidden, e->capT, e->ctx, e->cfg.heads, B, qgroups);
     return 0;
 }
 

@@ -38,7 +38,8 @@ int main(int argc, char** argv) {
     const int extra_lds = argc > 3 ? atoi(argv[3]) : 0;      // > 32 KiB: only one block fits a CU (one wave per SIMD): how much do two co-resident blocks overlap?
     if (extra_lds) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_dma), hipFuncAttributeMaxDynamicSharedMemorySize, ADMA_LDS + extra_lds));
     auto launch = [&] {
-        hipLaunchKernelGGL(k_attn_dma, dim3(heads, B, qgroups), dim3(ADMA_THREADS), ADMA_LDS + extra_lds, 0, q, k, vT, ldv, d_off, d_nk, d_nq, H, T, ctx);
+        hipLaunchKernelGGL(k_attn_dma, dim3(((B * heads + 7) / 8) * 8 * qgroups), dim3(ADMA_THREADS), ADMA_LDS + extra_lds, 0, q, k, vT, ldv, d_off, d_nk, d_nq, H, T, ctx,
+                           heads, B, qgroups);
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) launch();
