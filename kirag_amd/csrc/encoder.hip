@@ -1613,7 +1613,8 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
     const float eps = e->cfg.ln_eps;
     hipLaunchKernelGGL(k_seq_len, dim3(B), dim3(64), 0, st, e->d_mask, B, S, e->seq_nk, e->seq_has0);
     const int nqt_max = (S + (pool == KR_POOL_CLS ? 1 : 0) + 31) / 32;             // q-tiles of the longest possible sequence
-    const bool long_seq = nqt_max > 4 && !getenv("KIRAG_AMD_ATTN_LDS");            // > 128 tokens: the LDS-DMA attention kernel (KIRAG_AMD_ATTN_LDS=1: A/B against the register-staged one)
+    const bool long_seq = (nqt_max > 4 && !getenv("KIRAG_AMD_ATTN_LDS")) || (getenv("KIRAG_AMD_ATTN_DMA") && atoi(getenv("KIRAG_AMD_ATTN_DMA")) != 0);   // KIRAG_AMD_ATTN_DMA=1: the ring kernel for short sequences too (A/B)
+            // > 128 tokens: the LDS-DMA attention kernel (KIRAG_AMD_ATTN_LDS=1: A/B against the register-staged one)
     const int align = long_seq ? 8 : 4;                                            // sequence offsets: multiple of 8 tokens so that V^T chunks start 16-B aligned
     hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(64), 0, st, e->seq_nk, e->seq_has0, B, pool, align, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->d_err);
     hipLaunchKernelGGL(k_fill_tokens, dim3(B), dim3(64), 0, st, e->d_ids, e->d_mask, S, e->cfg.vocab, align, e->seq_off, e->seq_nk, e->seq_nq, e->tok_id,
