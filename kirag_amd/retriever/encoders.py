@@ -120,8 +120,35 @@ class HipBertForward:
         return out
 
     def check(self) -> None:
-        """Wait for the last device-output forward and raise if it saw a token id outside the vocabulary (``kr_encoder_check``)."""
+        """Wait for the last device-output forward and raise if it saw a token id outside the vocabulary (``kr_encoder_check``) or a
+        non-zero ``token_type_ids`` entry (deferred like the token ids: see ``defer_token_type_check``)."""
+        self.poll_token_type(block=True)
         _lib.check(self._lib.kr_encoder_check(self._h))
+
+    _TT_MSG = "token_type_ids != 0 is not used by any KiRAG caller and is not implemented on the HIP path"
+
+    def defer_token_type_check(self, token_type_ids: Tensor) -> None:
+        """``token_type_ids`` on the DEVICE: testing them with ``bool(t.any())`` would synchronise the host with the stream on every forward (the
+        module surface is enqueue-only).  The test runs on the stream instead, its one-byte result goes to pinned memory, and it is looked at when it
+        has arrived: at a later forward, or in ``check()`` at the latest — the same contract as out-of-vocabulary token ids."""
+        flag = torch.empty(1, dtype=torch.bool, pin_memory=True)
+        flag.copy_((token_type_ids != 0).any().reshape(1), non_blocking=True)
+        ev = torch.cuda.Event(); ev.record()
+        pend = self.__dict__.setdefault("_tt_pending", [])
+        pend.append((ev, flag))
+
+    def poll_token_type(self, block: bool = False) -> None:
+        pend = self.__dict__.get("_tt_pending")
+        while pend:
+            ev, flag = pend[0]
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            pend.pop(0)
+            if bool(flag[0]):
+                pend.clear()
+                raise NotImplementedError(self._TT_MSG)
 
     def last_hidden(self, B: int, S: int) -> Tensor:
         out = torch.empty((B, S, self.hidden), dtype=torch.float32)
@@ -143,8 +170,8 @@ class _HipSentenceEncoder(BertModel):
             raise RuntimeError(
                 f"{type(self).__name__} in eval mode runs on the MI355X HIP path only; its parameters are on {p.device}. "
                 "Move the model to a GPU (kirag_amd has no CPU fallback).")
-        if token_type_ids is not None and bool((token_type_ids != 0).any()):
-            raise NotImplementedError("token_type_ids != 0 is not used by any KiRAG caller and is not implemented on the HIP path")
+        if token_type_ids is not None and not token_type_ids.is_cuda and bool((token_type_ids != 0).any()):
+            raise NotImplementedError(HipBertForward._TT_MSG)          # host tensor: tested here
         if input_ids.dim() != 2:
             raise ValueError(f"input_ids must be [B,S], got {tuple(input_ids.shape)}")
         idx = p.device.index if p.device.index is not None else torch.cuda.current_device()
@@ -152,6 +179,9 @@ class _HipSentenceEncoder(BertModel):
             self._hip = HipBertForward(self.config, idx)
         self._hip.sync(self)
         with torch.cuda.device(idx):
+            self._hip.poll_token_type()                                # deferred tests of earlier forwards that have arrived
+            if token_type_ids is not None and token_type_ids.is_cuda:
+                self._hip.defer_token_type_check(token_type_ids)       # device tensor: no host synchronisation on the forward path
             return self._hip.forward(input_ids.to(p.device), attention_mask, self._pool)
 
     def invalidate_hip_weights(self) -> None:

@@ -163,7 +163,11 @@ class DenseRetriever(nn.Module):
         for s in range(0, len(texts), self.encode_batch_size):
             inputs = to_device(encode(texts[s:s + self.encode_batch_size], max_length=max_length, **kwargs), self.device)
             chunks.append(embed(inputs).detach())
-        return torch.cat(chunks, dim=0).cpu()
+        out = torch.cat(chunks, dim=0).cpu()
+        hip = getattr(getattr(self.retriever, "encoder", None), "_hip", None)
+        if hip is not None:
+            hip.check()                                     # deferred input errors (token ids outside the vocabulary, token_type_ids != 0) surface here
+        return out
 
     def calculate_query_embeddings(self, queries: List[str], max_length: int = None, verbose: bool = False, **kwargs) -> Tensor:
         return self._embed(queries, "query", max_length, verbose, **kwargs)

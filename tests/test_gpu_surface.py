@@ -290,3 +290,29 @@ def test_config4_flow_streamed_bge_encode_into_resident_shard_then_search(golden
         back = ShardedIndexer(H); back.deserialize_from(nat)
         res3 = back.search_knn(qv, 10, verbose=False)
         assert all(res3[r][0] == res[r][0] and np.array_equal(res3[r][1], res[r][1]) for r in range(4))
+
+
+def test_token_type_ids_are_checked_without_a_host_synchronisation(golden):
+    """token_type_ids != 0 is not implemented on the HIP path and must be refused — but testing a DEVICE tensor with bool(t.any()) would synchronise the host
+    with the stream on every forward of the module surface.  Host tensors are tested at once; device tensors on the stream, reported by a later forward or
+    by check() at the latest (the contract of out-of-vocabulary token ids)."""
+    from transformers import BertConfig
+    from kirag_amd.retriever.encoders import E5Encoder
+    g = golden("g4_g8_retriever.npz")
+    H, L, heads, FF, vocab, max_pos = [int(v) for v in g["cfg"]]
+    cfg = BertConfig(vocab_size=vocab, hidden_size=H, num_hidden_layers=L, num_attention_heads=heads, intermediate_size=FF, max_position_embeddings=max_pos)
+    m = E5Encoder(cfg, add_pooling_layer=False).cuda().eval()
+    ids = torch.randint(5, vocab, (4, 12)); mask = torch.ones_like(ids)
+    zeros = torch.zeros_like(ids); bad = zeros.clone(); bad[2, 3] = 1
+    ref = m(ids.cuda(), mask.cuda(), zeros.cuda())
+    m._hip.check()
+    assert torch.equal(m(ids.cuda(), mask.cuda(), zeros), ref) and torch.equal(m(ids.cuda(), mask.cuda()), ref)
+    with pytest.raises(NotImplementedError):
+        m(ids.cuda(), mask.cuda(), bad)                         # host tensor: refused before anything is enqueued
+    out = m(ids.cuda(), mask.cuda(), bad.cuda())                # device tensor: the forward itself only enqueues
+    assert out.shape == ref.shape
+    with pytest.raises(NotImplementedError):
+        m._hip.check()
+    m._hip.check()                                              # reported once
+    assert torch.equal(m(ids.cuda(), mask.cuda(), zeros.cuda()), ref)
+    m._hip.check()
