@@ -62,8 +62,9 @@ def model_encode(inputs: Dict[str, Tensor]) -> Tensor:
 def _embed(texts: List[str], max_length: int, batch_size: int) -> Tensor:
     # rows are independent of batch composition on the HIP path: one launch for the whole (short) list
     step = max(batch_size, 256)
-    outs = [model_encode(tokenizer_encode(texts[i:i + step], max_length=max_length)).detach().cpu() for i in range(0, len(texts), step)]
-    return torch.cat(outs, dim=0)
+    # every chunk is only ENQUEUED; the one device-to-host copy at the end is the only synchronisation (the reference copies per batch of 4)
+    outs = [model_encode(tokenizer_encode(texts[i:i + step], max_length=max_length)).detach() for i in range(0, len(texts), step)]
+    return torch.cat(outs, dim=0).cpu()
 
 
 def get_e5_embeddings_for_query(query_list: List[str], max_length: int = 128, batch_size: int = 4) -> Tensor:
