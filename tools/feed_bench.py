@@ -83,3 +83,31 @@ for depth, workers in ((2, 0), (8, 0), (2, 8), (8, 8)):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"[end to end] prefetch_batches={depth} tokenizer_workers={workers}: {n / dt:.0f} passages/s = {n / dt / enc_rate * 100:.0f} % of the encoder-only rate", flush=True)
+
+# the same loop through the MODULE surface the reference's callers use (E5Encoder.forward with input_ids / attention_mask / token_type_ids on the device):
+# until round 3 its token_type_ids test synchronised the host on every forward (now deferred, retriever/encoders.py)
+from transformers import BertConfig
+from kirag_amd.retriever.encoders import E5Encoder
+cfg = BertConfig(vocab_size=30522, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, max_position_embeddings=512)
+del hip
+mod = E5Encoder(cfg, add_pooling_layer=False).to(dev).eval()
+class ModelM:
+    encoder = mod
+    def to(self, d): return self
+    def eval(self): return self
+    def doc(self, a): return mod(**a)
+warm = SimpleNamespace(local_rank=-1, save_dir=td, name="f", index_folder="warm", per_gpu_batch_size=8, num_passage_per_index_file=10**9,
+                       encode_batch_size=512, prefetch_batches=8, tokenizer_workers=8, no_embedding_files=True)
+class Small(Corpus):
+    def __len__(self): return 4096
+CC.cal_doc_embeddings(warm, ModelM(), Small(), col, device=dev)
+for sync in (False, True):
+    if sync:      # emulate the old behaviour: a host round trip per forward
+        mod._hip.defer_token_type_check = lambda t: bool((t != 0).any())
+    args = SimpleNamespace(**{**vars(warm), "index_folder": "m%d" % int(sync)})
+    t0 = time.perf_counter()
+    CC.cal_doc_embeddings(args, ModelM(), Corpus(), col, device=dev)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tag = " + a host synchronisation per forward (the rounds 1-2 behaviour)" if sync else ""
+    print(f"[end to end, module surface{tag}] prefetch_batches=8 tokenizer_workers=8: {n / dt:.0f} passages/s = {n / dt / enc_rate * 100:.0f} % of the encoder-only rate", flush=True)
