@@ -501,7 +501,12 @@ __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage
 // read back 16 B per lane: a store instruction writes 64-B runs of sixteen V^T rows.
 template <class Shape, bool NT>
 __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ outT, int64_t ldT, int64_t t0, int f0) {
-    const int c = acc.lane & 31, h = acc.lane >> 5;
+    // the lane id is made opaque HERE: everything below that depends on it (LDS offsets, the 64-bit V^T addresses) is then recomputed per tile (a few VALU
+    // instructions) instead of being hoisted out of the persistent tile loop into registers the main loop has no room for — hipcc spilled them, and the
+    // scratch reloads (VMEM, followed by s_waitcnt vmcnt(0)) drained the LDS-DMA ring in every V^T tile (tests/test_capi_and_host.py: no spills allowed)
+    int ln = acc.lane;
+    asm volatile("" : "+v"(ln));
+    const int c = ln & 31, h = ln >> 5;
 #pragma unroll
     for (int mi = 0; mi < Shape::TM; ++mi)
 #pragma unroll
@@ -511,7 +516,7 @@ __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char*
                 *reinterpret_cast<uint16_t*>(stage + ((r & 3) + 8 * (r >> 2) + 4 * h) * 80 + c * 2) = ET::from_f32(acc.v[mi][ni][r]);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int fl = p * 16 + (acc.lane >> 2), ch = acc.lane & 3;
+                const int fl = p * 16 + (ln >> 2), ch = ln & 3;
                 const uint4 d = *reinterpret_cast<const uint4*>(stage + fl * 80 + ch * 16);
                 u32x4_t* dst = reinterpret_cast<u32x4_t*>(outT + (int64_t)(f0 + ni * 32 + fl) * ldT + t0 + mi * 32 + ch * 8);
                 if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d), dst);
@@ -838,6 +843,7 @@ __device__ __forceinline__ void attn_step64(AttnState& s, const uint4 (&qf)[4], 
 
 // normalise a finished 32-query tile and store it as whole 128-B rows of ctx through the wave-private 4-KiB LDS block Os
 __device__ __forceinline__ void attn_store_tile(const AttnState& s, char* Os, uint16_t* __restrict__ ctx, int64_t off, int q0, int nq, int H, int head, int lane) {
+    asm volatile("" : "+v"(lane));   // opaque: the store addresses are computed here, after the key loop, instead of living in registers (or scratch) across it
     const int c = lane & 31, hf = lane >> 5;
     // a query with no attendable key (all-masked sequence) is 0/0 = NaN, as under HF's -inf masking
     const float inv = 1.0f / s.l;
@@ -871,7 +877,8 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
                                                   const int* __restrict__ seq_off, const int* __restrict__ seq_nk, const int* __restrict__ seq_nq,
                                                   int H, int heads, int kchunk, uint16_t* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction; as a scalar, the head / q-tile / LDS bases derived from it cost no VGPRs
     const int hb = blockIdx.x, b = blockIdx.y;            // heads fastest: the heads of one sequence (same 2-KiB q/k rows) run together
     const int nq = seq_nq[b];
     constexpr int QT = 4 / HPB;                           // q-tiles per block (one per wave and head)
@@ -912,8 +919,10 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
             // all heads of the block in ONE batch: every global load (K and V^T of up to HPB heads) is issued before the first LDS store, so a block with
             // 2 / 4 heads pays one memory round trip per batch, not one per head (a 32-token sequence is a single batch)
             const int nkcs = nkp * 8, nvc = 64 * cpr;
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));      // opaque: the staging indices are derived per chunk and die with it (the key loop below runs at the register limit)
             for (int base = 0; base < nkcs || base < nvc; base += 256 * NB) {
-                uint4 kv[HPB][NB]; uint2 vv[HPB][NB]; int vd[NB], vk[NB];
+                uint4 kv[HPB][NB]; uint2 vv[HPB][NB];
 #pragma unroll
                 for (int h2 = 0; h2 < HPB; ++h2) {
                     const int head2 = hb * HPB + h2;
@@ -925,21 +934,19 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
                         if (head2 < heads && i < nkcs && key < nkc) kv[h2][j] = *reinterpret_cast<const uint4*>(k + (off + kc0 + key) * H + head2 * 64 + ch * 8);
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int i = base + j * 256 + tid;
-                    const int d = (int)__umulhi((unsigned)i, cpr_magic), kc = i - d * cpr;   // i / cpr (exact: i < 2^16, cpr <= 128)
-                    vd[j] = d; vk[j] = kc;
-                }
+                // (d row, 8-byte chunk) of element i of the V^T staging: i / cpr and i % cpr (exact: i < 2^16, cpr <= 128); recomputed where needed (two VALU
+                // instructions) instead of being kept in registers across the loads — the kernel runs at the 168-register limit of three blocks per CU
+                auto vsplit = [&](int i, int& d, int& kc) { d = (int)__umulhi((unsigned)i, cpr_magic); kc = i - d * cpr; };
 #pragma unroll
                 for (int h2 = 0; h2 < HPB; ++h2) {
                     const int head2 = hb * HPB + h2;
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
                         const int i = base + j * 256 + tid;
+                        int vd, vk; vsplit(i, vd, vk);
                         vv[h2][j] = make_uint2(0u, 0u);
-                        if (head2 < heads && i < nvc && vk[j] * 4 < nkc)
-                            vv[h2][j] = *reinterpret_cast<const uint2*>(vT + (int64_t)(head2 * 64 + vd[j]) * ldv + off + kc0 + vk[j] * 4);   // off, kc0 % 4 == 0: 8-B aligned
+                        if (head2 < heads && i < nvc && vk * 4 < nkc)
+                            vv[h2][j] = *reinterpret_cast<const uint2*>(vT + (int64_t)(head2 * 64 + vd) * ldv + off + kc0 + vk * 4);   // off, kc0 % 4 == 0: 8-B aligned
                     }
                 }
 #pragma unroll
@@ -960,13 +967,14 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
                         const int i = base + j * 256 + tid;
-                        const int key0 = vk[j] * 4;
+                        int vd, vk; vsplit(i, vd, vk);
+                        const int key0 = vk * 4;
                         uint2 v = vv[h2][j];
                         if (key0 + 4 > nkc) {      // keys >= nk (padding / the next sequence) are stored as zero
                             v.x &= (key0 + 0 < nkc ? 0xffffu : 0u) | (key0 + 1 < nkc ? 0xffff0000u : 0u);
                             v.y &= (key0 + 2 < nkc ? 0xffffu : 0u) | (key0 + 3 < nkc ? 0xffff0000u : 0u);
                         }
-                        if (i < nvc) *reinterpret_cast<uint2*>(Vw + vd[j] * vpitch + vk[j] * 8) = v;
+                        if (i < nvc) *reinterpret_cast<uint2*>(Vw + vd * vpitch + vk * 8) = v;
                     }
                 }
             }
@@ -1027,10 +1035,15 @@ __device__ __forceinline__ void attn_dma_body(const uint16_t* __restrict__ q, co
     // DMA of one chunk: 16 pieces of 1 KiB (8 K pieces = 8 keys x 128 B each, 8 V^T pieces = 8 d rows x 128 B each); wave w issues pieces
     // w * ADMA_PIECES .. + ADMA_PIECES - 1 of both.  lane -> row 8 p + (lane >> 3), 16-B chunk (lane & 7) ^ swizzle(row) of that row (the LDS destination is
     // lane-linear: the swizzle sits on the source)
-    const char* kbase = reinterpret_cast<const char*>(k) + (int64_t)head * 128;
-    const char* vbase = reinterpret_cast<const char*>(vT) + ((int64_t)head * 64) * ldv * 2 + off * 2;
-    // addresses = a wave-uniform chunk base (scalar registers) + a 32-bit per-lane offset that does not change from chunk to chunk.  Rows past the
-    // sequence (last chunk) are read and masked; the K buffer has 64 rows and V^T 64 columns of slack behind the last token (ensure_capacity)
+    // addresses = a buffer resource per operand whose base is this (sequence, head)'s first byte (scalar registers) + a wave-uniform chunk offset (the
+    // instruction's scalar offset) + a 32-bit per-lane offset that never changes: buffer_load_dwordx4 ... lds.  (With global_load_lds the compiler kept four
+    // zero-extended 64-bit lane offsets, spilled them at the 256-register limit and reloaded them — s_waitcnt vmcnt(0) each — in front of the DMA of the
+    // partial last chunk.)  Rows past the sequence (last chunk) are read and masked; the K buffer has 64 rows and V^T 64 columns of slack behind the last
+    // token (ensure_ws), so nothing is out of range.
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(k)) + (int64_t)head * 128 + off * H * 2, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(vT)) + ((int64_t)head * 64) * ldv * 2 + off * 2, 0, 0xffffffff, 0x00020000);
     uint32_t klane[ADMA_PIECES], vlane[ADMA_PIECES];
 #pragma unroll
     for (int pp = 0; pp < ADMA_PIECES; ++pp) {
@@ -1041,13 +1054,12 @@ __device__ __forceinline__ void attn_dma_body(const uint16_t* __restrict__ q, co
     }
     auto issue = [&](int cidx) {
         char* stg = smem + (cidx % ADMA_RING) * ADMA_STAGE;
-        const char* kc = kbase + (off + (int64_t)cidx * 64) * H * 2;
-        const char* vc = vbase + (int64_t)cidx * 128;
+        const int kc = cidx * 64 * H * 2, vc = cidx * 128;             // chunk offsets (bytes): <= 512 tokens per sequence
 #pragma unroll
         for (int pp = 0; pp < ADMA_PIECES; ++pp) {
             const int p = wave * ADMA_PIECES + pp;
-            __builtin_amdgcn_global_load_lds((gbl_void*)(kc + klane[pp]), (lds_void*)(stg + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(vc + vlane[pp]), (lds_void*)(stg + 8192 + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)(stg + p * 1024), 16, klane[pp], kc, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(stg + 8192 + p * 1024), 16, vlane[pp], vc, 0, 0);
         }
     };
     issue(0);

@@ -502,43 +502,54 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
     const int nk = K / BK;
     const int64_t total_g = my * nk;
 
-    // ---- DMA cursors: a position in this block's K-tile stream + per-lane source offsets of 4 pieces -------------------
+    // ---- DMA cursors: a position in this block's K-tile stream.  A piece's address = a buffer resource whose base is the first row of the cursor's
+    // output tile (scalar registers, re-made once per output tile) + the K-tile's byte offset (the instruction's scalar offset) + a 32-bit per-lane
+    // offset that never changes (row inside the tile and swizzled 16-B chunk): buffer_load_dwordx4 ... lds.  Rows past the end of the operand (a partial
+    // last tile) are out of the resource's range and arrive as zeros (their results are never read: see the callers), so nothing is clamped per tile.
+    // (global_load_lds with 64-bit per-lane addresses cost 16 VGPRs for the two cursors' pieces, 64-bit VALU adds per piece in every interval and a
+    // per-lane offset rebuild at every output tile.)
     struct Cursor {
         int64_t tile; int kt; int slot;      // output tile index (in this block's sequence), K-tile inside it, ring slot of the stream index
-        const char* base; uint32_t off[4];
+        __amdgpu_buffer_rsrc_t rs;
     };
-    auto set_base = [&](Cursor& c, bool isA, int piece0) {
+    auto lane_off = [&](int piece0, int64_t ld, uint32_t (&off)[4]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = (piece0 + p) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            off[p] = (uint32_t)(row * ld * 2 + chunk * 16);
+        }
+    };
+    auto set_base = [&](Cursor& c, bool isA) {
         int64_t m0, n0;
         coord(xcd_chunk_map((int64_t)blockIdx.x + c.tile * G, total_tiles), m0, n0);
         const int64_t r0 = isA ? m0 : n0, ld = isA ? lda : ldb, left = (isA ? M : N) - r0;
-        c.base = reinterpret_cast<const char*>((isA ? A : B) + r0 * ld);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int row = (piece0 + p) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            if (row >= left) row = (int)left - 1;
-            c.off[p] = (uint32_t)(row * ld * 2 + chunk * 16);
-        }
+        const uint64_t base = reinterpret_cast<uint64_t>((isA ? A : B) + r0 * ld);
+        const uint64_t bytes = (uint64_t)left * (uint64_t)ld * 2u;
+        // the tile coordinates come out of VALU arithmetic (fast_divmod): tell the compiler they are wave-uniform
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        const uint32_t num = __builtin_amdgcn_readfirstlane(bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes);
+        c.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0, (int)num, 0x00020000);
     };
-    auto init_cursor = [&](Cursor& c, int64_t s, bool isA, int piece0) {
+    auto init_cursor = [&](Cursor& c, int64_t s, bool isA) {
         c.slot = (int)(s & 1);
         if (s >= total_g) s = total_g - 1;
         c.tile = s / nk; c.kt = (int)(s - c.tile * nk);
-        set_base(c, isA, piece0);
+        set_base(c, isA);
     };
-    auto issue4 = [&](Cursor& c, bool isA, int piece0) {
+    auto issue4 = [&](Cursor& c, bool isA, int piece0, const uint32_t (&off)[4]) {
         char* dst = smem + c.slot * STAGE + (isA ? 0 : ABYTES) + piece0 * 1024;
-        const char* src = c.base + (int64_t)c.kt * (BK * 2);
+        const int koff = c.kt * (BK * 2);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             // A_NT: the A operand is a once-through stream (the corpus of the coarse scan): non-temporal, so that it does not push the small,
             // re-used B operand (the query block) out of L2
-            if (A_NT && isA) __builtin_amdgcn_global_load_lds((gbl_void*)(src + c.off[p]), (lds_void*)(dst + p * 1024), 16, 0, 2);
-            else __builtin_amdgcn_global_load_lds((gbl_void*)(src + c.off[p]), (lds_void*)(dst + p * 1024), 16, 0, 0);
+            if (A_NT && isA) __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rs, (lds_void*)(dst + p * 1024), 16, off[p], koff, 0, 2);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rs, (lds_void*)(dst + p * 1024), 16, off[p], koff, 0, 0);
         }
         c.slot ^= 1;
         if (c.kt + 1 < nk) { ++c.kt; }
-        else if (c.tile + 1 < my) { c.kt = 0; ++c.tile; set_base(c, isA, piece0); }
+        else if (c.tile + 1 < my) { c.kt = 0; ++c.tile; set_base(c, isA); }
         // else: end of the stream, stay on the last K-tile (dummy re-loads)
     };
 
@@ -548,14 +559,18 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
     // ---- prologue: K-tile 0 completely, A rows 0..127 of K-tile 1 ---------------------------------------------------------
     {
         Cursor c;
-        init_cursor(c, 0, true, wave * 4);  { Cursor d = c; issue4(d, true, wave * 4); }
-        init_cursor(c, 0, false, wave * 4); { Cursor d = c; issue4(d, false, wave * 4); }
+        uint32_t pa[4], pb[4];
+        lane_off(wave * 4, lda, pa); lane_off(wave * 4, ldb, pb);
+        init_cursor(c, 0, true);  { Cursor d = c; issue4(d, true, wave * 4, pa); }
+        init_cursor(c, 0, false); { Cursor d = c; issue4(d, false, wave * 4, pb); }
         // A rows 0..127 of tile 1 = 16 pieces = 2 per wave; issue4 moves 4 pieces, so waves 0..3 take them (pieces 4*wave .. +3)
-        if (wave < 4) { init_cursor(c, 1, true, wave * 4); issue4(c, true, wave * 4); }
+        if (wave < 4) { init_cursor(c, 1, true); issue4(c, true, wave * 4, pa); }
     }
     Cursor cx, cy;
-    init_cursor(cx, 1, false, xpiece);
-    init_cursor(cy, grp ? 2 : 1, true, ypiece);
+    uint32_t offx[4], offy[4];                     // per-lane piece offsets of the two cursors: fixed for the whole kernel
+    lane_off(xpiece, ldb, offx); lane_off(ypiece, lda, offy);
+    init_cursor(cx, 1, false);
+    init_cursor(cy, grp ? 2 : 1, true);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (grp) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind group 0
@@ -596,7 +611,7 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
                 for (int ni = 0; ni < 4; ++ni) bf16v[ni] = *reinterpret_cast<const uint4*>(sb + (wq * 64 + ni * 16 + r16) * 128 + coff16);
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) af16[mi] = *reinterpret_cast<const uint4*>(sa + (grp * 128 + mi * 16 + r16) * 128 + coff16);
-                if (h == 0) issue4(cx, false, xpiece); else issue4(cy, true, ypiece);
+                if (h == 0) issue4(cx, false, xpiece, offx); else issue4(cy, true, ypiece, offy);
                 wait_vmcnt<4>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -626,7 +641,7 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) af[k2][mi] = *reinterpret_cast<const uint4*>(sa + a_row_byte + mi * 32 * 128 + coff);
             }
-            if (h == 0) issue4(cx, false, xpiece); else issue4(cy, true, ypiece);
+            if (h == 0) issue4(cx, false, xpiece, offx); else issue4(cy, true, ypiece, offy);
             wait_vmcnt<4>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);

@@ -145,6 +145,7 @@ struct Index {
     int num_cu = 256;
     // environment switches, read ONCE at kr_index_create (round 2 called getenv() on every search)
     bool no_q32 = false, no_fine = false, no_mark = false, no_vmm = false;
+    int epiv = 0;   // -DKR_EXPERIMENT builds: k_coarse epilogue variant (KIRAG_AMD_EPIV)
     // asynchronous search (kr_index_search_async ... kr_index_search_finish): pass 1 of every block is enqueued, the per-query certificate flags
     // land in pinned memory behind it; finish() reads them and runs the rare passes 2 / 3
     struct Pending {
@@ -298,7 +299,9 @@ __device__ __forceinline__ void scatter_wave_lists(const CoarseArgs& a, char* sm
 // SMALLQ (at most 128 queries in the block: the KiRAG loop's 1-2 queries per hop, single-question retrieval): 128-row x 128-query tiles on the
 // producer / consumer loop (gemm_nt_split) instead of 256 x 256 on the ping-pong loop.  With a 256-query tile a small batch pays the MFMA time of 256
 // queries (2.0 ms per 5M rows, above the 1.3-1.6 ms the corpus needs to cross HBM); with 128 the scan is HBM-bound.
-template <class T, bool DIRECT, bool SMALLQ = false>
+// EPIV (experiments, -DKR_EXPERIMENT builds only; the product instantiates 0): 1 = the survivor path laid out as the unlikely branch, 2 = survivors
+// counted but never stored (diagnostic, wrong results), 3 = no filter at all (diagnostic)
+template <class T, bool DIRECT, bool SMALLQ = false, int EPIV = 0>
 __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
     using S = std::conditional_t<SMALLQ, ShapeSplit, ShapeC>;      // S::NWAVE = waves that own accumulators (4 of the 8 with SMALLQ)
     constexpr int RING_BYTES = SMALLQ ? SPLIT_RING * ShapeSplit::STAGE_BYTES : COARSE_STAGES * ShapeC::STAGE_BYTES;
@@ -355,14 +358,19 @@ __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
                     for (int mi = 0; mi < S::TM; ++mi) {
                         // (a block-level pre-test — the max of the lane's 16 scores against the threshold, ONE branch per 32 x 32 block instead of 16
                         // taken ones — was measured 7 % SLOWER in an interleaved A/B on one device, profiles/r02/ab_coarse_blockmax_epilogue.txt)
+                        if constexpr (EPIV == 3) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(acc.v[mi][ni][r]));
+                            continue;
+                        }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
                             const float s = acc.v[mi][ni][r];
                             const bool p = (s >= t);
                             const unsigned long long mask = __ballot(p);
-                            if (mask) {
-                                if (p) {
+                            if (EPIV == 1 ? __builtin_expect(mask != 0ull, 0) : (mask != 0ull)) {
+                                if (EPIV != 2 && p) {
                                     const unsigned int slot = wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                                     u32x4 e = {__float_as_uint(s), row_base + (uint32_t)ro, q, 0u};
                                     __builtin_amdgcn_raw_buffer_store_b128(e, wlist, slot * 16u, 0, 0);
@@ -1310,6 +1318,11 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
+#ifdef KR_EXPERIMENT
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
+#endif
         return 0;
     }));
     int final_preset = 0;
@@ -1320,6 +1333,11 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
             if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
             else hipLaunchKernelGGL((k_coarse<T, false, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
         } else if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+#ifdef KR_EXPERIMENT
+        else if (ix->epiv == 1) hipLaunchKernelGGL((k_coarse<T, false, false, 1>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+        else if (ix->epiv == 2) hipLaunchKernelGGL((k_coarse<T, false, false, 2>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+        else if (ix->epiv == 3) hipLaunchKernelGGL((k_coarse<T, false, false, 3>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+#endif
         else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
         return 0;
     }, final_preset, rounds));
@@ -1595,6 +1613,9 @@ int kr_index_create(int d, int metric, int coarse_dtype, int device, kr_index** 
     (void)hipMemset(ix->bounds, 0, 2 * sizeof(float));
     ix->no_q32 = getenv("KIRAG_AMD_NO_Q32") != nullptr; ix->no_fine = getenv("KIRAG_AMD_NO_FINE") != nullptr;
     ix->no_mark = getenv("KIRAG_AMD_NO_MARK") != nullptr; ix->no_vmm = getenv("KIRAG_AMD_NO_VMM") != nullptr;
+#ifdef KR_EXPERIMENT
+    { const char* v = getenv("KIRAG_AMD_EPIV"); ix->epiv = v ? atoi(v) : 0; }
+#endif
     *out = reinterpret_cast<kr_index*>(ix);
     return 0;
 }

@@ -1,0 +1,47 @@
+"""Static checks of the BUILT product library (no GPU): register allocation of every gfx950 kernel in kirag_amd/libkirag_amd.so.
+
+A spilled vector register is a scratch store / reload — a VMEM operation in the same in-order queue as the LDS-DMA rings, which hipcc follows with
+`s_waitcnt vmcnt(0)`: in round 3's library that drained the ring in the V^T tiles of the QKV projection and in front of the DMA of k_attn_dma's
+partial chunk.  The library must carry none."""
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+LIB = os.path.join(REPO, "kirag_amd", "libkirag_amd.so")
+
+
+@pytest.fixture(scope="module")
+def notes():
+    import kernel_notes
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    if not os.path.exists(kernel_notes.READELF):
+        pytest.skip("llvm-readelf not installed")
+    ks = kernel_notes.kernels(LIB)
+    assert len(ks) > 100, "expected the search + two encoder code objects"
+    return ks
+
+
+def test_no_product_kernel_spills_vector_registers(notes):
+    bad = [(k["name"], k.get("vgpr_spill_count", 0), k.get("private_segment_fixed_size", 0)) for k in notes
+           if k.get("vgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0)]
+    assert not bad, "kernels with scratch memory: %r" % bad
+
+
+def test_hot_kernels_keep_their_occupancy(notes):
+    by = {k["name"]: k for k in notes}
+    def find(*parts):
+        hits = [k for n, k in by.items() if all(p in n for p in parts)]
+        assert hits, parts
+        return hits
+    # ping-pong GEMMs and the coarse scan: two waves per SIMD (<= 256 registers each); the short-sequence attention: three blocks per CU (<= 168)
+    for k in find("k_projILi", "GemmShapeILi256ELi256") + find("k_coarseINS", "ELb0ELi0E"):
+        assert k["vgpr_count"] + k.get("agpr_count", 0) <= 256, k
+    for k in find("k_attn_ldsILi"):
+        assert k["vgpr_count"] <= 168, k
+    for k in find("k_attn_dma"):
+        assert k["vgpr_count"] <= 256, k

@@ -40,7 +40,7 @@ for rnd in range(8):
         res[v].append((np.median(cs), np.median(ts)))
         r = rows.cpu().numpy()
         ref = r if ref is None else ref
-        assert np.array_equal(r, ref), "variants disagree"
+        assert os.environ.get("AB_NOCHECK") or np.array_equal(r, ref), "variants disagree"   # AB_NOCHECK=1: diagnostic variants with wrong results
 for v in vals:
     a = np.array(res[v])
     print(f"{var}={v}: coarse median {np.median(a[:, 0]):.3f} ms (min {a[:, 0].min():.3f}), total median {np.median(a[:, 1]):.3f} ms; per round {np.round(a[:, 0], 3).tolist()}")
