@@ -49,8 +49,9 @@ def parse():
     ap.add_argument("--collective", default="torch", choices=["torch", "kr_comm"],
                     help="N > 1: exchange of the per-shard result lists through torch.distributed (default) or the library's own RCCL step (kr_shard_allgather_topk)")
     ap.add_argument("--encode-split", default="batch", choices=["batch", "queries"],
-                    help="N > 1: 'batch' = rank r encodes the whole query batch of every W-th step (one all-gather of W batches per W steps); "
-                         "'queries' = every rank encodes 1/W of every batch (round-2 schedule)")
+                    help="N > 1: 'batch' = up to W consecutive steps form a block: every rank encodes its 1/W slice of EVERY batch of the block in ONE "
+                         "forward (a full-size batch per rank and block), one all-gather of the block's query vectors, then the block's searches enqueue-only "
+                         "with one host synchronisation per block; 'queries' = every rank encodes 1/W of every batch, step by step (round-2 schedule)")
     ap.add_argument("--search-stream", action="store_true", help="one GPU experiment: enqueue the search of step i on a second stream (overlaps the encode of step i + 1)")
     ap.add_argument("--sync-search", action="store_true", help="one GPU: use the blocking kr_index_search per step instead of search_async + finish")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -223,7 +224,7 @@ def main():
         encoder = BS.make_hip_encoder(dev, operand_dtype=args.encoder_dtype, residual_lo=None if args.residual_lo is None else bool(args.residual_lo))
         tok_ids, tok_mask = BS.synthetic_tokens(dev, nq, args.query_tokens, seed=2)
         pas_ids, pas_mask = BS.synthetic_tokens(dev, args.passages, args.passage_tokens, seed=1)
-    searcher = ShardedSearcher(index, row_offset=row0, world=world)
+    searcher = ShardedSearcher(index, row_offset=row0, world=world, collective=args.collective)
     q_all = torch.empty((nq, d), dtype=torch.float32, device=dev)
     counts = [((r + 1) * nq) // world - (r * nq) // world for r in range(world)]
 
@@ -257,30 +258,42 @@ def main():
         inflight.append(j)
         step_async.keep = qv                                                          # the queries stay alive until finish()
 
-    # N > 1, default schedule ("batch"): W consecutive steps form a block — rank r ENCODES the whole query batch of step (block * W + r) (the full
-    # 1000-query forward runs at the large-batch MFMA rate; a 1/W slice of 125 queries does not: 715 vs 1030 TFLOP/s), ONE all-gather moves the W
-    # batches' query vectors (W x 4 MB over xGMI), then every rank searches the W batches one after the other on its corpus shard (all-gather of the
-    # per-shard top-k + device merge per batch, as before).  Same total work, same results; what changes is which rank encodes what.
-    # --encode-split queries keeps the round-2 schedule (every rank encodes 1/W of every batch).
-    q_blk = torch.empty((world, nq, d), dtype=torch.float32, device=dev) if world > 1 else None
+    # N > 1, default schedule ("batch"): up to W consecutive steps form a block.  Rank r ENCODES its 1/W slice of every batch of the block in ONE forward
+    # (count x nq / W sequences: with a full block that is a full-size batch, which runs at the large-batch MFMA rate — a 125-query forward does not:
+    # 715 vs 1030 TFLOP/s — and a partial last block, steps % W != 0, still gives every rank an equal share instead of idling W - count ranks), ONE
+    # all-gather moves the block's query vectors (count x 4 MB over xGMI), then every rank searches the block's batches one after the other on its
+    # corpus shard, ENQUEUE ONLY (kr_index_search_async + all-gather of the per-shard top-k + device merge + D2H per batch), and the host synchronises
+    # once per block (ShardedSearcher.finish_deferred: certificates of all batches, exchange repeated only for a batch some rank had to re-answer).
+    # Same total work and results as one step per batch.  --encode-split queries keeps the round-2 schedule (every rank encodes 1/W of every batch, step by step).
+    even = nq % world == 0
+    sl = nq // world
+    q_gath = torch.empty(world * world * sl * d, dtype=torch.float32, device=dev) if world > 1 and even else None     # gathered slices of a block
+    q_blk = torch.empty((world, nq, d), dtype=torch.float32, device=dev) if world > 1 else None                       # [batch-in-block][nq][d]
+    rep_ids = rep_mask = None
+    if world > 1 and encoder is not None and even:
+        rep_ids = tok_ids[q_lo:q_hi].repeat(world, 1).contiguous(); rep_mask = tok_mask[q_lo:q_hi].repeat(world, 1).contiguous()
 
     def block_of_steps(first, count):
-        """steps [first, first + count), count <= W; returns nothing (results land in the searcher's pinned buffers, as in step())"""
+        """steps [first, first + count), count <= W; returns the block's (scores, rows) pinned tensors (valid on return)"""
         if encoder is not None:
-            if rank < count:
-                q_mine = encoder.forward(tok_ids, tok_mask, 0)           # the batch of step first + rank
-            else:
-                q_mine = q_blk[rank]                                      # no batch to encode in a partial last block: contributes its old buffer
-            dist.all_gather_into_tensor(q_blk.view(world * nq, d), q_mine.contiguous())
+            if even:
+                # slice `rank` of the block's `count` batches in one forward (the synthetic batches repeat one token batch, as at N = 1)
+                mine = encoder.forward(rep_ids[:count * sl], rep_mask[:count * sl], 0)      # [count * sl, d]
+                flat = q_gath[:world * count * sl * d].view(world * count * sl, d)          # [rank][batch-in-block][slice row]
+                dist.all_gather_into_tensor(flat, mine.contiguous())
+                q_blk[:count].view(count, world, sl, d).copy_(flat.view(world, count, sl, d).permute(1, 0, 2, 3))   # -> each batch's nq vectors in order
+            else:                                                                           # ragged slices: batch by batch
+                for s_i in range(count):
+                    mine = encoder.forward(tok_ids[q_lo:q_hi], tok_mask[q_lo:q_hi], 0)
+                    dist.all_gather(list(q_blk[s_i].split(counts)), mine)
         can_defer = k <= index.ntotal and world * k <= searcher.DEVICE_MERGE_MAX     # (the host-merge fallbacks synchronise anyway)
+        res = []
         for s_i in range(count):
             qs = q_blk[s_i] if encoder is not None else q_vec
-            if can_defer:
-                searcher.search_deferred(qs, k)                          # enqueue-only: results land in pinned buffers of the searcher's ring
-            else:
-                searcher.search(qs, k)
+            res.append(searcher.search_deferred(qs, k) if can_defer else searcher.search(qs, k))
         if can_defer:
-            torch.cuda.current_stream().synchronize()                     # ONE host synchronisation per block of W steps
+            searcher.finish_deferred()                                    # ONE host synchronisation per block (+ the certificate agreement)
+        return res
 
     def step():
         if encoder is None:
@@ -406,8 +419,11 @@ def main():
                                    f"{world} GPU(s)), {nq}-query batch ({args.query_tokens} tokens) encoded then searched, brute-force top-{k}",
                        "rows_per_gpu": n, "dim": d, "queries": nq, "topk": k, "total_rows": total, "corpus_dist": args.corpus_dist,
                        "encoder_in_step": encoder is not None,
-                       "parallelism": (f"corpus row-sharded x{world}; rank r encodes the whole query batch of steps r, r + {world}, ... (one all-gather of {world} "
-                                       f"batches' query vectors per {world} steps); per batch: all-gather of per-shard top-k, device merge"
+                       "collective": (searcher.collective if world > 1 else None),
+                       "deferred_batches_re_exchanged": searcher.redone,
+                       "parallelism": (f"corpus row-sharded x{world}; blocks of up to {world} steps: every rank encodes its 1/{world} slice of each batch of the block "
+                                       f"in one forward (one all-gather of the block's query vectors), then per batch: enqueue-only local search, all-gather of "
+                                       f"per-shard top-k, device merge; one host synchronisation per block"
                                        if use_blocks else
                                        f"corpus row-sharded x{world}, query batch split x{world} for encoding, all-gather of query vectors and of "
                                        f"per-shard top-k, device merge")},

@@ -32,7 +32,7 @@ extern "C" {
 #define KR_EHIP (-5)      /* a HIP runtime call failed; see kr_last_error() */
 #define KR_ESTATE (-1)    /* handle not ready (e.g. encoder weights missing) */
 
-#define KR_ABI_VERSION 4
+#define KR_ABI_VERSION 5
 int kr_abi_version(void);
 const char* kr_last_error(void);
 int kr_device_count(void);
@@ -91,10 +91,17 @@ int kr_index_search(kr_index* ix, const float* q, int nq, int k, float* scores, 
  * for the device (given device pointers it performs no host synchronisation at all): the results of every query whose exactness certificate holds
  * are written to scores / rows in stream order, and the per-query certificate flags are copied to pinned memory behind them.
  * kr_index_search_finish waits for that point, reads the flags and - only for queries pass 1 could not certify - runs passes 2 / 3 and overwrites
- * their rows; after it returns the results are final and the statistics are updated.  q, scores and rows must stay valid until then.  One search
- * may be in flight per handle: any other call on the handle finishes it first.  kr_index_search(mode 0) == kr_index_search_async + _finish. */
+ * their rows; after it returns the results are final and the statistics are updated.  q, scores and rows must stay valid until then.
+ * Up to 16 calls may be outstanding per handle as long as they use ONE stream (ABI 5; the row-sharded search of bench.py --gpus N enqueues the W
+ * batches of a block back to back and looks at the certificates once): a call on another stream, a 17th call, and any other call that touches the
+ * handle's rows (add, reserve, get_rows ...) finish the outstanding ones first.  kr_index_search_finish finishes ALL outstanding calls, oldest first;
+ * kr_index_search_finish_ex does the same and reports, per call (oldest first, the first `cap` of them), how many of its queries pass 1 could not
+ * certify — i.e. whether rows of that call's result buffers were re-written after whatever the caller enqueued behind the call had consumed them.
+ * kr_index_search(mode 0) == kr_index_search_async + kr_index_search_finish. */
 int kr_index_search_async(kr_index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, void* stream);
 int kr_index_search_finish(kr_index* ix);
+int kr_index_search_finish_ex(kr_index* ix, int64_t* flagged, int cap, int* ncalls);
+int kr_index_search_pending(const kr_index* ix);   /* number of outstanding asynchronous calls */
 
 typedef struct {
     int64_t queries;          /* queries answered since creation / last reset */

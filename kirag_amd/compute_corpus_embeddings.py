@@ -120,7 +120,21 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
         def synchronize(self): pass
     on_gpu = torch.device(device).type == "cuda"
     hidden = None
+    # Token ids are validated on the HOST, before the batch goes anywhere: the HIP forward reports an id outside the vocabulary only after the fact
+    # (deferred error word, enc.check() below), by which time the batch's rows would already sit in the resident shard and in the .pkl buffers.
+    vocab = getattr(getattr(getattr(model, "encoder", None), "config", None), "vocab_size", None)
+    vocab = int(getattr(args, "vocab_size", 0) or 0) or (int(vocab) if vocab else None)
+
+    def validate(cpu_inputs, ids):
+        t = cpu_inputs.get("input_ids") if isinstance(cpu_inputs, dict) else None
+        if vocab is None or not torch.is_tensor(t) or t.is_cuda or t.numel() == 0:
+            return
+        lo, hi = int(t.min()), int(t.max())
+        if lo < 0 or hi >= vocab:
+            raise ValueError(f"input_ids of the batch starting at passage id {ids[0] if ids else '?'} contain a token id outside [0, {vocab}) "
+                             f"(min {lo}, max {hi}): nothing of this batch was encoded, indexed or written")
     for cpu_inputs, ids in source:
+        validate(cpu_inputs, ids)
         if on_gpu:
             inputs = {k: (v.pin_memory().to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in cpu_inputs.items()}
         else:

@@ -148,13 +148,21 @@ struct Index {
     int epiv = 0;   // -DKR_EXPERIMENT builds: k_coarse epilogue variant (KIRAG_AMD_EPIV)
     // asynchronous search (kr_index_search_async ... kr_index_search_finish): pass 1 of every block is enqueued, the per-query certificate flags
     // land in pinned memory behind it; finish() reads them and runs the rare passes 2 / 3
+    // Up to PEND_MAX calls may be outstanding on ONE stream (the row-sharded search enqueues the W batches of a block back to back and looks at their
+    // certificates once): every call owns a slot with its own pinned status records and completion event; the device workspace is shared in stream order.
     struct Pending {
         bool active = false;
         const float* q = nullptr; int nq = 0, k = 0; float* scores = nullptr; int64_t* rows = nullptr; hipStream_t st = nullptr;
         std::vector<int> rounds;        // coarse rounds per block (event pairs to read)
-    } pend;
-    int status_blocks = 0;          // h_status holds this many per-block status records
-    hipEvent_t ev_done = nullptr;   // behind the last enqueued block of an asynchronous search
+        uint32_t* status = nullptr; int status_blocks = 0;   // pinned host: one STATUS_STRIDE record per query block of THIS call
+        hipEvent_t ev_done = nullptr;   // behind the last enqueued block of the call
+        uint64_t seq = 0;               // the call's number (the workspace-resident theta1 / timing events belong to the newest call only)
+    };
+    static constexpr int PEND_MAX = 16;
+    Pending pend[PEND_MAX];
+    int pend_head = 0, pend_n = 0;  // ring of outstanding calls: slots pend_head .. pend_head + pend_n - 1 (mod PEND_MAX), oldest first
+    uint64_t call_seq = 0;
+    int status_blocks = 0;          // h_status: the pass-2 status region exists
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -299,8 +307,9 @@ __device__ __forceinline__ void scatter_wave_lists(const CoarseArgs& a, char* sm
 // SMALLQ (at most 128 queries in the block: the KiRAG loop's 1-2 queries per hop, single-question retrieval): 128-row x 128-query tiles on the
 // producer / consumer loop (gemm_nt_split) instead of 256 x 256 on the ping-pong loop.  With a 256-query tile a small batch pays the MFMA time of 256
 // queries (2.0 ms per 5M rows, above the 1.3-1.6 ms the corpus needs to cross HBM); with 128 the scan is HBM-bound.
-// EPIV (experiments, -DKR_EXPERIMENT builds only; the product instantiates 0): 1 = the survivor path laid out as the unlikely branch, 2 = survivors
-// counted but never stored (diagnostic, wrong results), 3 = no filter at all (diagnostic)
+// EPIV (experiments, -DKR_EXPERIMENT builds only; the product instantiates 0): 1 = the survivor path laid out as the LIKELY branch (the code before
+// round 4: every register without a survivor, 97 % of them, took a taken branch), 2 = survivors counted but never stored (diagnostic, wrong results),
+// 3 = no filter at all (diagnostic: the ceiling of any epilogue re-scheduling — measured 4.8 % below the real kernel, profiles/r04/tried_coarse_epilogue_ceiling.txt)
 template <class T, bool DIRECT, bool SMALLQ = false, int EPIV = 0>
 __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
     using S = std::conditional_t<SMALLQ, ShapeSplit, ShapeC>;      // S::NWAVE = waves that own accumulators (4 of the 8 with SMALLQ)
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
                             const float s = acc.v[mi][ni][r];
                             const bool p = (s >= t);
                             const unsigned long long mask = __ballot(p);
-                            if (EPIV == 1 ? __builtin_expect(mask != 0ull, 0) : (mask != 0ull)) {
+                            if (EPIV == 1 ? (mask != 0ull) : __builtin_expect(mask != 0ull, 0)) {   // a survivor is rare (2.8 % of the registers in the final round): fall through without one
                                 if (EPIV != 2 && p) {
                                     const unsigned int slot = wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                                     u32x4 e = {__float_as_uint(s), row_base + (uint32_t)ro, q, 0u};
@@ -1250,14 +1259,22 @@ static int launch_rerank(Index* ix, int nq, int k, int rmax, int final_preset, c
     return 0;
 }
 
-constexpr int P2_WORDS = 3 * QBLK + 16;      // pass-2 status region at the head of h_status
-static int ensure_status(Index* ix, int nblocks) {
-    if (nblocks <= ix->status_blocks) return 0;
+constexpr int P2_WORDS = 3 * QBLK + 16;      // pass-2 status region (h_status): the slow passes run synchronously, one call at a time
+static int ensure_status(Index* ix, int) {
+    if (ix->status_blocks) return 0;
+    KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->h_status), (size_t)P2_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    ix->status_blocks = 1;
+    return 0;
+}
+// the per-block status records of one outstanding call
+static int ensure_slot_status(Index::Pending& pd, int nblocks) {
+    if (!pd.ev_done) KR_HIP(hipEventCreateWithFlags(&pd.ev_done, hipEventDisableTiming));
+    if (nblocks <= pd.status_blocks) return 0;
     const int nb = std::max(nblocks, 4);
-    if (ix->h_status) (void)hipHostFree(ix->h_status);
-    ix->h_status = nullptr; ix->status_blocks = 0;
-    KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->h_status), ((size_t)P2_WORDS + (size_t)nb * STATUS_STRIDE) * sizeof(uint32_t), hipHostMallocDefault));
-    ix->status_blocks = nb;
+    if (pd.status) (void)hipHostFree(pd.status);
+    pd.status = nullptr; pd.status_blocks = 0;
+    KR_HIP(hipHostMalloc(reinterpret_cast<void**>(&pd.status), (size_t)nb * STATUS_STRIDE * sizeof(uint32_t), hipHostMallocDefault));
+    pd.status_blocks = nb;
     return 0;
 }
 
@@ -1299,7 +1316,7 @@ static void fill_args(const Index* ix, CoarseArgs& a) {
 // the list-overflow word go to the block's status record in pinned memory, the (optimistic) results straight into the caller's buffers; nothing here waits
 // for the device.  kr_index_search_finish reads the status records and re-answers the flagged queries (slow_passes).
 template <class T>
-static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int blk, hipStream_t st, int& rounds) {
+static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int blk, hipStream_t st, int& rounds, uint32_t* status) {
     const BlockPlan p = plan_block(ix, nq, k);
     KR_TRY(ensure_ws(ix, k, p.cap));
     KR_TRY(search_attrs(ix));
@@ -1343,7 +1360,7 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
     }, final_preset, rounds));
     ix->st.coarse_rounds += rounds;
     KR_TRY(launch_rerank(ix, nq, k, p.rmax, final_preset, ix->q_f, nullptr, blk < THETA_BLOCKS ? ix->theta1 + (size_t)blk * QBLK : nullptr, st));
-    uint32_t* rec = ix->h_status + P2_WORDS + (size_t)blk * STATUS_STRIDE;
+    uint32_t* rec = status + (size_t)blk * STATUS_STRIDE;
     KR_HIP(hipMemcpyAsync(rec, ix->flags, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     KR_HIP(hipMemcpyAsync(rec + QBLK, ix->nrer, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     KR_HIP(hipMemcpyAsync(rec + 2 * QBLK, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
@@ -1474,52 +1491,63 @@ static int slow_passes(Index* ix, const float* q, int nq, int k, float* scores, 
     return 0;
 }
 
-// enqueue pass 1 of every block of a search; ix->pend describes the call until finish_search() has run
+// enqueue pass 1 of every block of a search into the next free slot of the pending ring; the slot describes the call until it has been finished
+static int finish_one(Index* ix, int64_t* flagged_out);
 static int begin_search(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, hipStream_t st) {
     const int nblocks = (nq + QBLK - 1) / QBLK;
     KR_TRY(ensure_status(ix, nblocks));
-    if (!ix->ev_done) KR_HIP(hipEventCreateWithFlags(&ix->ev_done, hipEventDisableTiming));
+    // the device workspace is shared by all calls in STREAM order: outstanding calls of another stream are finished first, and so is the oldest one
+    // when the ring is full
+    while (ix->pend_n > 0 && (ix->pend[ix->pend_head].st != st || ix->pend_n == Index::PEND_MAX)) KR_TRY(finish_one(ix, nullptr));
     if (ix->ev_add) KR_HIP(hipStreamWaitEvent(st, ix->ev_add, 0));   // rows added asynchronously on another stream
     ix->force_exact = g_force_exact.load();
     ix->st.last_coarse_ms = 0.0; ix->st.last_total_ms = 0.0; ix->st.last_fine_ms = 0.0;
-    Index::Pending& pd = ix->pend;
+    Index::Pending& pd = ix->pend[(ix->pend_head + ix->pend_n) % Index::PEND_MAX];
+    KR_TRY(ensure_slot_status(pd, nblocks));
     pd.q = q; pd.nq = nq; pd.k = k; pd.scores = scores; pd.rows = rows; pd.st = st; pd.rounds.assign(nblocks, 0);
+    pd.seq = ++ix->call_seq;
     {   // ensure_ws creates the events on first use: make sure they exist before the first record
         int K1, cap, rmax; plan_buffers(k, K1, cap, rmax);
         KR_TRY(ensure_ws(ix, k, cap));
     }
     KR_HIP(hipEventRecord(ix->ev[0], st));
-    pd.active = true;      // from here on finish_search() has something to wait for, also when a later block fails to enqueue
+    pd.active = true;      // from here on finish_one() has something to wait for, also when a later block fails to enqueue
+    ++ix->pend_n;
     for (int b = 0; b < nblocks; ++b) {
         const int nb = std::min(QBLK, nq - b * QBLK);
         const float* qb = q + (size_t)b * QBLK * ix->d;
         float* sb = scores + (size_t)b * QBLK * k; int64_t* rb = rows + (size_t)b * QBLK * k;
         int rc;
-        if (ix->coarse == KR_COARSE_BF16) rc = pass1_enqueue<BF16>(ix, qb, nb, k, sb, rb, b, st, pd.rounds[b]);
-        else rc = pass1_enqueue<F16>(ix, qb, nb, k, sb, rb, b, st, pd.rounds[b]);
-        if (rc) { (void)hipStreamSynchronize(st); pd.active = false; return rc; }
+        if (ix->coarse == KR_COARSE_BF16) rc = pass1_enqueue<BF16>(ix, qb, nb, k, sb, rb, b, st, pd.rounds[b], pd.status);
+        else rc = pass1_enqueue<F16>(ix, qb, nb, k, sb, rb, b, st, pd.rounds[b], pd.status);
+        if (rc) { (void)hipStreamSynchronize(st); pd.active = false; --ix->pend_n; return rc; }
     }
     KR_HIP(hipEventRecord(ix->ev[3], st));
-    KR_HIP(hipEventRecord(ix->ev_done, st));
+    KR_HIP(hipEventRecord(pd.ev_done, st));
     return 0;
 }
 
-// wait for the enqueued pass 1, read the status records, run passes 2 / 3 for flagged queries (patching the caller's buffers), update the statistics
-static int finish_search(Index* ix) {
-    Index::Pending& pd = ix->pend;
+// the OLDEST outstanding call: wait for its pass 1, read its status records, run passes 2 / 3 for flagged queries (patching the caller's buffers),
+// update the statistics.  *flagged_out = queries of the call that pass 1 could not certify (their rows in the caller's buffers were re-written).
+static int finish_one(Index* ix, int64_t* flagged_out) {
+    if (flagged_out) *flagged_out = 0;
+    if (ix->pend_n == 0) return 0;
+    Index::Pending& pd = ix->pend[ix->pend_head];
+    ix->pend_head = (ix->pend_head + 1) % Index::PEND_MAX; --ix->pend_n;
     if (!pd.active) return 0;
     pd.active = false;
-    KR_HIP(hipEventSynchronize(ix->ev_done));
+    KR_HIP(hipEventSynchronize(pd.ev_done));
+    const bool newest = pd.seq == ix->call_seq;          // theta1 (pass 2's pre-scan bound) and the timing events hold the newest call's values
     const int nblocks = (pd.nq + QBLK - 1) / QBLK;
     int64_t flagged_total = 0;
     for (int b = 0; b < nblocks; ++b) {
         const int nb = std::min(QBLK, pd.nq - b * QBLK);
-        const uint32_t* rec = ix->h_status + P2_WORDS + (size_t)b * STATUS_STRIDE;
+        const uint32_t* rec = pd.status + (size_t)b * STATUS_STRIDE;
         const bool list_ovf = rec[2 * QBLK] != 0u;   // a block list overflowed: every query of the block goes on to the next pass
         std::vector<uint32_t> hflags(nb);
         int64_t nfl = 0;
         for (int i = 0; i < nb; ++i) { hflags[i] = rec[i] | (list_ovf ? 1u : 0u); ix->st.reranked_rows += rec[QBLK + i]; nfl += hflags[i] != 0u; }
-        if (b < TIMED_BLOCKS)
+        if (b < TIMED_BLOCKS && newest)
             for (int r = 0; r < pd.rounds[b] && r < 16; ++r) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, ix->evc[b * 32 + 2 * r], ix->evc[b * 32 + 2 * r + 1]) == hipSuccess) ix->st.last_coarse_ms += ms;
@@ -1527,17 +1555,25 @@ static int finish_search(Index* ix) {
         if (nfl) {
             const float* qb = pd.q + (size_t)b * QBLK * ix->d;
             float* sb = pd.scores + (size_t)b * QBLK * pd.k; int64_t* rb = pd.rows + (size_t)b * QBLK * pd.k;
+            const int tb = newest ? b : THETA_BLOCKS;     // an older call's theta1 has been overwritten: pass 2 without the pre-scan
             int rc;
-            if (ix->coarse == KR_COARSE_BF16) rc = slow_passes<BF16>(ix, qb, nb, pd.k, sb, rb, b, pd.st, hflags, true, true, nblocks > 1);
-            else rc = slow_passes<F16>(ix, qb, nb, pd.k, sb, rb, b, pd.st, hflags, true, true, nblocks > 1);
+            if (ix->coarse == KR_COARSE_BF16) rc = slow_passes<BF16>(ix, qb, nb, pd.k, sb, rb, tb, pd.st, hflags, true, true, nblocks > 1);
+            else rc = slow_passes<F16>(ix, qb, nb, pd.k, sb, rb, tb, pd.st, hflags, true, true, nblocks > 1);
             if (rc) return rc;
         }
         flagged_total += nfl;
     }
     float tot = 0.f;
-    if (hipEventElapsedTime(&tot, ix->ev[0], ix->ev[3]) == hipSuccess) ix->st.last_total_ms += tot;
+    if (newest && hipEventElapsedTime(&tot, ix->ev[0], ix->ev[3]) == hipSuccess) ix->st.last_total_ms += tot;
     ix->st.queries += pd.nq;
     ix->st.certified += pd.nq - flagged_total;
+    if (flagged_out) *flagged_out = flagged_total;
+    return 0;
+}
+
+// every outstanding call, oldest first
+static int finish_search(Index* ix) {
+    while (ix->pend_n > 0) KR_TRY(finish_one(ix, nullptr));
     return 0;
 }
 
@@ -1624,8 +1660,11 @@ void kr_index_destroy(kr_index* h) {
     if (!h) return;
     Index* ix = reinterpret_cast<Index*>(h);
     (void)hipSetDevice(ix->device);
-    if (ix->pend.active) { (void)hipEventSynchronize(ix->ev_done); ix->pend.active = false; }   // an unfinished asynchronous search: let its kernels drain
-    if (ix->ev_done) (void)hipEventDestroy(ix->ev_done);
+    for (auto& pd : ix->pend) {
+        if (pd.active) { (void)hipEventSynchronize(pd.ev_done); pd.active = false; }   // an unfinished asynchronous search: let its kernels drain
+        if (pd.ev_done) (void)hipEventDestroy(pd.ev_done);
+        if (pd.status) (void)hipHostFree(pd.status);
+    }
     if (ix->vmm == 1) { (void)hipDeviceSynchronize(); ix->vf.release(); ix->vc.release(); ix->xf = nullptr; ix->xc = nullptr; }
     void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_f2, ix->theta1, ix->thr_mark, ix->bitmap, ix->rowlist, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
                     ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt};
@@ -1800,8 +1839,7 @@ int kr_index_search_async(kr_index* h, const float* q, int nq, int k, float* sco
     KR_TRY(check_search_args(ix, q, nq, k, scores, rows));
     if (nq == 0) return 0;
     KR_TRY(select_device(ix->device));
-    KR_TRY(finish_search(ix));                       // at most one search in flight per handle
-    return begin_search(ix, q, nq, k, scores, rows, reinterpret_cast<hipStream_t>(stream));
+    return begin_search(ix, q, nq, k, scores, rows, reinterpret_cast<hipStream_t>(stream));   // up to PEND_MAX calls outstanding per handle (one stream)
 }
 
 int kr_index_search_finish(kr_index* h) {
@@ -1810,6 +1848,22 @@ int kr_index_search_finish(kr_index* h) {
     KR_TRY(select_device(ix->device));
     return finish_search(ix);
 }
+
+int kr_index_search_finish_ex(kr_index* h, int64_t* flagged, int cap, int* ncalls) {
+    if (!h || !ncalls || (cap > 0 && !flagged) || cap < 0) return fail(KR_EINVAL, "bad arguments");
+    Index* ix = reinterpret_cast<Index*>(h);
+    KR_TRY(select_device(ix->device));
+    *ncalls = 0;
+    while (ix->pend_n > 0) {
+        int64_t fl = 0;
+        KR_TRY(finish_one(ix, &fl));
+        if (*ncalls < cap) flagged[*ncalls] = fl;
+        ++*ncalls;
+    }
+    return 0;
+}
+
+int kr_index_search_pending(const kr_index* h) { return h ? reinterpret_cast<const Index*>(h)->pend_n : 0; }
 
 // exact top-k of q x^T for a small, transient candidate set (the KiRAG loop's aligner step): canonical scores of every (query, row)
 // pair by k_exact_scan + the sort tree, on a per-device scratch Index (no 16-bit copy, no certificate needed: this IS the exact scan)

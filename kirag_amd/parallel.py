@@ -33,6 +33,7 @@ class ShardedSearcher:
     on GPU ranks, ``search_into(q, k, scores_t, rows_t)``."""
 
     DEVICE_MERGE_MAX = 8192      # kr_topk_merge_device holds nshards * k entries per query in LDS
+    RING = 8                     # deferred searches that may be outstanding between two finish_deferred() calls (at least the world size)
 
     def __init__(self, index, row_offset: int = 0, world: Optional[int] = None, group=None, collective: str = "torch"):
         """``collective``: "torch" — ``torch.distributed.all_gather_into_tensor`` of the process group + ``kr_topk_merge_device``; "kr_comm" — the
@@ -47,21 +48,35 @@ class ShardedSearcher:
             raise ValueError("collective must be 'torch' or 'kr_comm'")
         self.collective = collective
         self._comm = None
+        self._outstanding = []
+        self.redone = 0              # deferred batches whose exchange was repeated because some rank re-answered queries (finish_deferred)
 
     def _kr_comm(self, dev):
-        """the library's communicator, created on first use (a collective call: every rank reaches it in its first search)"""
-        if self._comm is None:
+        """the library's communicator, created on first use (a COLLECTIVE call: every rank reaches it in its first search).  A failure on any rank —
+        RCCL not loadable, no id — is agreed on by all ranks BEFORE anyone enters the blocking ncclCommInitRank, and every rank then falls back to
+        the torch.distributed exchange (with a warning) instead of some ranks raising while the others wait in a collective for ever."""
+        if self._comm is None and self.collective == "kr_comm":
             import ctypes as C
+            import warnings
+            import torch
             import torch.distributed as dist
             lib = _lib.load()
             rank = dist.get_rank(self.group) if self.world > 1 else 0
-            ident = [None]
-            if rank == 0:
-                buf = C.create_string_buffer(128)
-                _lib.check(lib.kr_comm_unique_id(buf))
-                ident[0] = buf.raw
+            buf = C.create_string_buffer(128)
+            rc = lib.kr_comm_unique_id(buf)                  # on every rank: also the probe that RCCL can be loaded here
+            err = None if rc == 0 else (lib.kr_last_error() or b"").decode("utf-8", "replace")
+            ident = [buf.raw if rc == 0 else None, err]
             if self.world > 1:
+                ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+                all_ok = bool(int(ok.item()))
                 dist.broadcast_object_list(ident, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            else:
+                all_ok = rc == 0
+            if not all_ok or ident[0] is None:
+                warnings.warn(f"kr_comm unavailable on at least one rank ({err or ident[1] or 'see the other ranks'}): using the torch.distributed exchange")
+                self.collective = "torch"
+                return None
             h = C.c_void_p()
             _lib.check(lib.kr_comm_create(ident[0], rank, self.world, int(dev.index), C.byref(h)))
             self._comm = h
@@ -82,14 +97,67 @@ class ShardedSearcher:
             pass
 
     def search_deferred(self, q, k: int):
-        """GPU ranks with device queries: the same search, but the call returns as soon as everything is ENQUEUED (local search + certificate check,
-        all-gather, device merge, D2H into a pinned buffer of a small ring) — no stream synchronisation.  Returns (scores, rows) as pinned CPU tensors
-        that are valid after the caller has synchronised the stream (e.g. once per block of several searches: ``bench.py --gpus N``);
-        at most ``max(4, world)`` searches may be outstanding (the ring of pinned result buffers)."""
+        """GPU ranks with device queries: the same search, ENQUEUE ONLY — pass 1 of the local search (``kr_index_search_async``), the global-row
+        offset, the all-gather, the device merge and the D2H of the result into a pinned buffer of a small ring all go onto the current stream and
+        the call returns; nothing here waits for the device.  ``finish_deferred()`` — once per block of searches, e.g. per W steps in
+        ``bench.py --gpus N`` — synchronises ONCE, looks at the exactness certificates of every outstanding search on every rank, and repeats the
+        exchange only for a batch in which some rank had to re-answer queries (passes 2 / 3 patch the local list in place).  Returns the (scores, rows)
+        pinned CPU tensors that are valid after ``finish_deferred()``.  ``q`` must stay alive and untouched until then; at most ``RING`` (8, or the
+        world size) searches may be outstanding.  Raises ``ValueError`` where the enqueue-only path does not apply (a shard with fewer than k rows,
+        lists beyond the device merge) — use ``search``."""
         import torch
-        k = int(k); kl = min(k, int(self.index.ntotal)); nq = int(q.shape[0])
-        assert torch.is_tensor(q) and q.is_cuda and self.world > 1
-        return self._search_device(q, k, kl, nq, q.device, defer=True)
+        k = int(k); nq = int(q.shape[0])
+        if not (torch.is_tensor(q) and q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()):
+            raise ValueError("search_deferred needs a contiguous float32 CUDA tensor of queries")
+        import torch.distributed as dist
+        if not dist.is_initialized() or k > int(self.index.ntotal) or self.world * k > self.DEVICE_MERGE_MAX or not hasattr(self.index, "search_async"):
+            raise ValueError("search_deferred: needs a process group, k <= rows of every shard and world * k <= %d" % self.DEVICE_MERGE_MAX)
+        dev = q.device
+        self._buffers(nq, k, dev)
+        j = len(self._outstanding)
+        if j >= len(self._slots):
+            raise RuntimeError("too many deferred searches outstanding: call finish_deferred()")
+        mine, loc = self._slots[j]
+        ids = mine[:nq * k * 8].view(torch.int64).view(nq, k)
+        sc = mine[nq * k * 8:nq * k * 12].view(torch.float32).view(nq, k)
+        self.index.search_async(q, k, sc, loc)               # local rows; finish() may re-write rows of loc / sc for uncertified queries
+        torch.add(loc, self.row_offset, out=ids)
+        self._exchange(mine, sc, ids, nq, k, dev)
+        ps, pi = self._ring[j]
+        ps.copy_(self._out_s, non_blocking=True); pi.copy_(self._out_i, non_blocking=True)
+        self._outstanding.append((q, k, nq, dev, j))
+        return ps, pi
+
+    def finish_deferred(self):
+        """One host synchronisation for every search enqueued by ``search_deferred`` since the last call (a collective: every rank calls it with the
+        same number of outstanding searches).  Returns their (scores, rows) pinned tensors, oldest first, final."""
+        import torch
+        import torch.distributed as dist
+        out = [self._ring[j] for (_, _, _, _, j) in self._outstanding]
+        if not self._outstanding:
+            return out
+        dev = self._outstanding[0][3]
+        torch.cuda.current_stream(dev).synchronize()              # the one wait: everything enqueued (searches, exchanges, D2H) is done
+        flagged = self.index.finish()                             # certificates; re-answers uncertified queries in place (rare)
+        assert len(flagged) == len(self._outstanding), (flagged, len(self._outstanding))
+        redo = torch.tensor([1 if f else 0 for f in flagged], dtype=torch.int32, device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(redo, op=dist.ReduceOp.MAX, group=self.group)   # a batch is exchanged again if ANY rank patched its list
+        redo = redo.cpu().tolist()
+        self.redone += sum(1 for r in redo if r)
+        for (q, k, nq, dev, j), r in zip(self._outstanding, redo):
+            if not r:
+                continue
+            mine, loc = self._slots[j]
+            ids = mine[:nq * k * 8].view(torch.int64).view(nq, k)
+            sc = mine[nq * k * 8:nq * k * 12].view(torch.float32).view(nq, k)
+            torch.add(loc, self.row_offset, out=ids)
+            self._exchange(mine, sc, ids, nq, k, dev)
+            ps, pi = self._ring[j]
+            ps.copy_(self._out_s, non_blocking=True); pi.copy_(self._out_i, non_blocking=True)
+        if any(redo):
+            torch.cuda.current_stream(dev).synchronize()
+        self._outstanding = []
+        return out
 
     def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:
         """-> (scores float32 [nq,k], GLOBAL rows int64 [nq,k]) on every rank, ONE contract for every world size: always k columns; a corpus
@@ -128,26 +196,56 @@ class ShardedSearcher:
         dist.all_gather_into_tensor(all_i, ids, group=self.group)
         return merge_topk(all_s.view(self.world, nq, k).numpy(), all_i.view(self.world, nq, k).numpy(), k)
 
-    def _search_device(self, q, k: int, kl: int, nq: int, dev, defer: bool = False):
-        """GPU ranks: the local lists are written straight into this rank's block of ONE byte buffer ([ids int64 | scores fp32], so a single
-        all-gather moves both), the W lists are merged on the device (``kr_topk_merge_device``) and only the final [nq, k] result crosses
-        PCIe (1.2 MB instead of 9.6 MB at 8 x 1000 x 100).  Buffers persist across calls; the returned arrays are fresh copies."""
+    def _buffers(self, nq: int, k: int, dev):
+        """persistent device / pinned buffers for (nq, k): this rank's block of the gather buffer, the gathered blocks, the merged result, and one
+        (block, local rows) pair + one pinned result pair per deferred search that may be outstanding"""
         import torch
-        import torch.distributed as dist
         W = self.world
         block = (nq * k * 12 + 15) // 16 * 16                    # bytes per rank: multiple of 16 so both strides are whole elements
         key = (nq, k, W, dev)
         if getattr(self, "_dev_key", None) != key:
+            if getattr(self, "_outstanding", None):
+                raise RuntimeError("finish_deferred() before searching with another shape")
             self._mine = torch.empty(block, dtype=torch.uint8, device=dev)
             self._all = torch.empty(W * block, dtype=torch.uint8, device=dev)
             self._out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
             self._out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
             self._pin_s = torch.empty((nq, k), dtype=torch.float32, pin_memory=True)
             self._pin_i = torch.empty((nq, k), dtype=torch.int64, pin_memory=True)
+            ring = max(self.RING, W)
+            self._slots = [(torch.empty(block, dtype=torch.uint8, device=dev), torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(ring)]
             self._ring = [(torch.empty((nq, k), dtype=torch.float32, pin_memory=True), torch.empty((nq, k), dtype=torch.int64, pin_memory=True))
-                          for _ in range(max(4, W))]                # deferred results: at most max(4, W) searches between two synchronisations
-            self._ring_pos = 0
+                          for _ in range(ring)]
+            self._outstanding = []
             self._dev_key = key
+        return block
+
+    def _exchange(self, mine, sc, ids, nq: int, k: int, dev):
+        """all-gather of this rank's (ids | scores) block + device merge of the W lists into _out_s / _out_i: enqueue only"""
+        import torch
+        import torch.distributed as dist
+        W = self.world
+        block = mine.numel()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if self.collective == "kr_comm" and self._kr_comm(dev) is not None:
+            _lib.check(_lib.load().kr_shard_allgather_topk(self._comm, sc.data_ptr(), ids.data_ptr(), nq, k,
+                                                           self._out_s.data_ptr(), self._out_i.data_ptr(), stream))
+            return
+        dist.all_gather_into_tensor(self._all, mine, group=self.group)
+        base = self._all.data_ptr()
+        _lib.check(_lib.load().kr_topk_merge_device(base + nq * k * 8, block // 4, base, block // 8, W, nq, k,
+                                                    self._out_s.data_ptr(), self._out_i.data_ptr(), dev.index, stream))
+
+    def _search_device(self, q, k: int, kl: int, nq: int, dev):
+        """GPU ranks: the local lists are written straight into this rank's block of ONE byte buffer ([ids int64 | scores fp32], so a single
+        all-gather moves both), the W lists are merged on the device (``kr_topk_merge_device``) and only the final [nq, k] result crosses
+        PCIe (1.2 MB instead of 9.6 MB at 8 x 1000 x 100).  Buffers persist across calls; the returned arrays are fresh copies."""
+        import torch
+        import torch.distributed as dist
+        W = self.world
+        if getattr(self, "_outstanding", None):
+            raise RuntimeError("finish_deferred() before a blocking search")
+        block = self._buffers(nq, k, dev)
         ids = self._mine[:nq * k * 8].view(torch.int64).view(nq, k)
         sc = self._mine[nq * k * 8:nq * k * 12].view(torch.float32).view(nq, k)
         if kl == k and hasattr(self.index, "search_into"):
@@ -159,31 +257,14 @@ class ShardedSearcher:
                 sc[:, :kl] = torch.from_numpy(np.ascontiguousarray(s)).to(dev); ids[:, :kl] = torch.from_numpy(np.ascontiguousarray(i)).to(dev)
         if self.row_offset and kl > 0:
             (ids if kl == k else ids[:, :kl]).add_(self.row_offset)
-        if self.collective == "kr_comm" and W * k <= self.DEVICE_MERGE_MAX:
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(_lib.load().kr_shard_allgather_topk(self._kr_comm(dev), sc.data_ptr(), ids.data_ptr(), nq, k,
-                                                           self._out_s.data_ptr(), self._out_i.data_ptr(), stream))
-            return self._deliver(dev, defer)
-        dist.all_gather_into_tensor(self._all, self._mine, group=self.group)
         if W * k > self.DEVICE_MERGE_MAX:
             # beyond the device merge's LDS capacity (kr_topk_merge_device: nshards * k <= 8192, e.g. 16 shards x k = 1024): merge on the host
+            dist.all_gather_into_tensor(self._all, self._mine, group=self.group)
             host = self._all.cpu().numpy().reshape(W, block)
             ids_h = np.ascontiguousarray(host[:, :nq * k * 8]).view(np.int64).reshape(W, nq, k)
             sc_h = np.ascontiguousarray(host[:, nq * k * 8:nq * k * 12]).view(np.float32).reshape(W, nq, k)
             return merge_topk(sc_h, ids_h, k)
-        base = self._all.data_ptr()
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(_lib.load().kr_topk_merge_device(base + nq * k * 8, block // 4, base, block // 8, W, nq, k,
-                                                    self._out_s.data_ptr(), self._out_i.data_ptr(), dev.index, stream))
-        return self._deliver(dev, defer)
-
-    def _deliver(self, dev, defer: bool):
-        import torch
-        if defer:
-            ps, pi = self._ring[self._ring_pos % len(self._ring)]
-            self._ring_pos += 1
-            ps.copy_(self._out_s, non_blocking=True); pi.copy_(self._out_i, non_blocking=True)
-            return ps, pi
+        self._exchange(self._mine, sc, ids, nq, k, dev)
         self._pin_s.copy_(self._out_s, non_blocking=True); self._pin_i.copy_(self._out_i, non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()
         return self._pin_s.numpy().copy(), self._pin_i.numpy().copy()

@@ -138,15 +138,23 @@ class FlatIPIndex:
             raise ValueError(f"top_docs={k} must satisfy 0 < k <= ntotal={self.ntotal}")
         assert tuple(scores_out.shape) == (nq, k) and tuple(rows_out.shape) == (nq, k)
         assert scores_out.is_contiguous() and rows_out.is_contiguous() and scores_out.dtype == torch.float32 and rows_out.dtype == torch.int64
-        self._pending = (q, scores_out, rows_out)                                  # keep-alive until finish()
+        if not isinstance(getattr(self, "_pending", None), list):
+            self._pending = []
+        self._pending.append((q, scores_out, rows_out))                            # keep-alive until finish()
         _lib.check(self._lib.kr_index_search_async(self._h, int(q.data_ptr()), nq, k, int(scores_out.data_ptr()), int(rows_out.data_ptr()),
                                                    self._stream(q, scores_out, rows_out)))
 
-    def finish(self) -> None:
+    def finish(self):
+        """Finish EVERY outstanding ``search_async`` call (up to 16 may be enqueued back to back on one stream).  Returns, per call and oldest first,
+        the number of its queries that pass 1 could not certify: for those the rows of the call's output tensors were re-written by passes 2 / 3 after
+        anything the caller had enqueued behind the call read them (``kr_index_search_finish_ex``)."""
+        flagged = (C.c_int64 * 16)()
+        ncalls = C.c_int(0)
         try:
-            _lib.check(self._lib.kr_index_search_finish(self._h))
+            _lib.check(self._lib.kr_index_search_finish_ex(self._h, flagged, 16, C.byref(ncalls)))
         finally:
-            self._pending = None
+            self._pending = []
+        return [int(flagged[i]) for i in range(min(ncalls.value, 16))]
 
     def reconstruct_n(self, start: int, n: int) -> np.ndarray:
         out = np.empty((n, self.d), np.float32)
@@ -297,21 +305,20 @@ class ShardedIndexer(Indexer):
         self._local_ids.append(np.array(ids, dtype=np.int64))
         self._dirty = True
 
-    def sync_shards(self):
-        """Collective: assemble ``index_id_to_db_id`` (all ranks' ids in rank order), ``row_offset`` and ``ntotal_global`` after ``index_data`` calls."""
+    def _dirty_flag(self, async_op: bool):
+        """the collective part of the "did any rank append rows?" decision: (flag tensor, work handle or None).  A rank whose share of a streamed build
+        was empty (or that appended nothing after a reload) has _dirty == False while the others do: the decision has to be taken together."""
+        import torch
         import torch.distributed as dist
-        dirty = bool(self._dirty)
-        if self.world > 1:
-            # the decision itself is collective: a rank whose share of a streamed build was empty (or that appended nothing after a reload) has
-            # _dirty == False while the others are already waiting in the gather below
-            backend = dist.get_backend(self.group)
-            import torch
-            flag = torch.tensor([1 if dirty else 0], dtype=torch.int32,
-                                device=torch.device("cuda", self.index.device) if backend == "nccl" else torch.device("cpu"))
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-            dirty = bool(int(flag.item()))
-        if not dirty:
-            return
+        backend = dist.get_backend(self.group)
+        flag = torch.tensor([1 if self._dirty else 0], dtype=torch.int32,
+                            device=torch.device("cuda", self.index.device) if backend == "nccl" else torch.device("cpu"))
+        work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group, async_op=async_op)
+        return flag, work
+
+    def _assemble(self):
+        """Collective: ``index_id_to_db_id`` (all ranks' ids in rank order), ``row_offset`` and ``ntotal_global`` from every rank's local ids."""
+        import torch.distributed as dist
         local = np.concatenate(self._local_ids, axis=0) if self._local_ids else np.empty((0), dtype=np.int64)
         parts = [None] * self.world
         if self.world > 1:
@@ -323,6 +330,15 @@ class ShardedIndexer(Indexer):
         self.ntotal_global = len(self.index_id_to_db_id)
         self._local_ids = [local]
         self._dirty = False
+
+    def sync_shards(self):
+        """Collective: assemble ``index_id_to_db_id``, ``row_offset`` and ``ntotal_global`` after ``index_data`` calls (no-op when no rank appended rows)."""
+        dirty = bool(self._dirty)
+        if self.world > 1:
+            flag, _ = self._dirty_flag(async_op=False)
+            dirty = bool(int(flag.item()))
+        if dirty:
+            self._assemble()
 
     def set_local_shard(self, local_ids, embeddings):
         """Resident-shard build path (``compute_corpus_embeddings.cal_doc_embeddings(..., indexer=...)`` on every rank): this rank contributes
@@ -393,171 +409,47 @@ class ShardedIndexer(Indexer):
         if self.world > 1:
             dist.barrier(group=self.group)
 
-    def search_knn(self, query_vectors, top_docs: int, index_batch_size=1024, verbose: bool = True):
+    def _get_searcher(self):
         from ..parallel import ShardedSearcher
-        self.sync_shards()
+        sr = getattr(self, "_searcher", None)
+        if sr is None or sr.row_offset != self.row_offset or sr.index is not self.index:
+            sr = self._searcher = ShardedSearcher(self.index, row_offset=self.row_offset, world=self.world, group=self.group)
+        return sr
+
+    def search_knn(self, query_vectors, top_docs: int, index_batch_size=1024, verbose: bool = True):
+        """Collective (every rank passes the same queries).  Whether some rank appended rows since the last ``sync_shards()`` is decided together, but
+        NOT with a host round trip of its own per call: the flag's all-reduce is started before the first batch's search and looked at behind that
+        search's own synchronisation; only if it says "dirty" (the first search after a streamed build) is the id map assembled and that batch
+        searched again with the right row offsets.  (Every branch below depends on state that is identical on all ranks, so the ranks issue the same
+        collectives in the same order.)"""
         if isinstance(query_vectors, np.ndarray):
             query_vectors = query_vectors.astype('float32')
-        if top_docs > self.ntotal_global:
-            raise ValueError(f"top_docs={top_docs} must satisfy 0 < k <= ntotal={self.ntotal_global}")
-        searcher = ShardedSearcher(self.index, row_offset=self.row_offset, world=self.world, group=self.group)
+        top_docs = int(top_docs)
+        flag = work = None
+        if self.world > 1:
+            flag, work = self._dirty_flag(async_op=True)
+        elif self._dirty:
+            self._assemble()
         result = []
         for start_idx in range(0, len(query_vectors), index_batch_size):
             q = query_vectors[start_idx: start_idx + index_batch_size]
-            scores, rows = searcher.search(q, top_docs)
+            res = None
+            if flag is not None:
+                if 0 < top_docs <= self.ntotal_global:         # optimistic: the common case is "nobody appended anything"
+                    res = self._get_searcher().search(q, top_docs)
+                work.wait()
+                if bool(int(flag.item())):                     # behind the search's synchronisation: no round trip of its own
+                    self._assemble()
+                    res = None                                 # searched with stale row offsets / id map: again
+                flag = None
+            if not 0 < top_docs <= self.ntotal_global:
+                raise ValueError(f"top_docs={top_docs} must satisfy 0 < k <= ntotal={self.ntotal_global}")
+            scores, rows = res if res is not None else self._get_searcher().search(q, top_docs)
             ext = self.index_id_to_db_id[rows]
             db_ids = [[str(v) for v in row] for row in ext.tolist()]
             result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
+        if flag is not None:                                   # no query batch at all: still take the collective decision
+            work.wait()
+            if bool(int(flag.item())):
+                self._assemble()
         return result
-
-
-# ---------------------------------------------------------------------------------------------------------
-# faiss flat-index file layout.  faiss is a third-party dependency of the reference (requirements.txt:10) and
-# its source is not on disk here: the layout below restates faiss 1.8 `write_index` for IndexFlat from its
-# published io code (impl/index_write.cpp: fourcc, write_index_header, WRITEXBVECTOR) and is UNVERIFIED
-# against a real faiss build in this environment: tests/test_capi_and_host.py pins the writer to a hand-assembled
-# byte string of that field list (header 4+4+8+8+8+1+4 = 37 bytes, then the WRITEXBVECTOR count = payload bytes / 4),
-# which guards the layout against regressions but is NOT a round trip through faiss.
-#   u32  fourcc "IxFI"
-#   i32  d ; i64 ntotal ; i64 dummy (1<<20) ; i64 dummy (1<<20) ; u8 is_trained ; i32 metric_type (0 = IP)
-#   u64  number of float32 values (= ntotal * d) ; float32[ntotal * d] row-major
-# ---------------------------------------------------------------------------------------------------------
-_FOURCC_IXFI = struct.unpack("<I", b"IxFI")[0]
-
-
-def write_faiss_flat_ip(index: FlatIPIndex, path: str) -> None:
-    n, d = index.ntotal, index.d
-    with open(path, "wb") as f:
-        f.write(struct.pack("<I", _FOURCC_IXFI))
-        f.write(struct.pack("<iqqqBi", d, n, 1 << 20, 1 << 20, 1, 0))
-        f.write(struct.pack("<Q", n * d))
-        for s in range(0, n, _IO_CHUNK_ROWS):
-            m = min(_IO_CHUNK_ROWS, n - s)
-            f.write(index.reconstruct_n(s, m).tobytes())
-
-
-def read_faiss_flat_ip(path: str, device: Optional[int] = None, coarse_dtype: str = "bf16", row_range=None) -> FlatIPIndex:
-    """``row_range = (rank, world)`` loads only that rank's contiguous share of the rows (``ShardedIndexer``); the returned index carries
-    ``file_ntotal`` (rows in the file) and ``row_offset`` (first row held)."""
-    with open(path, "rb") as f:
-        (fourcc,) = struct.unpack("<I", f.read(4))
-        if fourcc != _FOURCC_IXFI:
-            raise ValueError(f"{path}: not a faiss IndexFlatIP file (fourcc {struct.pack('<I', fourcc)!r})")
-        d, n, _, _, _trained, metric = struct.unpack("<iqqqBi", f.read(4 + 8 * 3 + 1 + 4))
-        if metric != 0:
-            raise ValueError(f"{path}: metric_type {metric} is not METRIC_INNER_PRODUCT")
-        (nfloat,) = struct.unpack("<Q", f.read(8))
-        if nfloat != n * d:
-            raise ValueError(f"{path}: payload {nfloat} floats != ntotal*d = {n * d}")
-        a, b = 0, n
-        if row_range is not None:
-            rank, world = row_range
-            per = (n + world - 1) // world
-            a, b = min(rank * per, n), min((rank + 1) * per, n)
-            f.seek(a * d * 4, os.SEEK_CUR)
-        index = FlatIPIndex(d, device=device, coarse_dtype=coarse_dtype)
-        index.reserve(b - a)
-        for s in range(a, b, _IO_CHUNK_ROWS):
-            m = min(_IO_CHUNK_ROWS, b - s)
-            buf = np.frombuffer(f.read(m * d * 4), dtype=np.float32).reshape(m, d)
-            index.add(buf)
-        index.file_ntotal, index.row_offset = n, a
-    return index
-
-
-# ---------------------------------------------------------------------------------------------------------
-# Native shard files (SURVEY.md 8f-1): what one rank's FlatIPIndex holds, byte for byte, so that a reload does not re-quantise.
-#   bytes 0..7    magic  b"KRSHARD1"
-#   i32 d ; i32 coarse_dim ; i32 coarse_dtype (0 bf16, 1 f16) ; i32 reserved = 0
-#   i64 row0 (first global row) ; i64 rows ; i64 ntotal (rows of the whole corpus)
-#   f32 bounds[2]   max |x - c(x)|_2 , max |c(x)|_2 over the rows of the index that wrote the file
-#   f32 [rows, d]   master rows ; u16 [rows, coarse_dim]  scan copy
-# ---------------------------------------------------------------------------------------------------------
-SHARD_MANIFEST = "kirag_shards.json"
-
-
-def _ids_crc32(ids) -> int:
-    import zlib
-    return int(zlib.crc32(np.ascontiguousarray(np.asarray(ids, dtype=np.int64)).tobytes()) & 0xFFFFFFFF)
-
-
-def _manifest_matches(manifest_path: str, id_map) -> bool:
-    """The native shards belong to the ``index_meta.faiss`` next to them: same row count and (manifests written since round 3) the same CRC-32 of
-    the id map.  A directory later rewritten with the reference-format files fails this and is loaded from ``index.faiss``."""
-    import json
-    try:
-        with open(manifest_path) as f:
-            man = json.load(f)
-    except Exception:
-        return False
-    if int(man.get("ntotal", -1)) != len(id_map):
-        return False
-    crc = man.get("meta_crc32")
-    return crc is None or int(crc) == _ids_crc32(id_map)
-_SHARD_MAGIC = b"KRSHARD1"
-_SHARD_HEADER = struct.Struct("<8siiiiqqqff")
-
-
-def shard_file_name(rank: int, world: int) -> str:
-    return f"index_shard_{rank:04d}_of_{world:04d}.krshard"
-
-
-def write_native_shard(index: FlatIPIndex, path: str, row0: int, ntotal: int) -> None:
-    n, d, dc = index.ntotal, index.d, index.coarse_dim
-    b = index.bounds() if n else np.zeros(2, np.float32)
-    with open(path, "wb") as f:
-        f.write(_SHARD_HEADER.pack(_SHARD_MAGIC, d, dc, {"bf16": 0, "f16": 1}[index.coarse_dtype], 0, int(row0), n, int(ntotal), float(b[0]), float(b[1])))
-        for s in range(0, n, _IO_CHUNK_ROWS):
-            f.write(index.reconstruct_n(s, min(_IO_CHUNK_ROWS, n - s)).tobytes())
-        for s in range(0, n, _IO_CHUNK_ROWS):
-            f.write(index.coarse_rows(s, min(_IO_CHUNK_ROWS, n - s)).tobytes())
-
-
-def read_native_shards(dir_path: str, device: Optional[int] = None, coarse_dtype: str = "bf16", row_range=None) -> FlatIPIndex:
-    """Rows [a, b) of the corpus (``row_range = (rank, world)``: that rank's contiguous share; None: everything) from whichever shard files hold
-    them — the loading world size need not be the saving one.  The 16-bit copy is taken from the files when their dtype matches ``coarse_dtype``
-    (bounds = the maximum over the files read, which is valid for any subset of their rows), otherwise the rows are re-quantised."""
-    import json
-    with open(os.path.join(dir_path, SHARD_MANIFEST)) as f:
-        man = json.load(f)
-    if man.get("format") != "krshard-1":
-        raise ValueError(f"{dir_path}: unknown shard format {man.get('format')!r}")
-    n, d = int(man["ntotal"]), int(man["d"])
-    a, b = 0, n
-    if row_range is not None:
-        rank, world = row_range
-        per = (n + world - 1) // world
-        a, b = min(rank * per, n), min((rank + 1) * per, n)
-    index = FlatIPIndex(d, device=device, coarse_dtype=coarse_dtype)
-    index.reserve(b - a)
-    raw = man["coarse_dtype"] == coarse_dtype
-    want_code = {"bf16": 0, "f16": 1}[coarse_dtype]
-    covered = a
-    for sh in man["shards"]:
-        r0, rows = int(sh["row0"]), int(sh["rows"])
-        lo, hi = max(a, r0), min(b, r0 + rows)
-        if lo >= hi:
-            continue
-        if lo != covered:
-            raise ValueError(f"{dir_path}: rows [{covered}, {lo}) are in no shard file")
-        with open(os.path.join(dir_path, sh["file"]), "rb") as f:
-            magic, fd, fdc, fct, _, fr0, frows, fnt, b0, b1 = _SHARD_HEADER.unpack(f.read(_SHARD_HEADER.size))
-            if magic != _SHARD_MAGIC or fd != d or fr0 != r0 or frows != rows or fnt != n:
-                raise ValueError(f"{sh['file']}: header does not match the manifest")
-            base_f = _SHARD_HEADER.size
-            base_c = base_f + rows * d * 4
-            for s0 in range(lo, hi, _IO_CHUNK_ROWS):
-                m = min(_IO_CHUNK_ROWS, hi - s0)
-                f.seek(base_f + (s0 - r0) * d * 4)
-                xf = np.frombuffer(f.read(m * d * 4), dtype=np.float32).reshape(m, d)
-                if raw and fdc == index.coarse_dim and fct == want_code:     # the FILE's own dtype code, not only the manifest's word
-                    f.seek(base_c + (s0 - r0) * fdc * 2)
-                    xc = np.frombuffer(f.read(m * fdc * 2), dtype=np.uint16).reshape(m, fdc)
-                    index.add_raw(xf, xc, np.array([b0, b1], np.float32))
-                else:
-                    index.add(xf)
-        covered = hi
-    if covered != b:
-        raise ValueError(f"{dir_path}: rows [{covered}, {b}) are in no shard file")
-    index.file_ntotal, index.row_offset = n, a
-    return index

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.kr_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.kr_abi_version() == _lib.ABI_VERSION == 5
 
 
 @pytest.mark.skipif(not NO_GPU, reason="checks the no-GPU failure mode")
@@ -264,6 +264,45 @@ def test_corpus_embedding_shard_files_and_index_builder(tmp_path):
     assert ids == [str(7 * i + 1) for i in range(53)]
     ref = ret.doc(col.encode_doc([corpus[i]["passage"] for i in range(53)]))
     torch.testing.assert_close(full, ref.detach())
+
+
+def test_corpus_encode_rejects_a_bad_batch_before_it_reaches_files_or_the_shard(tmp_path):
+    """ADVICE r02 / VERDICT r03 item 6: a token id outside the vocabulary used to be reported only by enc.check() after the LAST flush, when the bad
+    rows already sat in the resident shard and in a .pkl file.  Now the host validates every batch before it is sent anywhere
+    (compute_corpus_embeddings.py: validate)."""
+    from kirag_amd import compute_corpus_embeddings as CC
+    from kirag_amd.collators import E5Collator
+
+    class Corpus:
+        def __init__(self, n):
+            self.index_to_passage_id = {i: str(i) for i in range(n)}
+        def __len__(self): return len(self.index_to_passage_id)
+        def __getitem__(self, i): return {"index": i, "passage": f"title:  t{i}, text:  word{i}" + (" BAD" if i == 37 else "")}
+
+    class Tok(_WordTok):
+        def __call__(self, texts, **kw):
+            out = super().__call__(texts, **kw)
+            for r, t in enumerate(texts):
+                if "BAD" in t:
+                    out["input_ids"][r, 1] = 999_999        # outside the 200-entry vocabulary
+            return out
+
+    class Shard:                                            # the indexer surface cal_doc_embeddings uses
+        def __init__(self): self.ids = []
+        def index_data(self, ids, emb): self.ids += list(ids)
+
+    ret = _FakeRetriever(); ret.encoder = SimpleNamespace(config=SimpleNamespace(vocab_size=200))
+    col = E5Collator(Tok(), 12, 20)
+    args = SimpleNamespace(local_rank=-1, save_dir=str(tmp_path), name="n", index_folder="f", per_gpu_batch_size=8, num_passage_per_index_file=16,
+                           encode_batch_size=16)
+    shard = Shard()
+    with pytest.raises(ValueError, match="outside"):
+        CC.cal_doc_embeddings(args, ret, Corpus(53), col, rank=0, world=1, device=torch.device("cpu"), indexer=shard)
+    assert shard.ids == [str(i) for i in range(32)]        # the two good batches before it; not one row of the bad batch (passages 32..47)
+    folder = os.path.join(str(tmp_path), "n", "f")
+    for f in os.listdir(folder):                            # whatever was flushed holds good rows only
+        if f.startswith("passage_id_list_"):
+            assert all(int(i) < 32 for i in pickle.load(open(os.path.join(folder, f), "rb")))
 
 
 def test_faiss_flat_file_layout_byte_for_byte(tmp_path):

@@ -41,9 +41,27 @@ def _worker(rank, world, port, ret):
         sr = ShardedSearcher(ix, row_offset=a, world=world)
         qs = [torch.from_numpy(np.ascontiguousarray(np.roll(q, r, axis=0))).cuda() for r in range(3)]
         pend = [sr.search_deferred(qq, k) for qq in qs]
-        torch.cuda.current_stream().synchronize()
+        assert ix._lib.kr_index_search_pending(ix._h) == 3        # three local searches outstanding: nothing has waited for the device
+        done = sr.finish_deferred()                               # ONE host synchronisation + the certificate check of all three
+        assert len(done) == 3 and sr.redone == 0 and ix._lib.kr_index_search_pending(ix._h) == 0
         for r, (ps, pi) in enumerate(pend):
+            assert ps is done[r][0] and pi is done[r][1]
             assert np.array_equal(pi.numpy(), np.roll(io, r, axis=0)) and np.array_equal(ps.numpy().view(np.uint32), np.roll(so, r, axis=0).view(np.uint32))
+        # the same with a corpus NO query can be certified on by pass 1 (every row within 3e-5 of one direction): every rank re-answers its queries in
+        # finish() (passes 2 / 3 patch the local lists in place) and the exchange of those batches is repeated — results must still be the oracle's
+        u = rng.standard_normal(d).astype(np.float32); u /= np.linalg.norm(u)
+        xn = u[None, :] + 3e-5 * rng.standard_normal((4000, d)).astype(np.float32); xn /= np.linalg.norm(xn, axis=1, keepdims=True)
+        qn = xn[rng.choice(4000, 9)].copy()
+        an, bn = shard_range(4000, rank, world)
+        ixn = FlatIPIndex(d, device=0); ixn.add(torch.from_numpy(xn[an:bn]).cuda())
+        srn = ShardedSearcher(ixn, row_offset=an, world=world)
+        qns = [torch.from_numpy(np.ascontiguousarray(np.roll(qn, r, axis=0))).cuda() for r in range(2)]
+        pend = [srn.search_deferred(qq, 10) for qq in qns]
+        srn.finish_deferred()
+        son, ion = S.search_canonical(qn, xn, 10)
+        assert srn.redone == 2, srn.redone
+        for r, (ps, pi) in enumerate(pend):
+            assert np.array_equal(pi.numpy(), np.roll(ion, r, axis=0)) and np.array_equal(ps.numpy().view(np.uint32), np.roll(son, r, axis=0).view(np.uint32))
         # more gathered entries than the device merge holds (16 shards x k = 1024 in production): the host-merge fallback, forced here by a small limit
         searcher = ShardedSearcher(ix, row_offset=a, world=world)
         searcher.DEVICE_MERGE_MAX = 64
@@ -276,8 +294,8 @@ def _worker_nccl_one_rank(rank, world, port, ret):
             sr = ShardedSearcher(ix, row_offset=0, world=1, collective=coll)
             s, i = sr._search_device(qd, k, k, nq, qd.device)                 # the N > 1 device path with W = 1: RCCL all-gather of the uint8 block / kr_comm
             assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32)), coll
-            ps, pi = sr._search_device(qd, k, k, nq, qd.device, defer=True)
-            torch.cuda.current_stream().synchronize()
+            ps, pi = sr.search_deferred(qd, k)
+            sr.finish_deferred()
             assert np.array_equal(pi.numpy(), io) and np.array_equal(ps.numpy().view(np.uint32), so.view(np.uint32)), coll
             sr.close()
         # the collectives bench.py --gpus N issues, on the RCCL backend: query-vector all-gather, barrier, max over ranks of the elapsed time

@@ -18,8 +18,12 @@ def rnd(t, mode):
     return t
 
 
-def forward(W, ids, mask, heads, op, resid_lo, y16=True, pool="mean"):
-    """op: 'bf16' | 'f16' | 'f32' = precision of every MFMA operand and of every stored activation."""
+def forward(W, ids, mask, heads, op, resid_lo, y16=True, pool="mean", site=None):
+    """op: 'bf16' | 'f16' | 'f32' = precision of every MFMA operand and of every stored activation.  site: optional {name: precision} overriding op for
+    single rounding points — 'wqkv' 'w1' 'wo' 'w2' (weights), 'ctx' 'h' (the activations only the out-proj / FF2 GEMMs read), 'y' (dense outputs) —
+    e.g. {'h': 'bf16', 'w2': 'bf16'} = the FF2 GEMM on bf16 operands inside an f16 encoder (round 4: which GEMMs need the 11 bits?)."""
+    site = site or {}
+    def sop(name): return site.get(name, op)
     B, S = ids.shape
     H = W["embeddings.word_embeddings.weight"].shape[1]; dh = H // heads
     def ln(x, g, b): return torch.nn.functional.layer_norm(x, (H,), g, b, 1e-12)
@@ -40,7 +44,7 @@ def forward(W, ids, mask, heads, op, resid_lo, y16=True, pool="mean"):
     while f"encoder.layer.{L}.attention.self.query.weight" in W: L += 1
     for l in range(L):
         p = f"encoder.layer.{l}."
-        def lin(t, name): return t @ rnd(W[p + name + ".weight"], op).T + W[p + name + ".bias"]
+        def lin(t, name): return t @ rnd(W[p + name + ".weight"], sop("w1" if name.startswith("intermediate") else "wqkv")).T + W[p + name + ".bias"]
         q = rnd(lin(xh, "attention.self.query") / math.sqrt(dh), op).view(B, S, heads, dh).transpose(1, 2)
         k = rnd(lin(xh, "attention.self.key"), op).view(B, S, heads, dh).transpose(1, 2)
         v = rnd(lin(xh, "attention.self.value"), op).view(B, S, heads, dh).transpose(1, 2)
@@ -48,14 +52,14 @@ def forward(W, ids, mask, heads, op, resid_lo, y16=True, pool="mean"):
         pr = torch.softmax(s, -1)
         m = s.max(-1, keepdim=True).values
         e = rnd(torch.exp(s - m), op)                       # P is fed to the MFMA as 16-bit, the row sum is kept in fp32
-        ctx = rnd(((e @ v) / torch.exp(s - m).sum(-1, keepdim=True)), op).transpose(1, 2).reshape(B, S, H)
-        y = ctx @ rnd(W[p + "attention.output.dense.weight"], op).T
-        y = rnd(y, op) if y16 else y
+        ctx = rnd(((e @ v) / torch.exp(s - m).sum(-1, keepdim=True)), sop("ctx")).transpose(1, 2).reshape(B, S, H)
+        y = ctx @ rnd(W[p + "attention.output.dense.weight"], sop("wo")).T
+        y = rnd(y, sop("y")) if y16 else y
         x = ln(y + W[p + "attention.output.dense.bias"] + xr, W[p + "attention.output.LayerNorm.weight"], W[p + "attention.output.LayerNorm.bias"])
         xh, xr = stream(x, 1)
-        h = rnd(torch.nn.functional.gelu(lin(xh, "intermediate.dense")), op)
-        y = h @ rnd(W[p + "output.dense.weight"], op).T
-        y = rnd(y, op) if y16 else y
+        h = rnd(torch.nn.functional.gelu(lin(xh, "intermediate.dense")), sop("h"))
+        y = h @ rnd(W[p + "output.dense.weight"], sop("w2")).T
+        y = rnd(y, sop("y")) if y16 else y
         x = ln(y + W[p + "output.dense.bias"] + xr, W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"])
         if l + 1 < L: xh, xr = stream(x, 2)
     if pool == "mean":
@@ -73,6 +77,10 @@ if __name__ == "__main__":
     W = {k: torch.from_numpy(v).to(dev) for k, v in g10_spec.weights(wname).items()}
     outs = {}
     modes = [("f16", 1, True), ("f16", 4, True)]
+    SITES = {"ff2": {"h": "bf16", "w2": "bf16"}, "ff2out": {"h": "bf16", "w2": "bf16", "ctx": "bf16", "wo": "bf16"},
+             "allw": {"h": "bf16", "w2": "bf16", "ctx": "bf16", "wo": "bf16", "w1": "bf16", "wqkv": "bf16"}, "w8": {"w2": "bf16", "wo": "bf16", "w1": "bf16", "wqkv": "bf16"}}
+    if os.environ.get("PROBE_SITES"):      # e.g. PROBE_SITES=ff2,ff2out : f16 + 8-bit low half with single GEMMs / weights at bf16 precision
+        modes = [("f16", 4, True)] + [("f16", 4, nm) for nm in os.environ["PROBE_SITES"].split(",")]
     for case in cases:
         tag, ci = case.split(".c"); ci = int(ci)
         B, S, layout, seed = g10_spec.CASES[wname][tag][ci]
@@ -80,12 +88,13 @@ if __name__ == "__main__":
         ref = g[f"{wname}.{case}.out"]
         for op, lo, y16 in modes:
             with torch.no_grad():
-                out = forward(W, torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev), 16, op, lo, y16, "mean" if tag == "e5" else "cls").cpu().numpy()
+                out = forward(W, torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev), 16, op, lo, True, "mean" if tag == "e5" else "cls",
+                              site=SITES.get(y16) if isinstance(y16, str) else None).cpu().numpy()
             cos = (out * ref).sum(1)
             outs[(case, op, lo, y16)] = out
-            print(f"{wname}.{case} B{B} S{S}  operands {op:4s} resid_lo={int(lo)} y16={int(y16)}: max abs err {np.abs(out - ref).max():.2e}  1-cos {float((1 - cos).max()):.2e}", flush=True)
+            print(f"{wname}.{case} B{B} S{S}  operands {op:4s} resid_lo={int(lo)} y16={y16}: max abs err {np.abs(out - ref).max():.2e}  1-cos {float((1 - cos).max()):.2e}", flush=True)
     if len(cases) >= 2:
         a, b = cases[0], cases[1]
         ra, rb = g[f"{wname}.{a}.out"], g[f"{wname}.{b}.out"]
         for op, lo, y16 in modes:
-            print(f"scores {a} x {b}  operands {op:4s} resid_lo={int(lo)} y16={int(y16)}: max |q.d - ref| = {np.abs(outs[(a, op, lo, y16)] @ outs[(b, op, lo, y16)].T - ra @ rb.T).max():.2e}")
+            print(f"scores {a} x {b}  operands {op:4s} resid_lo={int(lo)} y16={y16}: max |q.d - ref| = {np.abs(outs[(a, op, lo, y16)] @ outs[(b, op, lo, y16)].T - ra @ rb.T).max():.2e}")
