@@ -2,11 +2,13 @@
 """Per-rank work of `bench.py --gpus W` measured on ONE GPU (no collectives): for W in 1, 2, 4, 8 the rank's share of the strong-scaling job
 (5M x 1024 corpus / W rows resident, all 1000 query vectors searched top-100 over the local shard, device merge of W lists + D2H of the result) under the
 two encode schedules of bench.py:
-  queries  every rank encodes 1000 / W queries of every batch (round 2)
-  batch    rank r encodes the WHOLE batch of every W-th step (default since round 3): per block of W steps one full-batch encode + W searches
+  queries  every rank encodes 1000 / W queries of every batch, step by step (round 2)
+  batch    blocks of up to W steps: every rank encodes its 1 / W slice of each batch of the block in ONE forward (default; round 4: a partial last block
+           of c < W steps is a forward of c * 1000 / W queries per rank instead of a full batch on c ranks and nothing on the others)
+The driver runs `--steps 20`: at W = 8 that is two full blocks and one block of 4 steps; the K = 20 line uses the measured forward of 4 * 125 = 500 queries.
 The two all-gathers cannot be measured on a one-GPU box; they are ESTIMATED (marked est.) as a ring all-gather at 100 GB/s per direction of the
 7 x 153 GB/s xGMI links plus 20 us of latency per collective: per step  queries: 4 MB of query vectors + 1.2 MB x W of results;  batch: 4 MB (its share
-of the W x 4 MB block gather) + 1.2 MB x W.  Usage: python tools/scale_emulate.py [total_rows]"""
+of the block gather) + 1.2 MB x W.  Usage: python tools/scale_emulate.py [total_rows] [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,6 +18,7 @@ from kirag_amd import _lib
 from kirag_amd.retriever.index import FlatIPIndex
 
 total = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 nq, k, d = 1000, 100, 1024
 dev = torch.device("cuda:0")
 enc = BS.make_hip_encoder(dev)
@@ -69,10 +72,17 @@ for world in (1, 2, 4, 8):
     coll_b = gather(4.0 * world) / world + gather(1.2 * world)  # batch schedule, per step
     tot_q = ms_e + ms_s + ms_m
     tot_b = ms_full / world + ms_s + ms_m
+    # K steps = K // W full blocks + one block of c = K % W steps, whose encode is ONE forward of c * nq / W queries per rank
+    c = K % world
+    ms_part = timed(lambda: enc.forward(ids[:c * mine], mask[:c * mine], 0))[0] if c else 0.0
+    tot_k = ((K // world) * ms_full + ms_part) / K + ms_s + ms_m
+    base_k = globals().setdefault("base_k", tot_k)
     base = base or tot_q
     print(f"W={world}: encode {mine} queries {ms_e:.2f} ms | search 1000 x {n} rows {ms_s:.2f} ms (coarse {coarse:.2f}) | device merge + D2H of the result {ms_m:.2f} ms\n"
           f"      queries schedule: {tot_q:.2f} ms per step (x{base / tot_q:.2f}); with est. collectives {tot_q + coll_q:.2f} ms (x{base / (tot_q + coll_q):.2f})\n"
           f"      batch schedule:   full-batch encode {ms_full:.2f} ms per {world} steps -> {tot_b:.2f} ms per step (x{base / tot_b:.2f}); "
-          f"with est. collectives {tot_b + coll_b:.2f} ms (x{base / (tot_b + coll_b):.2f})", flush=True)
+          f"with est. collectives {tot_b + coll_b:.2f} ms (x{base / (tot_b + coll_b):.2f})\n"
+          f"      batch schedule, K = {K} steps ({K // world} full blocks + one of {c}: forward of {c * mine} queries {ms_part:.2f} ms): {tot_k:.2f} ms per step "
+          f"(x{base_k / tot_k:.2f}); with est. collectives {tot_k + coll_b:.2f} ms (x{base_k / (tot_k + coll_b):.2f})", flush=True)
     del ix
     torch.cuda.empty_cache()
