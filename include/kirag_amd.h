@@ -31,6 +31,7 @@ extern "C" {
 #define KR_ENODEV (-19)   /* no usable HIP device */
 #define KR_EHIP (-5)      /* a HIP runtime call failed; see kr_last_error() */
 #define KR_ESTATE (-1)    /* handle not ready (e.g. encoder weights missing) */
+#define KR_ERANGE (-34)   /* the encoder met non-finite activations (a value outside the f16 operand range, or NaN / Inf weights): results unusable */
 
 #define KR_ABI_VERSION 5
 int kr_abi_version(void);
@@ -207,7 +208,9 @@ int kr_encoder_forward(kr_encoder* enc, const int64_t* input_ids, const int64_t*
 /* kr_encoder_forward with a DEVICE `out` pointer only enqueues work on `stream` and returns (no host synchronisation); with a host `out`
  * it returns when the result is in the caller's buffer.  The one thing a forward can get wrong at run time - a token id outside [0, vocab)
  * - is recorded by the kernels (the offending token is read as id 0) and reported as KR_EINVAL by the host-output call itself, or, for
- * device-output calls, by the NEXT call on the handle once that forward has finished, or by kr_encoder_check(), which waits for it. */
+ * device-output calls, by the NEXT call on the handle once that forward has finished, or by kr_encoder_check(), which waits for it.
+ * The same channel reports KR_ERANGE when a LayerNorm row of the forward was not finite: with f16 operands (the default) an activation beyond
+ * +-65504 becomes inf and the embedding NaN; nothing saturates silently. */
 int kr_encoder_check(kr_encoder* enc);
 /* debugging / parity: last_hidden_state of the previous forward, fp32 [B*S_packed...] see DESIGN.md */
 int kr_encoder_last_hidden(kr_encoder* enc, float* out /* [B,S,hidden] */, int B, int S);

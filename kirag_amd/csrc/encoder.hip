@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ 
         if (v) {
             const int r = run + __popcll(bal & ((1ull << lane) - 1ull));
             int64_t id = ids[(int64_t)b * S + p];
-            if (id < 0 || id >= vocab) { *err = 1; id = 0; }
+            if (id < 0 || id >= vocab) { atomicOr(err, 1); id = 0; }
             tok_id[o + r] = (int)id; tok_pos[o + r] = p;
         }
         run += __popcll(bal);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ 
     const int n = nq[b];
     if (lane == 0 && n > nk[b]) {
         int64_t id = ids[(int64_t)b * S];
-        if (id < 0 || id >= vocab) { *err = 1; id = 0; }
+        if (id < 0 || id >= vocab) { atomicOr(err, 1); id = 0; }
         tok_id[o + nk[b]] = (int)id; tok_pos[o + nk[b]] = 0;
     }
     const int padded = (n + align - 1) & ~(align - 1);
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id
 // independent of the batch).  KIRAG_AMD_LN8=1 selects the 8-byte kernel (A/B).
 template <int NS>
 __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, const float* __restrict__ ybias, const int* __restrict__ Tp, const float* __restrict__ g,
-                                              const float* __restrict__ bta, float eps, int H, const uint8_t* xlo_in, uint8_t* xlo, uint16_t* xb) {
+                                              const float* __restrict__ bta, float eps, int H, const uint8_t* xlo_in, uint8_t* xlo, uint16_t* xb, int* __restrict__ err) {
     const int lane = threadIdx.x & 63;
     const int T = *Tp;
     float gg[NS][8], bb[NS][8], yb[NS][8];
@@ -368,6 +368,9 @@ __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, co
                 for (int c = 0; c < 8; ++c) s += v[j][c];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        // a token row whose sum is not finite: an activation left the 16-bit operand range upstream (f16: |x| > 65504 becomes inf, inf - inf = NaN here)
+        // or the weights hold NaN / Inf.  Recorded in the sticky error word (bit 1) and reported like an out-of-vocabulary token id (kr_encoder_check)
+        if (lane == 0 && !(fabsf(s) < INFINITY)) atomicOr(err, 2);
         const float mu = s / (float)H;
         float q = 0.f;
 #pragma unroll
@@ -1665,12 +1668,12 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
             a.Tp = e->d_B;
             a.W = l.wo; a.X = e->c_ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->c_y; a.ldx = 0; a.ldo = 0;
             KR_TRY(launch_proj(EPI_DENSE, a, B, e->num_cu, e->device, st));
-            hipLaunchKernelGGL(ln_kernel, dim3(c_ln_grid), dim3(256), 0, st, e->c_y, l.bo_eff, e->d_B, l.ln1g, l.ln1b, eps, H, c_lo, c_lo, e->c_xb);
+            hipLaunchKernelGGL(ln_kernel, dim3(c_ln_grid), dim3(256), 0, st, e->c_y, l.bo_eff, e->d_B, l.ln1g, l.ln1b, eps, H, c_lo, c_lo, e->c_xb, e->d_err);
             a.W = l.w1; a.X = e->c_xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->c_h; a.ldx = 0; a.ldo = FF + e->h_pad;
             KR_TRY(launch_proj(EPI_GELU, a, B, e->num_cu, e->device, st));
             a.W = l.w2; a.X = e->c_h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->c_y; a.ldx = FF + e->h_pad; a.ldo = 0;
             KR_TRY(launch_proj(EPI_DENSE, a, B, e->num_cu, e->device, st));
-            hipLaunchKernelGGL(ln_kernel, dim3(c_ln_grid), dim3(256), 0, st, e->c_y, l.b2, e->d_B, l.ln2g, l.ln2b, eps, H, c_lo, e->c_xlo, e->c_xb);
+            hipLaunchKernelGGL(ln_kernel, dim3(c_ln_grid), dim3(256), 0, st, e->c_y, l.b2, e->d_B, l.ln2g, l.ln2b, eps, H, c_lo, e->c_xlo, e->c_xb, e->d_err);
             hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->c_xb, e->c_xlo, e->c_off, e->c_nk, e->c_cls, H, pool, e->out);
             KR_HIP(hipGetLastError());
             return 0;
@@ -1678,7 +1681,7 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y; a.ldx = 0; a.ldo = 0;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
-        hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.bo_eff, e->d_T, l.ln1g, l.ln1b, eps, H, lo_rw, lo_rw, e->xb);
+        hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.bo_eff, e->d_T, l.ln1g, l.ln1b, eps, H, lo_rw, lo_rw, e->xb, e->d_err);
         // intermediate.dense + GELU
         a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h; a.ldx = 0; a.ldo = FF + e->h_pad;
         KR_TRY(launch_proj(EPI_GELU, a, maxT, e->num_cu, e->device, st));
@@ -1686,7 +1689,7 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
         a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->y; a.ldx = FF + e->h_pad; a.ldo = 0;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
         // the LAST LayerNorm always writes the low half: pooling and kr_encoder_last_hidden read the final hidden state with 16 mantissa bits
-        hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.b2, e->d_T, l.ln2g, l.ln2b, eps, H, lo_rw, last ? e->xlo : lo_rw, e->xb);
+        hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.b2, e->d_T, l.ln2g, l.ln2b, eps, H, lo_rw, last ? e->xlo : lo_rw, e->xb, e->d_err);
     }
     hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);
     KR_HIP(hipGetLastError());
@@ -1739,10 +1742,17 @@ static int run_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
 
 // the sticky device error word has been copied to e->h_err and that copy has completed
 static int report_token_error(Encoder* e, hipStream_t st) {
-    if (*e->h_err == 0) return 0;
+    const int w = *e->h_err;
+    if (w == 0) return 0;
     *e->h_err = 0;
     KR_HIP(hipMemsetAsync(e->d_err, 0, sizeof(int), st));
-    return fail(KR_EINVAL, "input_ids contain a token id outside [0, %d)", e->cfg.vocab);
+    if (w & 1) return fail(KR_EINVAL, "input_ids contain a token id outside [0, %d)", e->cfg.vocab);
+#ifdef KR_ENC_BUILD_F16
+    return fail(KR_ERANGE, "non-finite activations in the forward: a value left the f16 operand range (|x| > 65504) or the weights hold NaN / Inf; "
+                           "the embeddings of this batch are not usable (KIRAG_AMD_ENCODER_DTYPE=bf16 has the fp32 exponent range)");
+#else
+    return fail(KR_ERANGE, "non-finite activations in the forward: the weights (or an overflowing accumulation) hold NaN / Inf; the embeddings of this batch are not usable");
+#endif
 }
 
 int enc_forward(void* h, const int64_t* input_ids, const int64_t* attention_mask, int B, int S, int pool, float* out, void* stream) {

@@ -1556,9 +1556,10 @@ static int finish_one(Index* ix, int64_t* flagged_out) {
             const float* qb = pd.q + (size_t)b * QBLK * ix->d;
             float* sb = pd.scores + (size_t)b * QBLK * pd.k; int64_t* rb = pd.rows + (size_t)b * QBLK * pd.k;
             const int tb = newest ? b : THETA_BLOCKS;     // an older call's theta1 has been overwritten: pass 2 without the pre-scan
+            const bool restore = nblocks > 1 || !newest;  // ... and so have its queries and pass-1 results in the workspace: copied in again
             int rc;
-            if (ix->coarse == KR_COARSE_BF16) rc = slow_passes<BF16>(ix, qb, nb, pd.k, sb, rb, tb, pd.st, hflags, true, true, nblocks > 1);
-            else rc = slow_passes<F16>(ix, qb, nb, pd.k, sb, rb, tb, pd.st, hflags, true, true, nblocks > 1);
+            if (ix->coarse == KR_COARSE_BF16) rc = slow_passes<BF16>(ix, qb, nb, pd.k, sb, rb, tb, pd.st, hflags, true, true, restore);
+            else rc = slow_passes<F16>(ix, qb, nb, pd.k, sb, rb, tb, pd.st, hflags, true, true, restore);
             if (rc) return rc;
         }
         flagged_total += nfl;

@@ -64,7 +64,11 @@ def _embed(texts: List[str], max_length: int, batch_size: int) -> Tensor:
     step = max(batch_size, 256)
     # every chunk is only ENQUEUED; the one device-to-host copy at the end is the only synchronisation (the reference copies per batch of 4)
     outs = [model_encode(tokenizer_encode(texts[i:i + step], max_length=max_length)).detach() for i in range(0, len(texts), step)]
-    return torch.cat(outs, dim=0).cpu()
+    out = torch.cat(outs, dim=0).cpu()
+    hip = getattr(model, "_hip", None)
+    if hip is not None:
+        hip.check()          # deferred input errors of the forwards above (token id outside the vocabulary, token_type_ids != 0, non-finite activations)
+    return out               # surface here, behind the copy that already waited for the device — never as plausible-looking vectors
 
 
 def get_e5_embeddings_for_query(query_list: List[str], max_length: int = 128, batch_size: int = 4) -> Tensor:

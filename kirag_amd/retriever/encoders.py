@@ -122,8 +122,10 @@ class HipBertForward:
     def check(self) -> None:
         """Wait for the last device-output forward and raise if it saw a token id outside the vocabulary (``kr_encoder_check``) or a
         non-zero ``token_type_ids`` entry (deferred like the token ids: see ``defer_token_type_check``)."""
-        self.poll_token_type(block=True)
-        _lib.check(self._lib.kr_encoder_check(self._h))
+        try:
+            self.poll_token_type(block=True)
+        finally:                                               # a pending token-type error must not leave a pending out-of-vocabulary / overflow error unreported
+            _lib.check(self._lib.kr_encoder_check(self._h))
 
     _TT_MSG = "token_type_ids != 0 is not used by any KiRAG caller and is not implemented on the HIP path"
 

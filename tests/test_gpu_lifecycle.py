@@ -108,6 +108,34 @@ def test_async_boundary_device_pointers_streams_and_deferred_errors():
     assert np.array_equal(rows.cpu().numpy(), io) and np.array_equal(i_np, io) and np.array_equal(sc.cpu().numpy().view(np.uint32), so.view(np.uint32))
 
 
+def test_f16_overflow_is_reported_not_returned_as_embeddings():
+    """the default encoder stores every activation as f16; a value beyond +-65504 becomes inf, the next LayerNorm row NaN, and until
+    round 4 that came back as an embedding without any error.  Now the LayerNorm kernel records a non-finite row sum in the sticky error word and
+    the forward / kr_encoder_check report KR_ERANGE with a hint; the bf16 mode (fp32 exponent range) encodes the same weights fine."""
+    from kirag_amd import _lib
+    from kirag_amd.retriever.encoders import HipBertForward
+    cfg = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
+                          max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    w = E.synth_weights(128, 2, 512, 1000, 512, seed=5)
+    big = dict(w)
+    big["encoder.layer.0.intermediate.dense.weight"] = w["encoder.layer.0.intermediate.dense.weight"] * 3.0e5     # GELU outputs far beyond 65504
+    ids, mask = E.synth_tokens(6, 24, seed=1, ragged=True, vocab_lo=5, vocab_hi=1000, min_len=3)
+    h = HipBertForward(cfg, 0, operand_dtype="f16"); h.load_state(big)
+    with pytest.raises(_lib.KiragAmdError, match="non-finite") as ei:
+        h.forward_np(ids, mask, 0)                                    # host output: reported by the call itself
+    assert ei.value.code == -34 and "bf16" in str(ei.value)
+    tid = torch.from_numpy(ids).cuda(); tm = torch.from_numpy(mask).cuda()
+    h.forward(tid, tm, 0)                                             # device output: deferred ...
+    with pytest.raises(_lib.KiragAmdError, match="non-finite"):
+        h.check()                                                     # ... to kr_encoder_check
+    h.load_state(w)                                                   # the handle is usable again and the flag was cleared
+    ref = E.e5_encode(w, ids, mask, 2)
+    assert np.abs(h.forward_np(ids, mask, 0) - ref).max() < 4e-3
+    hb = HipBertForward(cfg, 0, operand_dtype="bf16", residual_lo=False); hb.load_state(big)
+    out = hb.forward_np(ids, mask, 0)                                 # the same weights in the bf16 mode: finite, unit norm
+    assert np.isfinite(out).all() and np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
+
+
 def test_large_index_grows_in_place_without_copies():
     """An index that outgrows 256 MiB moves once into mapped 64-MiB chunks (hipMemAddressReserve / hipMemMap) and from then on grows in place:
     50k-row appends WITHOUT reserve() (the reference's faiss_index_corpus loop, index.py:88-106 style) must not need a second copy of the rows —

