@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id
 // independent of the batch).  KIRAG_AMD_LN8=1 selects the 8-byte kernel (A/B).
 template <int NS>
 __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, const float* __restrict__ ybias, const int* __restrict__ Tp, const float* __restrict__ g,
-                                              const float* __restrict__ bta, float eps, int H, const uint8_t* xlo_in, uint8_t* xlo, uint16_t* xb, int* __restrict__ err) {
+                                              const float* __restrict__ bta, float eps, int H, const uint8_t* xlo_in, uint8_t* xlo, uint16_t* xb) {
     const int lane = threadIdx.x & 63;
     const int T = *Tp;
     float gg[NS][8], bb[NS][8], yb[NS][8];
@@ -368,9 +368,6 @@ __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, co
                 for (int c = 0; c < 8; ++c) s += v[j][c];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        // a token row whose sum is not finite: an activation left the 16-bit operand range upstream (f16: |x| > 65504 becomes inf, inf - inf = NaN here)
-        // or the weights hold NaN / Inf.  Recorded in the sticky error word (bit 1) and reported like an out-of-vocabulary token id (kr_encoder_check)
-        if (lane == 0 && !(fabsf(s) < INFINITY)) atomicOr(err, 2);
         const float mu = s / (float)H;
         float q = 0.f;
 #pragma unroll
@@ -1191,7 +1188,7 @@ __global__ __launch_bounds__(ADMA_THREADS, 512 / ADMA_THREADS) void k_attn_dma(c
 // pooling + L2 normalisation: one block per sequence.  Mean pooling: wave w sums the tokens t = w, w+4, ... (8-byte loads of the (hi, lo)
 // stream, 4 columns per lane and step), the four partial sums are combined in a fixed order (w = 0..3), so the result is deterministic.
 __global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, const uint8_t* __restrict__ xlo, const int* __restrict__ seq_off, const int* __restrict__ seq_nk,
-                                              const int* __restrict__ seq_cls, int H, int pool, float* __restrict__ out) {
+                                              const int* __restrict__ seq_cls, int H, int pool, float* __restrict__ out, int* __restrict__ err) {
     __shared__ float part[4][2048];   // H <= 2048
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1250,6 +1247,10 @@ __global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, c
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
     const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    // A sequence WITH attended tokens whose pooled vector is not finite: an activation left the 16-bit operand range upstream (f16: |x| > 65504 becomes
+    // inf, the next LayerNorm row NaN) or the weights hold NaN / Inf.  Recorded in the sticky error word (bit 1) and reported like an out-of-vocabulary
+    // token id (kr_encoder_check: KR_ERANGE) instead of being returned as an embedding.  nk == 0 is the reference's own NaN (average_pool of nothing).
+    if (tid == 0 && nk > 0 && !(nrm < INFINITY)) atomicOr(err, 2);
     const float den = fmaxf(nrm, 1e-12f);   // F.normalize eps; NaN norm stays NaN (fmaxf would drop it)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1668,20 +1669,20 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
             a.Tp = e->d_B;
             a.W = l.wo; a.X = e->c_ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->c_y; a.ldx = 0; a.ldo = 0;
             KR_TRY(launch_proj(EPI_DENSE, a, B, e->num_cu, e->device, st));
-            hipLaunchKernelGGL(ln_kernel, dim3(c_ln_grid), dim3(256), 0, st, e->c_y, l.bo_eff, e->d_B, l.ln1g, l.ln1b, eps, H, c_lo, c_lo, e->c_xb, e->d_err);
+            hipLaunchKernelGGL(ln_kernel, dim3(c_ln_grid), dim3(256), 0, st, e->c_y, l.bo_eff, e->d_B, l.ln1g, l.ln1b, eps, H, c_lo, c_lo, e->c_xb);
             a.W = l.w1; a.X = e->c_xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->c_h; a.ldx = 0; a.ldo = FF + e->h_pad;
             KR_TRY(launch_proj(EPI_GELU, a, B, e->num_cu, e->device, st));
             a.W = l.w2; a.X = e->c_h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->c_y; a.ldx = FF + e->h_pad; a.ldo = 0;
             KR_TRY(launch_proj(EPI_DENSE, a, B, e->num_cu, e->device, st));
-            hipLaunchKernelGGL(ln_kernel, dim3(c_ln_grid), dim3(256), 0, st, e->c_y, l.b2, e->d_B, l.ln2g, l.ln2b, eps, H, c_lo, e->c_xlo, e->c_xb, e->d_err);
-            hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->c_xb, e->c_xlo, e->c_off, e->c_nk, e->c_cls, H, pool, e->out);
+            hipLaunchKernelGGL(ln_kernel, dim3(c_ln_grid), dim3(256), 0, st, e->c_y, l.b2, e->d_B, l.ln2g, l.ln2b, eps, H, c_lo, e->c_xlo, e->c_xb);
+            hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->c_xb, e->c_xlo, e->c_off, e->c_nk, e->c_cls, H, pool, e->out, e->d_err);
             KR_HIP(hipGetLastError());
             return 0;
         }
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y; a.ldx = 0; a.ldo = 0;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
-        hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.bo_eff, e->d_T, l.ln1g, l.ln1b, eps, H, lo_rw, lo_rw, e->xb, e->d_err);
+        hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.bo_eff, e->d_T, l.ln1g, l.ln1b, eps, H, lo_rw, lo_rw, e->xb);
         // intermediate.dense + GELU
         a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h; a.ldx = 0; a.ldo = FF + e->h_pad;
         KR_TRY(launch_proj(EPI_GELU, a, maxT, e->num_cu, e->device, st));
@@ -1689,9 +1690,9 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
         a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->y; a.ldx = FF + e->h_pad; a.ldo = 0;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e->num_cu, e->device, st));
         // the LAST LayerNorm always writes the low half: pooling and kr_encoder_last_hidden read the final hidden state with 16 mantissa bits
-        hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.b2, e->d_T, l.ln2g, l.ln2b, eps, H, lo_rw, last ? e->xlo : lo_rw, e->xb, e->d_err);
+        hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.b2, e->d_T, l.ln2g, l.ln2b, eps, H, lo_rw, last ? e->xlo : lo_rw, e->xb);
     }
-    hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out);
+    hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out, e->d_err);
     KR_HIP(hipGetLastError());
     return 0;
 }

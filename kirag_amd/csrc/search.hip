@@ -162,6 +162,7 @@ struct Index {
     Pending pend[PEND_MAX];
     int pend_head = 0, pend_n = 0;  // ring of outstanding calls: slots pend_head .. pend_head + pend_n - 1 (mod PEND_MAX), oldest first
     uint64_t call_seq = 0;
+    uint64_t ws_owner = 0;          // the call whose last query block (queries, pass-1 results) the search workspace currently holds
     int status_blocks = 0;          // h_status: the pass-2 status region exists
 };
 
@@ -1506,6 +1507,7 @@ static int begin_search(Index* ix, const float* q, int nq, int k, float* scores,
     KR_TRY(ensure_slot_status(pd, nblocks));
     pd.q = q; pd.nq = nq; pd.k = k; pd.scores = scores; pd.rows = rows; pd.st = st; pd.rounds.assign(nblocks, 0);
     pd.seq = ++ix->call_seq;
+    ix->ws_owner = pd.seq;
     {   // ensure_ws creates the events on first use: make sure they exist before the first record
         int K1, cap, rmax; plan_buffers(k, K1, cap, rmax);
         KR_TRY(ensure_ws(ix, k, cap));
@@ -1556,7 +1558,10 @@ static int finish_one(Index* ix, int64_t* flagged_out) {
             const float* qb = pd.q + (size_t)b * QBLK * ix->d;
             float* sb = pd.scores + (size_t)b * QBLK * pd.k; int64_t* rb = pd.rows + (size_t)b * QBLK * pd.k;
             const int tb = newest ? b : THETA_BLOCKS;     // an older call's theta1 has been overwritten: pass 2 without the pre-scan
-            const bool restore = nblocks > 1 || !newest;  // ... and so have its queries and pass-1 results in the workspace: copied in again
+            // ... and so have its queries and pass-1 results in the workspace (by a later call's pass 1, or by the slow passes of an older call that was
+            // finished just before this one): copied in again
+            const bool restore = nblocks > 1 || ix->ws_owner != pd.seq;
+            ix->ws_owner = pd.seq;
             int rc;
             if (ix->coarse == KR_COARSE_BF16) rc = slow_passes<BF16>(ix, qb, nb, pd.k, sb, rb, tb, pd.st, hflags, true, true, restore);
             else rc = slow_passes<F16>(ix, qb, nb, pd.k, sb, rb, tb, pd.st, hflags, true, true, restore);
