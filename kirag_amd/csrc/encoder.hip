@@ -1607,7 +1607,7 @@ int enc_finalize(void* h) {
 // CLS shortcut: row seq_off[b] + seq_cls[b] of ctx / the residual stream (hi, lo) -> row b of the compact buffers; also the compact "sequence" tables
 // (one token per sequence) and the row count for the B-row kernels that follow
 __global__ __launch_bounds__(256) void k_gather_cls(const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ xb, const uint8_t* __restrict__ xlo,
-                                                    const int* __restrict__ seq_off, const int* __restrict__ seq_cls, int H, uint16_t* __restrict__ c_ctx,
+                                                    const int* __restrict__ seq_off, const int* __restrict__ seq_cls, const int* __restrict__ seq_nk, int H, uint16_t* __restrict__ c_ctx,
                                                     uint16_t* __restrict__ c_xb, uint8_t* __restrict__ c_xlo, int* __restrict__ c_off, int* __restrict__ c_nk,
                                                     int* __restrict__ c_cls, int* __restrict__ d_B) {
     const int b = blockIdx.x;
@@ -1618,7 +1618,7 @@ __global__ __launch_bounds__(256) void k_gather_cls(const uint16_t* __restrict__
         if (xlo) *reinterpret_cast<uint2*>(c_xlo + (int64_t)b * H + i) = *reinterpret_cast<const uint2*>(xlo + src * H + i);
     }
     if (threadIdx.x == 0) {
-        c_off[b] = b; c_nk[b] = 1; c_cls[b] = 0;
+        c_off[b] = b; c_nk[b] = seq_nk[b] > 0 ? 1 : 0; c_cls[b] = 0;   // c_nk == 0: an all-masked sequence (its NaN is the reference's own, not an overflow: k_pool)
         if (b == 0) *d_B = (int)gridDim.x;
     }
 }
@@ -1662,7 +1662,7 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
         if (last && shortcut) {
             // only the CLS row of every sequence is read after this layer: gather those rows and finish the layer on B rows (same kernels, same arithmetic per
             // row: the projection loops are bit-identical for every tiling and LayerNorm is per row, so the embedding does not change by one bit)
-            hipLaunchKernelGGL(k_gather_cls, dim3(B), dim3(256), 0, st, e->ctx, e->xb, lo_rw, e->seq_off, e->seq_cls, H, e->c_ctx, e->c_xb, e->c_xlo, e->c_off,
+            hipLaunchKernelGGL(k_gather_cls, dim3(B), dim3(256), 0, st, e->ctx, e->xb, lo_rw, e->seq_off, e->seq_cls, e->seq_nk, H, e->c_ctx, e->c_xb, e->c_xlo, e->c_off,
                                e->c_nk, e->c_cls, e->d_B);
             uint8_t* const c_lo = e->use_lo ? e->c_xlo : nullptr;
             const unsigned c_ln_grid = std::min((unsigned)((B + 3) / 4), (unsigned)e->num_cu * 4u);
