@@ -70,6 +70,19 @@ while time.time() < t_end - budget * 0.35:
             bad = np.nonzero((i0 != i2).any(1) | (s0.view(np.uint32) != s2.view(np.uint32)).any(1))[0]
             why.append(("mode0 != mode2", bad[:5].tolist(), i0[bad[0]][:4].tolist(), i2[bad[0]][:4].tolist(), s0[bad[0]][:4].tolist(), s2[bad[0]][:4].tolist(), ix.stats()))
         ok = ok and ok2
+    if cases % 3 == 0:                                  # several asynchronous searches outstanding on one stream (ABI 5), finished together
+        m = int(rng.integers(2, 5))
+        qs = [torch.roll(q, r, dims=0).contiguous() for r in range(m)]
+        outs_a = [(torch.empty((nq, k), dtype=torch.float32, device="cuda"), torch.empty((nq, k), dtype=torch.int64, device="cuda")) for _ in range(m)]
+        for qq, (sa, ia) in zip(qs, outs_a):
+            ix.search_async(qq, k, sa, ia)
+        fl = ix.finish()
+        oka = len(fl) == m
+        for r, (sa, ia) in enumerate(outs_a):
+            oka = oka and np.array_equal(ia.cpu().numpy(), np.roll(i0, r, axis=0)) and np.array_equal(sa.cpu().numpy().view(np.uint32), np.roll(s0, r, axis=0).view(np.uint32))
+        if not oka:
+            why.append(("outstanding async searches != blocking search", m, fl))
+        ok = ok and oka
     ref = (q[:4] @ x.T).cpu().numpy()                   # independent arithmetic: fp32 matmul scores of the returned rows
     got = np.take_along_axis(ref, i0[:4], axis=1)
     scale = float(np.abs(ref).max()) + 1e-30
