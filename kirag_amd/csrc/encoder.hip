@@ -91,7 +91,8 @@ struct Encoder {
     hipEvent_t ev_done = nullptr;    // recorded after that copy
     bool pending = false;            // an asynchronous forward's error word has not been looked at yet
     hipStream_t last_stream = nullptr;
-    int num_cu = 256;
+    int num_cu = 256;         // CUs the persistent projection grids are sized for
+    int num_cu_all = 256;     // CUs of the device (grids of the memory-bound kernels)
     struct GraphEntryT { uint64_t key; int calls; hipGraphExec_t exec; };
     std::vector<GraphEntryT> graphs;   // captured forwards of small batch shapes (run_forward)
     hipStream_t gstream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -1501,6 +1502,11 @@ int enc_create(const kr_bert_cfg* cfg, int device, int residual_lo, void** out) 
     { const char* v = getenv("KIRAG_AMD_GRAPH"); e->graphs_off = !(v && atoi(v) != 0); }   // opt-in: measured SLOWER than eager launches on ROCm 7.2 (see run_forward)
     { const char* v = getenv("KIRAG_AMD_HPAD"); e->h_pad = v ? (atoi(v) / 8) * 8 : 0; }   // diagnostic (tools/stamp_hpad.py): a row pitch of h that is not a power of two made no difference
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) e->num_cu = (p.multiProcessorCount / 8) * 8; }
+    e->num_cu_all = e->num_cu;
+#ifdef KR_EXPERIMENT
+    // experiment (profiles/r04/tried_cu_split.txt): persistent projection grids on a SUBSET of the CUs, so that a search running on another stream keeps the rest
+    { const char* v = getenv("KIRAG_AMD_ENC_CUS"); if (v && atoi(v) >= 8) e->num_cu = std::min(e->num_cu, (atoi(v) / 8) * 8); }
+#endif
     e->L.resize(cfg->layers);
     e->got.assign(T_LAYER0 + (size_t)cfg->layers * L_COUNT, 0);
     const size_t H = cfg->hidden, FF = cfg->intermediate;
@@ -1637,7 +1643,7 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
                        e->tok_pos, e->d_err);
     const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + align - 1) & ~(align - 1));   // upper bound of the packed token count (each sequence is padded to `align`)
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
-    const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu * 4u);   // k_ln is grid-stride (its parameters stay in registers across rows)
+    const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu_all * 4u);   // k_ln is grid-stride (its parameters stay in registers across rows)
     auto ln_kernel = H <= 512 ? &k_ln16<1> : H <= 1024 ? &k_ln16<2> : &k_ln16<4>;
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->use_lo ? e->xlo : nullptr, e->xb);
@@ -1665,7 +1671,7 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
             hipLaunchKernelGGL(k_gather_cls, dim3(B), dim3(256), 0, st, e->ctx, e->xb, lo_rw, e->seq_off, e->seq_cls, e->seq_nk, H, e->c_ctx, e->c_xb, e->c_xlo, e->c_off,
                                e->c_nk, e->c_cls, e->d_B);
             uint8_t* const c_lo = e->use_lo ? e->c_xlo : nullptr;
-            const unsigned c_ln_grid = std::min((unsigned)((B + 3) / 4), (unsigned)e->num_cu * 4u);
+            const unsigned c_ln_grid = std::min((unsigned)((B + 3) / 4), (unsigned)e->num_cu_all * 4u);
             a.Tp = e->d_B;
             a.W = l.wo; a.X = e->c_ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->c_y; a.ldx = 0; a.ldo = 0;
             KR_TRY(launch_proj(EPI_DENSE, a, B, e->num_cu, e->device, st));

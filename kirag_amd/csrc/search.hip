@@ -1650,6 +1650,9 @@ int kr_index_create(int d, int metric, int coarse_dtype, int device, kr_index** 
     Index* ix = new Index();
     ix->d = d; ix->dpad = (int)round_up(d, 64); ix->coarse = coarse_dtype; ix->device = device;
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) ix->num_cu = (p.multiProcessorCount / 8) * 8; }
+#ifdef KR_EXPERIMENT
+    { const char* v = getenv("KIRAG_AMD_IDX_CUS"); if (v && atoi(v) >= 8) ix->num_cu = std::min(ix->num_cu, (atoi(v) / 8) * 8); }   // see encoder.hip: KIRAG_AMD_ENC_CUS
+#endif
     hipError_t e = hipMalloc(&ix->bounds, 2 * sizeof(float));
     if (e != hipSuccess) { delete ix; return fail(KR_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
     (void)hipMemset(ix->bounds, 0, 2 * sizeof(float));

@@ -42,6 +42,33 @@ def _worker(rank, world, port, ret):
         s2, i2 = ShardedSearcher(Small(), row_offset=0 if rank == 0 else 5, world=world).search(torch.from_numpy(q), 8)
         so2, io2 = S.search_canonical(q, x[:605], 8)
         assert np.array_equal(i2, io2) and np.array_equal(s2, so2)
+        # ShardedIndexer.search_knn: the "did any rank append rows?" decision is collective but rides behind the first batch's search (no round trip of
+        # its own); a rank with an EMPTY share (never dirty itself) must still take part, and a later search must not assemble again
+        from kirag_amd.retriever.index import ShardedIndexer
+
+        class Rows:                                              # oracle-backed stand-in for FlatIPIndex (host queries, gloo: the CPU exchange path)
+            def __init__(self): self.x = np.empty((0, 32), np.float32); self.device = 0
+            @property
+            def ntotal(self): return len(self.x)
+            def add(self, e): self.x = np.concatenate([self.x, np.asarray(e, np.float32)])
+            def search(self, qq, k): return S.search_canonical(np.asarray(qq), self.x, k)
+        sx = ShardedIndexer.__new__(ShardedIndexer)
+        sx.group, sx.rank, sx.world, sx.faiss_padding = None, rank, world, False
+        sx.index, sx.index_id_to_db_id = Rows(), np.empty((0), dtype=np.int64)
+        sx.row_offset, sx.ntotal_global, sx._local_ids, sx._dirty = 0, 0, [], False
+        if rank == 1:                                            # rank 0's share of the streamed build is empty
+            sx.index_data([str(7 * j + 1) for j in range(len(x))], x)
+        calls = []
+        orig = sx._assemble
+        sx._assemble = lambda: (calls.append(1), orig())[1]
+        res = sx.search_knn(q, 20, index_batch_size=4)          # three batches: the decision is taken behind the first one
+        assert len(calls) == 1 and sx.ntotal_global == len(x) and sx.row_offset == 0
+        for j, (ids, sc) in enumerate(res):
+            assert ids == [str(7 * int(r) + 1) for r in io[j]] and np.array_equal(np.asarray(sc), so[j])
+        res2 = sx.search_knn(q[:3], 5)                           # nothing appended since: no second assembly, optimistic search kept
+        assert len(calls) == 1 and [r[0] for r in res2] == [[str(7 * int(r) + 1) for r in io[j][:5]] for j in range(3)]
+        with pytest.raises(ValueError):
+            sx.search_knn(q[:2], len(x) + 1)
         # in-batch helpers
         emb = torch.full((2, 4), float(rank), requires_grad=True)
         g = U.get_global_embeddings_for_inbatchtraining(rank, world, emb)
