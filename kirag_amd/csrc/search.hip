@@ -393,7 +393,7 @@ __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
             }
         };
     if constexpr (SMALLQ) gemm_nt_split<T, false>(a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem, coord, epi);
-    else gemm_nt_pingpong<T, false, true>(a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem, coord, epi);
+    else gemm_nt_pingpong<T, false, EPIV != 4>(a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem, coord, epi);   // EPIV 4 (experiment): corpus loads with the default cache policy
     if constexpr (!DIRECT) scatter_wave_lists(a, smem, wave_id, wcnt, ShapeC::NTHREADS);
 }
 
@@ -1340,6 +1340,7 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
 #endif
         return 0;
     }));
@@ -1355,6 +1356,7 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
         else if (ix->epiv == 1) hipLaunchKernelGGL((k_coarse<T, false, false, 1>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
         else if (ix->epiv == 2) hipLaunchKernelGGL((k_coarse<T, false, false, 2>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
         else if (ix->epiv == 3) hipLaunchKernelGGL((k_coarse<T, false, false, 3>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
+        else if (ix->epiv == 4) hipLaunchKernelGGL((k_coarse<T, false, false, 4>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
 #endif
         else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
         return 0;
