@@ -55,10 +55,10 @@ using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LD
 using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB ring, two blocks per CU: for launches with too few 256x256 tiles to fill the chip
 
 // all main loops run with exchanged MFMA operands (accumulators hold 4 consecutive features per lane)
-template <class ShapeE, int STAGES, class Coord, class Epilogue>
+template <class ShapeE, int STAGES, bool ANT = false, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_main(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb, int64_t N,
                                           int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
-    if constexpr (ShapeE::BM == 256 && ShapeE::BN == 256) gemm_nt_pingpong<ET, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
+    if constexpr (ShapeE::BM == 256 && ShapeE::BN == 256) gemm_nt_pingpong<ET, true, ANT>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
     else gemm_nt_stream<ET, ShapeE, STAGES, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
 }
 
@@ -414,6 +414,7 @@ struct ProjArgs {
     int64_t ldx, ldo;   // row pitch (elements) of X and of out0 (EPI_DENSE / EPI_GELU); 0 = K / F
     int pw;   // feature tiles per XCD patch of the tile walk (patch_coord)
     int epi_prio;   // A/B knob, see proj_epilogue
+    int ant;  // experiment builds: activation loads non-temporal (FF2's h)
     int nt;   // epilogue stores non-temporal (large launches: the output is consumed from HBM by the next kernel, keep it out of L2) or plain
               // (small launches: the whole output fits in L2 / Infinity Cache, the next kernel reads it from there)
 };
@@ -569,13 +570,14 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>
     if (a.epi_prio) __builtin_amdgcn_s_setprio(0);
 }
 
-template <int EPI, class ShapeE, int STAGES, bool NT>
+// ANT (experiment builds only): the activation operand is loaded non-temporally (profiles/r04/tried_nt_activations.txt)
+template <int EPI, class ShapeE, int STAGES, bool NT, bool ANT = false>
 __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = *a.Tp;
     const int64_t tm_count = (T + ShapeE::BM - 1) / ShapeE::BM, tn_count = (a.F + ShapeE::BN - 1) / ShapeE::BN;
     char* stage = smem + STAGES * ShapeE::STAGE_BYTES + (threadIdx.x >> 6) * EPI_STAGE_BYTES;
-    gemm_main<ShapeE, STAGES>(
+    gemm_main<ShapeE, STAGES, ANT>(
         a.X, a.ldx, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
             int64_t tm, tn;
@@ -873,7 +875,7 @@ constexpr bool ALDS_PF = ALDS_PF_N != 0;                   // fragment prefetch 
 // HPB = heads per block: 1 when a sequence has >= 3 q-tiles, 2 / 4 for short sequences so that all four waves have work.
 // __launch_bounds__(256, 3): at most 168 registers per lane, which makes hipcc keep the MFMA accumulators in VGPRs; with the default bound it put
 // them in AGPRs and spent 112 of the 276 VALU instructions of a key tile on v_accvgpr_read / _write around the softmax rescale
-template <int HPB>
+template <int HPB, bool NTL = false>   // NTL (experiment builds only): q / k / v loaded non-temporally
 __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vT, int64_t ldv,
                                                   const int* __restrict__ seq_off, const int* __restrict__ seq_nk, const int* __restrict__ seq_nq,
                                                   int H, int heads, int kchunk, uint16_t* __restrict__ ctx) {
@@ -903,7 +905,8 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
         const int qi = (q0 + c < nq) ? (q0 + c) : (nq - 1);
         const uint16_t* qrow = q + (off + qi) * H + head * 64;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(qrow + 16 * s + 8 * hf);
+        for (int s = 0; s < 4; ++s) qf[s] = NTL ? __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(qrow + 16 * s + 8 * hf)))
+                                                : *reinterpret_cast<const uint4*>(qrow + 16 * s + 8 * hf);
     }
     AttnState st;
     attn_init(st);
@@ -932,7 +935,10 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
                         const int i = base + j * 256 + tid;
                         const int key = i >> 3, ch = i & 7;
                         kv[h2][j] = make_uint4(0u, 0u, 0u, 0u);
-                        if (head2 < heads && i < nkcs && key < nkc) kv[h2][j] = *reinterpret_cast<const uint4*>(k + (off + kc0 + key) * H + head2 * 64 + ch * 8);
+                        if (head2 < heads && i < nkcs && key < nkc) {
+                            const uint16_t* kp = k + (off + kc0 + key) * H + head2 * 64 + ch * 8;
+                            kv[h2][j] = NTL ? __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kp))) : *reinterpret_cast<const uint4*>(kp);
+                        }
                     }
                 }
                 // (d row, 8-byte chunk) of element i of the V^T staging: i / cpr and i % cpr (exact: i < 2^16, cpr <= 128); recomputed where needed (two VALU
@@ -946,8 +952,11 @@ __global__ __launch_bounds__(256, 3) void k_attn_lds(const uint16_t* __restrict_
                         const int i = base + j * 256 + tid;
                         int vd, vk; vsplit(i, vd, vk);
                         vv[h2][j] = make_uint2(0u, 0u);
-                        if (head2 < heads && i < nvc && vk * 4 < nkc)
-                            vv[h2][j] = *reinterpret_cast<const uint2*>(vT + (int64_t)(head2 * 64 + vd) * ldv + off + kc0 + vk * 4);   // off, kc0 % 4 == 0: 8-B aligned
+                        if (head2 < heads && i < nvc && vk * 4 < nkc) {
+                            const uint16_t* vp = vT + (int64_t)(head2 * 64 + vd) * ldv + off + kc0 + vk * 4;   // off, kc0 % 4 == 0: 8-B aligned
+                            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+                            vv[h2][j] = NTL ? __builtin_bit_cast(uint2, __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(vp))) : *reinterpret_cast<const uint2*>(vp);
+                        }
                     }
                 }
 #pragma unroll
@@ -1375,6 +1384,16 @@ static int launch_attn(const Encoder* e, int B, int cap, int nqt, hipStream_t st
         attr_lds = lds;
     }
     const int qgroups = (nqt + (4 / HPB) - 1) / (4 / HPB);   // blocks per (sequence, head group): 4 / HPB q-tiles each
+#ifdef KR_EXPERIMENT
+    { const char* v = getenv("KIRAG_AMD_NT_QKV");
+      if (v && atoi(v)) {
+          static int attr2[64] = {};
+          if (lds > attr2[e->device & 63]) { KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_lds<HPB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr2[e->device & 63] = lds; }
+          hipLaunchKernelGGL((k_attn_lds<HPB, true>), dim3((unsigned)((heads + HPB - 1) / HPB), (unsigned)B, (unsigned)qgroups), dim3(256), lds, st, e->q, e->k, e->vT,
+                             e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, kchunk, e->ctx);
+          return 0;
+      } }
+#endif
     hipLaunchKernelGGL((k_attn_lds<HPB>), dim3((unsigned)((heads + HPB - 1) / HPB), (unsigned)B, (unsigned)qgroups), dim3(256), lds, st, e->q, e->k, e->vT,
                        e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, kchunk, e->ctx);
     return 0;
@@ -1409,6 +1428,14 @@ static int launch_proj_shape_nt(int epi, const ProjArgs& a, int blocks, int devi
 #ifdef KR_STAMP
     { const char* r = getenv("KIRAG_AMD_DEBUG_REPEAT"); if (r) repeat = atoi(r); }   // diagnostic: the same launch again (warm instruction cache?)
 #endif
+#ifdef KR_EXPERIMENT
+    if (a.ant && epi == EPI_DENSE && Shape::BM == 256) {
+        static bool set_ant[64] = {};
+        if (!set_ant[device & 63]) { KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_DENSE, Shape, STAGES, NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); set_ant[device & 63] = true; }
+        hipLaunchKernelGGL((k_proj<EPI_DENSE, Shape, STAGES, NT, true>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
+        return 0;
+    }
+#endif
     for (int rep = 0; rep < repeat; ++rep) {
         if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj<EPI_QKV, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
         else if (epi == EPI_DENSE) hipLaunchKernelGGL((k_proj<EPI_DENSE, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
@@ -1433,6 +1460,9 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int nu
         const char* se = getenv("KIRAG_AMD_STORE_NT");
         a.nt = se ? atoi(se) : (max_tokens * (int64_t)a.F * 2 > ((int64_t)96 << 20) ? 1 : 0);
     }
+#ifdef KR_EXPERIMENT
+    { const char* v = getenv("KIRAG_AMD_NT_H"); a.ant = (v && atoi(v) && a.K > a.H) ? 1 : 0; }   // FF2 only: its activation operand h is the 256-MiB once-read stream
+#endif
     const int64_t big_tiles = ((max_tokens + 255) / 256) * ((a.F + 255) / 256);
     const int64_t small_tiles = ((max_tokens + 127) / 128) * ((a.F + 127) / 128);
     const char* fe = getenv("KIRAG_AMD_PROJ_TILE");   // 128 / 256 force a path (tests run every parity case through both); read per call
