@@ -414,7 +414,7 @@ struct ProjArgs {
     int64_t ldx, ldo;   // row pitch (elements) of X and of out0 (EPI_DENSE / EPI_GELU); 0 = K / F
     int pw;   // feature tiles per XCD patch of the tile walk (patch_coord)
     int epi_prio;   // A/B knob, see proj_epilogue
-    int ant;  // experiment builds: activation loads non-temporal (FF2's h)
+    int ant;  // activation loads non-temporal (FF2's h: launch_proj)
     int nt;   // epilogue stores non-temporal (large launches: the output is consumed from HBM by the next kernel, keep it out of L2) or plain
               // (small launches: the whole output fits in L2 / Infinity Cache, the next kernel reads it from there)
 };
@@ -570,7 +570,7 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>
     if (a.epi_prio) __builtin_amdgcn_s_setprio(0);
 }
 
-// ANT (experiment builds only): the activation operand is loaded non-temporally (profiles/r04/tried_nt_activations.txt)
+// ANT: the activation operand is loaded non-temporally (FF2's h: launch_proj)
 template <int EPI, class ShapeE, int STAGES, bool NT, bool ANT = false>
 __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1428,14 +1428,12 @@ static int launch_proj_shape_nt(int epi, const ProjArgs& a, int blocks, int devi
 #ifdef KR_STAMP
     { const char* r = getenv("KIRAG_AMD_DEBUG_REPEAT"); if (r) repeat = atoi(r); }   // diagnostic: the same launch again (warm instruction cache?)
 #endif
-#ifdef KR_EXPERIMENT
     if (a.ant && epi == EPI_DENSE && Shape::BM == 256) {
         static bool set_ant[64] = {};
         if (!set_ant[device & 63]) { KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<EPI_DENSE, Shape, STAGES, NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); set_ant[device & 63] = true; }
         hipLaunchKernelGGL((k_proj<EPI_DENSE, Shape, STAGES, NT, true>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
         return 0;
     }
-#endif
     for (int rep = 0; rep < repeat; ++rep) {
         if (epi == EPI_QKV) hipLaunchKernelGGL((k_proj<EPI_QKV, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
         else if (epi == EPI_DENSE) hipLaunchKernelGGL((k_proj<EPI_DENSE, Shape, STAGES, NT>), dim3(blocks), dim3(Shape::NTHREADS), lds, st, a);
@@ -1460,9 +1458,10 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int nu
         const char* se = getenv("KIRAG_AMD_STORE_NT");
         a.nt = se ? atoi(se) : (max_tokens * (int64_t)a.F * 2 > ((int64_t)96 << 20) ? 1 : 0);
     }
-#ifdef KR_EXPERIMENT
-    { const char* v = getenv("KIRAG_AMD_NT_H"); a.ant = (v && atoi(v) && a.K > a.H) ? 1 : 0; }   // FF2 only: its activation operand h is the 256-MiB once-read stream
-#endif
+    // FF2 (K = FF > H): its activation operand h is a once-through stream four times the size of every other activation (256 MiB at 32 k tokens); loaded
+    // non-temporally it leaves the L2 / Infinity Cache to the weights and to the residual stream the LayerNorm behind it reads: -0.7 % forward time at
+    // 1000 x 32 tokens, neutral elsewhere (profiles/r04/tried_nt_activations.txt; outputs bit-identical).  KIRAG_AMD_NT_H=0 switches it off (A/B).
+    { const char* v = getenv("KIRAG_AMD_NT_H"); a.ant = (a.K > a.H && !(v && atoi(v) == 0)) ? 1 : 0; }
     const int64_t big_tiles = ((max_tokens + 255) / 256) * ((a.F + 255) / 256);
     const int64_t small_tiles = ((max_tokens + 127) / 128) * ((a.F + 127) / 128);
     const char* fe = getenv("KIRAG_AMD_PROJ_TILE");   // 128 / 256 force a path (tests run every parity case through both); read per call
