@@ -194,6 +194,7 @@ __global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ 
 }
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 // two floats -> packed 16-bit pair (lo in bits 0..15), round-to-nearest-even, NaN stays NaN: ONE v_cvt_pk_bf16_f32 / the f16 conversions of the target
@@ -310,9 +311,12 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id
 // 8-byte ones: 8-byte accesses reach 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md).  NS 512-element steps cover a row (H <= 512 NS, H % 8 == 0).
 // Same arithmetic per element as k_ln; the row sums add the elements in a different lane order (tolerances of DESIGN.md section 2 unaffected; rows stay
 // independent of the batch).  KIRAG_AMD_LN8=1 selects the 8-byte kernel (A/B).
-template <int NS>
+// POL (cache policy of the streams; profiles/r04/tried_ln_policies.txt): bit 0 = y loaded non-temporally (dead after this kernel), bit 1 = the low half loaded
+// non-temporally, bit 2 = the low half stored non-temporally (its next reader is the next LayerNorm, ~600 MiB of traffic later)
+template <int NS, int POL = 0>
 __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, const float* __restrict__ ybias, const int* __restrict__ Tp, const float* __restrict__ g,
                                               const float* __restrict__ bta, float eps, int H, const uint8_t* xlo_in, uint8_t* xlo, uint16_t* xb) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
     const int lane = threadIdx.x & 63;
     const int T = *Tp;
     float gg[NS][8], bb[NS][8], yb[NS][8];
@@ -340,9 +344,9 @@ __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, co
             const int i = lane * 8 + j * 512;
             a[j] = rh[j] = make_uint4(0u, 0u, 0u, 0u); rl[j] = make_uint2(0x80808080u, 0x80808080u);      // byte 128 = a zero low half
             if (i < H && row < T) {
-                a[j] = *reinterpret_cast<const uint4*>(y + row * H + i);
+                a[j] = (POL & 1) ? __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(y + row * H + i))) : *reinterpret_cast<const uint4*>(y + row * H + i);
                 rh[j] = *reinterpret_cast<const uint4*>(xb + row * H + i);
-                if (xlo_in) rl[j] = *reinterpret_cast<const uint2*>(xlo_in + row * H + i);
+                if (xlo_in) rl[j] = (POL & 2) ? __builtin_bit_cast(uint2, __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(xlo_in + row * H + i))) : *reinterpret_cast<const uint2*>(xlo_in + row * H + i);
             }
         }
     };
@@ -397,7 +401,8 @@ __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, co
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         ol[c >> 1] |= (lo_encode(o[2 * c], lo16(ob[c])) | (lo_encode(o[2 * c + 1], hi16(ob[c])) << 8)) << (16 * (c & 1));
-                    *reinterpret_cast<uint2*>(xlo_row + i) = make_uint2(ol[0], ol[1]);
+                    if (POL & 4) __builtin_nontemporal_store(u32x2_t{ol[0], ol[1]}, reinterpret_cast<u32x2_t*>(xlo_row + i));
+                    else *reinterpret_cast<uint2*>(xlo_row + i) = make_uint2(ol[0], ol[1]);
                 }
             }
         }
@@ -448,7 +453,6 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
 //   V^T:   each 32x32 tile is written TRANSPOSED ([feature][token], 4 consecutive tokens of a lane packed into 8 B, 80-B rows) and
 //          read back 16 B per lane: a store instruction writes 64-B runs of sixteen V^T rows.
 constexpr int EPI_STAGE_BYTES = 4096;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // Both helpers take the SWAPPED accumulator layout of gemm_nt_pingpong / gemm_nt_split / gemm_nt_stream / gemm_nt_skinny with SWAP = true: tile (mi, ni), register r,
 // lane (c = l & 31, h = l >> 5) is token mi*32 + c, feature ni*32 + (r & 3) + 8 (r >> 2) + 4 h of the wave's (TM*32 tokens) x (TN*32 features).
@@ -1462,6 +1466,9 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int nu
     // non-temporally it leaves the L2 / Infinity Cache to the weights and to the residual stream the LayerNorm behind it reads: -0.7 % forward time at
     // 1000 x 32 tokens, neutral elsewhere (profiles/r04/tried_nt_activations.txt; outputs bit-identical).  KIRAG_AMD_NT_H=0 switches it off (A/B).
     { const char* v = getenv("KIRAG_AMD_NT_H"); a.ant = (a.K > a.H && !(v && atoi(v) == 0)) ? 1 : 0; }
+#ifdef KR_EXPERIMENT
+    { const char* v = getenv("KIRAG_AMD_NT_CTX"); if (v && atoi(v) && epi == EPI_DENSE && a.K == a.H) a.ant = 1; }   // the attention output read by the out-projection
+#endif
     const int64_t big_tiles = ((max_tokens + 255) / 256) * ((a.F + 255) / 256);
     const int64_t small_tiles = ((max_tokens + 127) / 128) * ((a.F + 127) / 128);
     const char* fe = getenv("KIRAG_AMD_PROJ_TILE");   // 128 / 256 force a path (tests run every parity case through both); read per call
@@ -1672,8 +1679,14 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
                        e->tok_pos, e->d_err);
     const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + align - 1) & ~(align - 1));   // upper bound of the packed token count (each sequence is padded to `align`)
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
-    const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu_all * 4u);   // k_ln is grid-stride (its parameters stay in registers across rows)
     auto ln_kernel = H <= 512 ? &k_ln16<1> : H <= 1024 ? &k_ln16<2> : &k_ln16<4>;
+    unsigned ln_mult = 4u;
+#ifdef KR_EXPERIMENT
+    { const char* v = getenv("KIRAG_AMD_LN_POL"); const int pol = v ? atoi(v) : 0;
+      if (H > 512 && H <= 1024) ln_kernel = pol == 1 ? &k_ln16<2, 1> : pol == 3 ? &k_ln16<2, 3> : pol == 5 ? &k_ln16<2, 5> : pol == 7 ? &k_ln16<2, 7> : pol == 6 ? &k_ln16<2, 6> : ln_kernel;
+      const char* g = getenv("KIRAG_AMD_LN_GRID"); if (g && atoi(g) > 0) ln_mult = (unsigned)atoi(g); }
+#endif
+    const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu_all * ln_mult);   // k_ln is grid-stride (its parameters stay in registers across rows)
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->use_lo ? e->xlo : nullptr, e->xb);
     uint8_t* const lo_rw = e->use_lo ? e->xlo : nullptr;       // low half read / written by the inner LayerNorms

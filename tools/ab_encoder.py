@@ -11,6 +11,8 @@ vals = vals.split(",")
 dev = torch.device("cuda:0")
 enc = BS.make_hip_encoder(dev)
 shapes = [(1, 32), (2, 256), (4, 64), (8, 128), (32, 32), (100, 32)] if os.environ.get("AB_TINY") else [(125, 32), (150, 32), (250, 32), (64, 64), (32, 128), (1000, 32)] if os.environ.get("AB_SMALL") else [(125, 32), (250, 32), (1000, 32), (8, 128), (1024, 128), (128, 512)]
+if os.environ.get("AB_SHAPES"):       # e.g. AB_SHAPES=1000x32,1024x128
+    shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["AB_SHAPES"].split(",")]
 for B, S in shapes:
     ids, mask = BS.synthetic_tokens(dev, B, S, seed=1)
     res = {v: [] for v in vals}
