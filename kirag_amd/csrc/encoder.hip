@@ -1679,11 +1679,14 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
                        e->tok_pos, e->d_err);
     const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + align - 1) & ~(align - 1));   // upper bound of the packed token count (each sequence is padded to `align`)
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
-    auto ln_kernel = H <= 512 ? &k_ln16<1> : H <= 1024 ? &k_ln16<2> : &k_ln16<4>;
-    unsigned ln_mult = 4u;
+    // LayerNorm streams: y (dead after the kernel) and the low half (next read by the next LayerNorm, ~600 MiB of traffic later) are loaded / stored
+    // non-temporally — they do not displace the 16-bit stream the next GEMM reads: -1.3 % forward at 1024 x 128 tokens, -0.1...0.5 % at 1000 x 32; 8 blocks
+    // per CU instead of 4: -0.25 % (profiles/r04/tried_ln_policies.txt; outputs bit-identical)
+    auto ln_kernel = H <= 512 ? &k_ln16<1, 7> : H <= 1024 ? &k_ln16<2, 7> : &k_ln16<4, 7>;
+    unsigned ln_mult = 8u;
 #ifdef KR_EXPERIMENT
-    { const char* v = getenv("KIRAG_AMD_LN_POL"); const int pol = v ? atoi(v) : 0;
-      if (H > 512 && H <= 1024) ln_kernel = pol == 1 ? &k_ln16<2, 1> : pol == 3 ? &k_ln16<2, 3> : pol == 5 ? &k_ln16<2, 5> : pol == 7 ? &k_ln16<2, 7> : pol == 6 ? &k_ln16<2, 6> : ln_kernel;
+    { const char* v = getenv("KIRAG_AMD_LN_POL"); const int pol = v ? atoi(v) : 7;
+      if (H > 512 && H <= 1024) ln_kernel = pol == 0 ? &k_ln16<2, 0> : pol == 1 ? &k_ln16<2, 1> : pol == 3 ? &k_ln16<2, 3> : pol == 5 ? &k_ln16<2, 5> : pol == 6 ? &k_ln16<2, 6> : ln_kernel;
       const char* g = getenv("KIRAG_AMD_LN_GRID"); if (g && atoi(g) > 0) ln_mult = (unsigned)atoi(g); }
 #endif
     const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu_all * ln_mult);   // k_ln is grid-stride (its parameters stay in registers across rows)
@@ -1713,7 +1716,7 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
             hipLaunchKernelGGL(k_gather_cls, dim3(B), dim3(256), 0, st, e->ctx, e->xb, lo_rw, e->seq_off, e->seq_cls, e->seq_nk, H, e->c_ctx, e->c_xb, e->c_xlo, e->c_off,
                                e->c_nk, e->c_cls, e->d_B);
             uint8_t* const c_lo = e->use_lo ? e->c_xlo : nullptr;
-            const unsigned c_ln_grid = std::min((unsigned)((B + 3) / 4), (unsigned)e->num_cu_all * 4u);
+            const unsigned c_ln_grid = std::min((unsigned)((B + 3) / 4), (unsigned)e->num_cu_all * ln_mult);
             a.Tp = e->d_B;
             a.W = l.wo; a.X = e->c_ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->c_y; a.ldx = 0; a.ldo = 0;
             KR_TRY(launch_proj(EPI_DENSE, a, B, e->num_cu, e->device, st));
