@@ -1461,6 +1461,10 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int nu
     {   // store policy by output size (see ProjArgs::nt); KIRAG_AMD_STORE_NT = 0 / 1 forces it (A/B measurements)
         const char* se = getenv("KIRAG_AMD_STORE_NT");
         a.nt = se ? atoi(se) : (max_tokens * (int64_t)a.F * 2 > ((int64_t)96 << 20) ? 1 : 0);
+#ifdef KR_EXPERIMENT
+        const char* qe = getenv("KIRAG_AMD_QKV_NT");   // the q / k / v^T stores alone (three arrays of T x H: read back by the attention kernel right away)
+        if (qe && epi == EPI_QKV) a.nt = atoi(qe);
+#endif
     }
     // FF2 (K = FF > H): its activation operand h is a once-through stream four times the size of every other activation (256 MiB at 32 k tokens); loaded
     // non-temporally it leaves the L2 / Infinity Cache to the weights and to the residual stream the LayerNorm behind it reads: -0.7 % forward time at
