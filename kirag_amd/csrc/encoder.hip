@@ -419,6 +419,7 @@ struct ProjArgs {
     int64_t ldx, ldo;   // row pitch (elements) of X and of out0 (EPI_DENSE / EPI_GELU); 0 = K / F
     int pw;   // feature tiles per XCD patch of the tile walk (patch_coord)
     int epi_prio;   // A/B knob, see proj_epilogue
+    int skip_from;  // experiment builds: first token block (of 4) whose global stores are skipped (99 = none)
     int ant;  // activation loads non-temporal (FF2's h: launch_proj)
     int nt;   // epilogue stores non-temporal (large launches: the output is consumed from HBM by the next kernel, keep it out of L2) or plain
               // (small launches: the whole output fits in L2 / Infinity Cache, the next kernel reads it from there)
@@ -461,7 +462,7 @@ constexpr int EPI_STAGE_BYTES = 4096;
 // consecutive features -> one packed ds_write_b64 (16-B chunk index XOR (token & 7): 2-way instead of 16-way conflicts), read back 16 B
 // per lane: every global store instruction writes eight whole 128-B rows.  f(v, ni, g) maps 4 features (bias / GELU) before packing.
 template <class Shape, bool NT, class F>
-__device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ out, int64_t ld, int64_t row0, int col0, F&& f) {
+__device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ out, int64_t ld, int64_t row0, int col0, F&& f, int skip_from = 99) {
     static_assert(Shape::TN == 2, "stage geometry assumes 64 features per wave");
     const int c = acc.lane & 31, h = acc.lane >> 5;
     const int r8 = acc.lane >> 3, ch = acc.lane & 7;
@@ -489,6 +490,9 @@ __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage
 #pragma unroll
             for (int p = 0; p < 4; ++p) d[mi & 1][p] = *reinterpret_cast<const uint4*>(st_rd + p * 8 * 128);
         }
+#ifdef KR_EXPERIMENT
+        if (mi > 0 && mi - 1 >= skip_from) continue;   // diagnostic (wrong output): the global stores of the later token blocks are skipped — what would trickling them buy?
+#endif
         if (mi > 0) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {  // rl & 7 == lane >> 3 for every p: one lane-dependent LDS / global base, the rest are wave-uniform steps (8 rows per store)
@@ -560,16 +564,16 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>
             store_transposed_bf16<ShapeE, NT>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H);   // value bias lives in bo_eff
         } else {
             store_rows_bf16<ShapeE, NT>(acc, stage, region ? a.out1 : a.out0, a.H, t0, f0 - region * a.H,
-                                    [&](f32x4 v, int ni, int g) { return v + b[ni][g]; });
+                                    [&](f32x4 v, int ni, int g) { return v + b[ni][g]; }, a.skip_from);
         }
     } else if constexpr (EPI == EPI_DENSE) {
-        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.ldo, t0, f0, [&](f32x4 v, int, int) { return v; });   // the bias is added in k_ln (fp32)
+        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.ldo, t0, f0, [&](f32x4 v, int, int) { return v; }, a.skip_from);   // the bias is added in k_ln (fp32)
     } else {
         store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.ldo, t0, f0, [&](f32x4 v, int ni, int g) {
             const f32x4 x = v + b[ni][g];
             const f32x2 lo = gelu_erf_fast2(f32x2{x.x, x.y}), hi = gelu_erf_fast2(f32x2{x.z, x.w});
             return f32x4{lo.x, lo.y, hi.x, hi.y};
-        });
+        }, a.skip_from);
     }
     if (a.epi_prio) __builtin_amdgcn_s_setprio(0);
 }
@@ -1457,7 +1461,11 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int nu
     if (a.ldx == 0) a.ldx = a.K;
     if (a.ldo == 0) a.ldo = a.F;
     { const char* pe = getenv("KIRAG_AMD_PATCH_W"); a.pw = pe ? atoi(pe) : 8; if (a.pw < 1) a.pw = 8; }
-    { const char* pe = getenv("KIRAG_AMD_EPI_PRIO"); a.epi_prio = pe ? atoi(pe) : 0; }   // A/B knob (profiles/r03): feature tiles per XCD patch
+    { const char* pe = getenv("KIRAG_AMD_EPI_PRIO"); a.epi_prio = pe ? atoi(pe) : 0; }
+    a.skip_from = 99;
+#ifdef KR_EXPERIMENT
+    { const char* pe = getenv("KIRAG_AMD_SKIP_STORES_FROM"); if (pe) a.skip_from = atoi(pe); }
+#endif   // A/B knob (profiles/r03): feature tiles per XCD patch
     {   // store policy by output size (see ProjArgs::nt); KIRAG_AMD_STORE_NT = 0 / 1 forces it (A/B measurements)
         const char* se = getenv("KIRAG_AMD_STORE_NT");
         a.nt = se ? atoi(se) : (max_tokens * (int64_t)a.F * 2 > ((int64_t)96 << 20) ? 1 : 0);
