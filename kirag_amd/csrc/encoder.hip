@@ -55,10 +55,10 @@ using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LD
 using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB ring, two blocks per CU: for launches with too few 256x256 tiles to fill the chip
 
 // all main loops run with exchanged MFMA operands (accumulators hold 4 consecutive features per lane)
-template <class ShapeE, int STAGES, bool ANT = false, class Coord, class Epilogue, class Trickle>
+template <class ShapeE, int STAGES, bool ANT = false, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_main(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb, int64_t N,
-                                          int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi, Trickle& trickle) {
-    if constexpr (ShapeE::BM == 256 && ShapeE::BN == 256) gemm_nt_pingpong<ET, true, ANT>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi, trickle);
+                                          int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
+    if constexpr (ShapeE::BM == 256 && ShapeE::BN == 256) gemm_nt_pingpong<ET, true, ANT>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
     else gemm_nt_stream<ET, ShapeE, STAGES, true>(A, lda, M, B, ldb, N, K, total_tiles, smem, coord, epi);
 }
 
@@ -419,7 +419,6 @@ struct ProjArgs {
     int64_t ldx, ldo;   // row pitch (elements) of X and of out0 (EPI_DENSE / EPI_GELU); 0 = K / F
     int pw;   // feature tiles per XCD patch of the tile walk (patch_coord)
     int epi_prio;   // A/B knob, see proj_epilogue
-    int trickle;    // 256x256 dense / GELU projections: the stores of a wave's last two token blocks are trickled into the next tile (KIRAG_AMD_TRICKLE=0: off)
     int skip_from;  // experiment builds: first token block (of 4) whose global stores are skipped (99 = none)
     int ant;  // activation loads non-temporal (FF2's h: launch_proj)
     int nt;   // epilogue stores non-temporal (large launches: the output is consumed from HBM by the next kernel, keep it out of L2) or plain
@@ -456,66 +455,23 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
 //          read back 16 B per lane: a store instruction writes 64-B runs of sixteen V^T rows.
 constexpr int EPI_STAGE_BYTES = 4096;
 
-// Trickled epilogue stores of the 256x256 projections (gemm_nt.hpp: "Trickled epilogue stores"): the row stores of a wave's LAST TWO 32-token blocks are not
-// issued in the epilogue; their data — the epilogue's own 2 x 16-register double buffer — stays live and the main loop issues them one per interval during the
-// first four K-tiles of the next output tile, as buffer stores (scalar resource + scalar row offset + one constant lane offset: no VALU).  Measured upper bound
-// of the idea (those stores skipped outright): -3.8 % forward at 1000 x 32 tokens (profiles/r04/tried_store_trickle_upper_bound.txt).
-template <bool NT>
-struct PendingStores {
-    static constexpr bool enabled = true;
-    uint4 d[2][4];                   // d[0] = token block 2, d[1] = token block 3 of the wave's four (row chunk p = 0..3: rows 8 p + (lane >> 3))
-    __amdgpu_buffer_rsrc_t rs;       // base: element (first token of the wave's 128 x 64 block, its first feature) of the output
-    uint32_t voff = 0, ld2 = 0;      // lane part of the address ((lane >> 3) rows + 8 (lane & 7) elements), row pitch in bytes
-    bool on = false, can_ = false;   // wave-uniform: stores pending; the K loop is long enough to carry them (>= 4 K-tiles)
-    __device__ __forceinline__ bool armed() const { return on; }
-    __device__ __forceinline__ bool can() const { return can_; }
-    template <class I> __device__ __forceinline__ void issue(I) {
-        constexpr int i = I::value, blk = 2 + i / 4, pp = i % 4;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, d[blk & 1][pp]), rs, voff, (uint32_t)(blk * 32 + pp * 8) * ld2, NT ? 2 : 0);
-        if (i == 7) on = false;
-    }
-    __device__ __forceinline__ void flush() {     // after the block's last tile
-        if (!on) return;
-        issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{}); issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{});
-        issue(std::integral_constant<int, 4>{}); issue(std::integral_constant<int, 5>{}); issue(std::integral_constant<int, 6>{}); issue(std::integral_constant<int, 7>{});
-    }
-};
-struct NoPending {                    // kernels / tile shapes without trickling
-    static constexpr bool enabled = false;
-    template <class I> __device__ __forceinline__ void issue(I) {}
-    __device__ __forceinline__ bool armed() const { return false; }
-    __device__ __forceinline__ bool can() const { return false; }
-    __device__ __forceinline__ void flush() {}
-};
-
 // Both helpers take the SWAPPED accumulator layout of gemm_nt_pingpong / gemm_nt_split / gemm_nt_stream / gemm_nt_skinny with SWAP = true: tile (mi, ni), register r,
 // lane (c = l & 31, h = l >> 5) is token mi*32 + c, feature ni*32 + (r & 3) + 8 (r >> 2) + 4 h of the wave's (TM*32 tokens) x (TN*32 features).
 //
 // rows: for one mi the wave's 32 tokens x 64 features are staged as bf16 [32 tokens][128 B]; registers 4g .. 4g+3 of a lane are 4
 // consecutive features -> one packed ds_write_b64 (16-B chunk index XOR (token & 7): 2-way instead of 16-way conflicts), read back 16 B
 // per lane: every global store instruction writes eight whole 128-B rows.  f(v, ni, g) maps 4 features (bias / GELU) before packing.
-template <class Shape, bool NT, class F, class P>
-__device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ out, int64_t ld, int64_t row0, int col0, F&& f, P& pend, int skip_from = 99) {
+template <class Shape, bool NT, class F>
+__device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ out, int64_t ld, int64_t row0, int col0, F&& f, int skip_from = 99) {
     static_assert(Shape::TN == 2, "stage geometry assumes 64 features per wave");
-    int ln = acc.lane;
-    asm volatile("" : "+v"(ln));          // opaque: the per-lane LDS / global offsets below are rebuilt per tile (a few VALU) instead of living in registers across the main loop
-    const int c = ln & 31, h = ln >> 5;
-    const int r8 = ln >> 3, ch = ln & 7;
+    const int c = acc.lane & 31, h = acc.lane >> 5;
+    const int r8 = acc.lane >> 3, ch = acc.lane & 7;
     const char* st_rd = stage + r8 * 128 + ((ch ^ r8) << 4);
     uint16_t* g_base = out + (row0 + r8) * ld + col0 + ch * 8;
-    bool trickle = false;
-    constexpr bool BUF = P::enabled && Shape::TM == 4;      // row stores as buffer stores: scalar resource (the wave's first output element of the tile) + scalar row offset + constant lane offset
-    if constexpr (BUF) {
-        trickle = pend.can();
-        const uint64_t base = reinterpret_cast<uint64_t>(out + row0 * ld + col0);     // the tile coordinates come out of VALU arithmetic: tell the compiler they are uniform
-        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-        pend.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0, -1, 0x00020000);
-    }
     // software pipeline over the mi blocks: write(mi), read(mi), THEN the global stores of mi-1 — LDS operations of one wave complete in order, so
     // the single 4-KiB stage is safe to overwrite right after the reads were issued, and the stores of block mi-1 only wait for their own reads
     // (counted lgkmcnt) while the LDS round trip of block mi is in flight (one exposed round trip per tile instead of one per block)
-    uint4 d_local[2][4];
-    auto& d = [&]() -> uint4 (&)[2][4] { if constexpr (P::enabled && Shape::TM == 4) return pend.d; else return d_local; }();
+    uint4 d[2][4];
 #pragma unroll
     for (int mi = 0; mi <= Shape::TM; ++mi) {
 #ifdef KR_STAMP
@@ -537,25 +493,18 @@ __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage
 #ifdef KR_EXPERIMENT
         if (mi > 0 && mi - 1 >= skip_from) continue;   // diagnostic (wrong output): the global stores of the later token blocks are skipped — what would trickling them buy?
 #endif
-        if (mi > 0 && !(trickle && mi - 1 >= 2)) {   // blocks 2 and 3 of a trickling wave stay in d[0] / d[1] (PendingStores)
+        if (mi > 0) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {  // rl & 7 == lane >> 3 for every p: one lane-dependent LDS / global base, the rest are wave-uniform steps (8 rows per store)
-                if constexpr (BUF) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, d[(mi - 1) & 1][p]), pend.rs, pend.voff, (uint32_t)((mi - 1) * 32 + p * 8) * pend.ld2, NT ? 2 : 0);
-                } else {
-                    u32x4_t* dst = reinterpret_cast<u32x4_t*>(g_base + (int64_t)((mi - 1) * 32 + p * 8) * ld);
-                    if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d[(mi - 1) & 1][p]), dst);
-                    else *dst = __builtin_bit_cast(u32x4_t, d[(mi - 1) & 1][p]);
-                }
+                u32x4_t* dst = reinterpret_cast<u32x4_t*>(g_base + (int64_t)((mi - 1) * 32 + p * 8) * ld);
+                if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, d[(mi - 1) & 1][p]), dst);
+                else *dst = __builtin_bit_cast(u32x4_t, d[(mi - 1) & 1][p]);
             }
         }
     }
 #ifdef KR_STAMP
     acc.stamp(Shape::TM + 1);
 #endif
-    if constexpr (BUF) {
-        if (trickle) pend.on = true;      // blocks 2 and 3 wait in pend.d for the next tile's first intervals (or for flush())
-    }
 }
 
 // V^T[feature, token]: each 32x32 tile is staged as [32 features][32 tokens] (80-B rows), lanes = consecutive tokens of a feature row,
@@ -593,8 +542,8 @@ __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char*
 //   EPI_QKV:   F = 3H: features [0,H) -> q (bias, 1/8 folded into the weights), [H,2H) -> k, [2H,3H) -> V^T (its bias lives in bo_eff)
 //   EPI_DENSE: out0[T,F] = acc as bf16 (k_ln adds the bias and the residual in fp32)
 //   EPI_GELU:  out0[T,F] = gelu(acc + bias)
-template <int EPI, class ShapeE, bool NT, class P>
-__device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>& acc, int64_t m0, int64_t n0, char* stage, P& pend) {
+template <int EPI, class ShapeE, bool NT>
+__device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>& acc, int64_t m0, int64_t n0, char* stage) {
     const int64_t t0 = m0 + acc.m_wave;
     const int f0 = (int)n0 + acc.n_wave;          // first feature of this wave's 64 columns; F % 64 == 0, so a wave is never partial
     if (f0 >= a.F) return;
@@ -615,16 +564,16 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>
             store_transposed_bf16<ShapeE, NT>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H);   // value bias lives in bo_eff
         } else {
             store_rows_bf16<ShapeE, NT>(acc, stage, region ? a.out1 : a.out0, a.H, t0, f0 - region * a.H,
-                                    [&](f32x4 v, int ni, int g) { return v + b[ni][g]; }, pend, a.skip_from);
+                                    [&](f32x4 v, int ni, int g) { return v + b[ni][g]; }, a.skip_from);
         }
     } else if constexpr (EPI == EPI_DENSE) {
-        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.ldo, t0, f0, [&](f32x4 v, int, int) { return v; }, pend, a.skip_from);   // the bias is added in k_ln (fp32)
+        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.ldo, t0, f0, [&](f32x4 v, int, int) { return v; }, a.skip_from);   // the bias is added in k_ln (fp32)
     } else {
         store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.ldo, t0, f0, [&](f32x4 v, int ni, int g) {
             const f32x4 x = v + b[ni][g];
             const f32x2 lo = gelu_erf_fast2(f32x2{x.x, x.y}), hi = gelu_erf_fast2(f32x2{x.z, x.w});
             return f32x4{lo.x, lo.y, hi.x, hi.y};
-        }, pend, a.skip_from);
+        }, a.skip_from);
     }
     if (a.epi_prio) __builtin_amdgcn_s_setprio(0);
 }
@@ -636,15 +585,6 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
     const int T = *a.Tp;
     const int64_t tm_count = (T + ShapeE::BM - 1) / ShapeE::BM, tn_count = (a.F + ShapeE::BN - 1) / ShapeE::BN;
     char* stage = smem + STAGES * ShapeE::STAGE_BYTES + (threadIdx.x >> 6) * EPI_STAGE_BYTES;
-    // trickled epilogue stores: the 256x256 tiles of the dense / GELU projections (the QKV kernel has no registers to spare and a second epilogue form)
-    constexpr bool TRICKLE = ShapeE::BM == 256 && ShapeE::BN == 256 && EPI != EPI_QKV;
-    std::conditional_t<TRICKLE, PendingStores<NT>, NoPending> pend;
-    if constexpr (TRICKLE) {
-        const int lane = threadIdx.x & 63;
-        pend.ld2 = (uint32_t)(a.ldo * 2);
-        pend.voff = (uint32_t)((lane >> 3) * a.ldo + (lane & 7) * 8) * 2u;
-        pend.can_ = a.K / ShapeE::BK >= 4 && a.trickle != 0;
-    }
     gemm_main<ShapeE, STAGES, ANT>(
         a.X, a.ldx, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem,
         [&](int64_t nat, int64_t& m0, int64_t& n0) {
@@ -652,8 +592,7 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
             patch_coord(nat, tm_count, tn_count, tm, tn, (uint32_t)a.pw);
             m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
         },
-        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeE, NT>(a, acc, m0, n0, stage, pend); }, pend);
-    pend.flush();
+        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeE, NT>(a, acc, m0, n0, stage); });
 }
 
 // the same projections on the producer / consumer 128x128 loop (gemm_nt_split): 4 multiplying + 4 staging waves, 4-slot ring + one 4-KiB epilogue
@@ -671,7 +610,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_proj_split(ProjArgs a) {
             patch_coord(nat, tm_count, tn_count, tm, tn, (uint32_t)a.pw);
             m0 = tm * 128; n0 = tn * 128;
         },
-        [&](AccTile<ShapeSplit>& acc, int64_t m0, int64_t n0, int64_t) { NoPending np; proj_epilogue<EPI, ShapeSplit, false>(a, acc, m0, n0, stage, np); });
+        [&](AccTile<ShapeSplit>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeSplit, false>(a, acc, m0, n0, stage); });
 }
 
 // the same projections for a handful of token rows on the skinny loop (gemm_nt_skinny): one 32-token x 32-feature tile per block, grid = (F / 32, T / 32).
@@ -1523,7 +1462,6 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, int nu
     if (a.ldo == 0) a.ldo = a.F;
     { const char* pe = getenv("KIRAG_AMD_PATCH_W"); a.pw = pe ? atoi(pe) : 8; if (a.pw < 1) a.pw = 8; }
     { const char* pe = getenv("KIRAG_AMD_EPI_PRIO"); a.epi_prio = pe ? atoi(pe) : 0; }
-    { const char* pe = getenv("KIRAG_AMD_TRICKLE"); a.trickle = pe ? atoi(pe) : 1; }
     a.skip_from = 99;
 #ifdef KR_EXPERIMENT
     { const char* pe = getenv("KIRAG_AMD_SKIP_STORES_FROM"); if (pe) a.skip_from = atoi(pe); }

@@ -487,22 +487,9 @@ using ShapePP = GemmShape<256, 256, 2, 4>;
 // the same 12 ds_read_b128 and the same matrix-pipe cycles per interval (MI355X_MICROARCH.md, DVFS give-back item 7: the chip may hold a higher clock on
 // this shape).  The accumulators are handed to the epilogue in AccTile's storage with block (mi16, ni16) in v[mi16 >> 1][ni16 >> 1] registers
 // 8 (mi16 & 1) + 4 (ni16 & 1) .. + 3 — a layout no product epilogue understands.
-// Trickled epilogue stores (round 4).  An epilogue may leave up to 8 global stores per wave PENDING (their data stays in registers) and arm the
-// `trickle` object; the main loop then calls trickle.issue(integral_constant<I>) in the L phase of interval I = 0..7 of the next output tile, so that those
-// stores travel through the CU's in-order memory pipeline while the other group's MFMAs run, instead of in the epilogue where nothing overlaps them.
-// A wave that issued a trickled store in an interval may leave TWO more operations outstanding at that interval's counted wait (the store of the previous
-// interval and its own): everything older — in particular the DMA pieces of the previous interval — has still landed.  trickle.armed() is wave-uniform.
-// The first four K-tiles of an output tile are peeled for this when K has at least four (trickle.can() tells the epilogue whether it may arm).
-struct NoTrickle {
-    static constexpr bool enabled = false;
-    template <class I> __device__ __forceinline__ void issue(I) {}
-    __device__ __forceinline__ bool armed() const { return false; }
-};
-
-template <class T, bool SWAP = false, bool A_NT = false, bool M16 = false, class Coord, class Epilogue, class Trickle = NoTrickle>
+template <class T, bool SWAP = false, bool A_NT = false, bool M16 = false, class Coord, class Epilogue>
 __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A, int64_t lda, int64_t M, const uint16_t* __restrict__ B, int64_t ldb,
-                                                 int64_t N, int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi, Trickle&& trickle = Trickle{}) {
-    using TrickleT = std::remove_reference_t<Trickle>;
+                                                 int64_t N, int K, int64_t total_tiles, char* smem, Coord&& coord, Epilogue&& epi) {
     using Shape = ShapePP;
     constexpr int BK = Shape::BK, STAGE = Shape::STAGE_BYTES, ABYTES = Shape::A_BYTES;
     const int tid = threadIdx.x;
@@ -614,9 +601,8 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
         // One interval = L(t,h) (fragments of k-half h, 4 DMA pieces, counted waits) + barrier + M(t,h) (16 MFMAs, nothing else).  The first interval of
         // an output tile is a separate instantiation (FIRST): its first k-step takes the inline constant 0 as the C operand, so the accumulators are never
         // zero-initialised (128 v_mov per wave and tile at the boundary, where nothing overlaps them).
-        auto interval = [&](auto first_tag, auto ti_tag, const char* sa, const char* sb, int h, bool last) {
+        auto interval = [&](auto first_tag, const char* sa, const char* sb, int h, bool last) {
             constexpr bool FIRST = decltype(first_tag)::value;
-            constexpr int TI = decltype(ti_tag)::value;      // >= 0: this interval's L phase may carry trickled epilogue store TI of the previous tile
             if constexpr (M16) {
                 uint4 af16[8], bf16v[4];
                 const int r16 = lane & 15;
@@ -656,12 +642,7 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
                 for (int mi = 0; mi < 4; ++mi) af[k2][mi] = *reinterpret_cast<const uint4*>(sa + a_row_byte + mi * 32 * 128 + coff);
             }
             if (h == 0) issue4(cx, false, xpiece, offx); else issue4(cy, true, ypiece, offy);
-            if constexpr (TrickleT::enabled && TI >= 0) {
-                if (trickle.armed()) {                                  // wave-uniform
-                    trickle.issue(std::integral_constant<int, TI>{});
-                    wait_vmcnt<6>();                                    // may stay outstanding: last interval's trickled store, this interval's 4 pieces + store
-                } else wait_vmcnt<4>();
-            } else wait_vmcnt<4>();
+            wait_vmcnt<4>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -690,33 +671,17 @@ __device__ __forceinline__ void gemm_nt_pingpong(const uint16_t* __restrict__ A,
             if (!(last && grp)) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
-        using NoTI = std::integral_constant<int, -1>;
         {
             const char* sa = smem + cur * STAGE;
             cur ^= 1;
-            interval(std::true_type{}, std::integral_constant<int, 0>{}, sa, sa + ABYTES, 0, false);
-            interval(std::false_type{}, std::integral_constant<int, TrickleT::enabled ? 1 : -1>{}, sa, sa + ABYTES, 1, nk == 1);   // (-1: one instantiation fewer without trickling)
+            interval(std::true_type{}, sa, sa + ABYTES, 0, false);
+            interval(std::false_type{}, sa, sa + ABYTES, 1, nk == 1);
         }
-        int kt = 1;
-        if constexpr (TrickleT::enabled) {
-            if (nk >= 4) {                                              // the next three K-tiles peeled: trickle slots 2 .. 7
-                auto peeled = [&](auto t0, auto t1, bool lastkt) {
-                    const char* sa = smem + cur * STAGE;
-                    cur ^= 1;
-                    interval(std::false_type{}, t0, sa, sa + ABYTES, 0, false);
-                    interval(std::false_type{}, t1, sa, sa + ABYTES, 1, lastkt);
-                };
-                peeled(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, false);
-                peeled(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, false);
-                peeled(std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{}, nk == 4);
-                kt = 4;
-            }
-        }
-        for (; kt < nk; ++kt) {
+        for (int kt = 1; kt < nk; ++kt) {
             const char* sa = smem + cur * STAGE;
             cur ^= 1;
-            interval(std::false_type{}, NoTI{}, sa, sa + ABYTES, 0, false);
-            interval(std::false_type{}, NoTI{}, sa, sa + ABYTES, 1, kt == nk - 1);
+            interval(std::false_type{}, sa, sa + ABYTES, 0, false);
+            interval(std::false_type{}, sa, sa + ABYTES, 1, kt == nk - 1);
         }
 #ifdef KR_STAMP
         const unsigned long long st_t2 = KR_STAMP_NOW();
