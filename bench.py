@@ -286,7 +286,8 @@ def main():
                 for s_i in range(count):
                     mine = encoder.forward(tok_ids[q_lo:q_hi], tok_mask[q_lo:q_hi], 0)
                     dist.all_gather(list(q_blk[s_i].split(counts)), mine)
-        can_defer = k <= index.ntotal and world * k <= searcher.DEVICE_MERGE_MAX     # (the host-merge fallbacks synchronise anyway)
+        smallest = min(max(0, min(per, total - r * per)) for r in range(world))      # rows of the smallest shard: known to every rank
+        can_defer = k <= smallest and world * k <= searcher.DEVICE_MERGE_MAX         # the deferred / blocking decision must be the same on all ranks
         res = []
         for s_i in range(count):
             qs = q_blk[s_i] if encoder is not None else q_vec

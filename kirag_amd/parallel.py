@@ -104,7 +104,8 @@ class ShardedSearcher:
         exchange only for a batch in which some rank had to re-answer queries (passes 2 / 3 patch the local list in place).  Returns the (scores, rows)
         pinned CPU tensors that are valid after ``finish_deferred()``.  ``q`` must stay alive and untouched until then; at most ``RING`` (8, or the
         world size) searches may be outstanding.  Raises ``ValueError`` where the enqueue-only path does not apply (a shard with fewer than k rows,
-        lists beyond the device merge) — use ``search``."""
+        lists beyond the device merge) — use ``search``.  Like ``search`` it is collective: the caller must take the deferred / blocking decision from
+        something every rank knows (``bench.py``: k against the smallest shard), never from one rank's shard alone."""
         import torch
         k = int(k); nq = int(q.shape[0])
         if not (torch.is_tensor(q) and q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()):
