@@ -518,6 +518,16 @@ def test_metric_size_5M_all_queries_vs_independent_topk(kind):
     xs = ix.reconstruct_rows(rows) if hasattr(ix, "reconstruct_rows") else np.stack([ix.reconstruct_n(int(r), 1)[0] for r in rows])
     sc = S.scores_at(q[:8].cpu().numpy(), xs, np.arange(8 * k).reshape(8, k).astype(np.int64))
     assert np.array_equal(sc.view(np.uint32), s[:8].view(np.uint32))
+    # the block schedule of bench.py --gpus N at the metric's size: three batches enqueued back to back (ABI 5: several asynchronous searches outstanding on
+    # one stream, nothing waits for the device), finished together — each bit-identical to the blocking search of its batch
+    qs = [torch.roll(q, r, dims=0).contiguous() for r in range(3)]
+    outs = [(torch.empty((nq, k), dtype=torch.float32, device="cuda"), torch.empty((nq, k), dtype=torch.int64, device="cuda")) for _ in qs]
+    for qq, (sa, ia) in zip(qs, outs):
+        ix.search_async(qq, k, sa, ia)
+    assert ix._lib.kr_index_search_pending(ix._h) == 3
+    assert len(ix.finish()) == 3 and ix._lib.kr_index_search_pending(ix._h) == 0
+    for r, (sa, ia) in enumerate(outs):
+        assert np.array_equal(ia.cpu().numpy(), np.roll(i, r, axis=0)) and np.array_equal(sa.cpu().numpy().view(np.uint32), np.roll(s, r, axis=0).view(np.uint32))
 
 
 def test_config4_size_21M_search_only_vs_independent_topk():
