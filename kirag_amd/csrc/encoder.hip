@@ -7,7 +7,8 @@
 // beyond the device-side total exit.  Residual stream = xb, 16-bit (it is also the MFMA operand) + by default xlo, ONE byte per element holding the
 // remainder in units of ulp(hi) / 256 (lo_encode: 19 significand bits with f16 operands).  Operand type (f16 default, bf16) and the low half are fixed
 // per handle at creation (encoder_api.hip: kr_encoder_create_ex); why the defaults are what they are: DESIGN.md sections 2 and 4.2a (golden set G10:
-// with outlier hidden channels two orders above the median only f16 + low half stays inside the 1e-3 score tolerance with margin).  MFMA operands
+// with outlier hidden channels two orders above the median (out3) only f16 + low half stays inside the 1e-3 score tolerance with margin: 1.4e-4; on the 5 x harsher
+// out16 set it measures 1.0e-3 and its test bar is 1.5e-3).  MFMA operands
 // 16-bit (xb, q, k, vT, ctx, h), fp32 accumulation everywhere.
 //
 // Per layer (post-LN BERT):  ONE GEMM [Wq/8|Wk|Wv] x -> q, k (row-major) and v TRANSPOSED [H, T] (so that attention reads
