@@ -205,6 +205,11 @@ int kr_encoder_finalize(kr_encoder* enc);
  *   A sequence whose mask is all zero yields NaN (mean pool) exactly like the reference. */
 int kr_encoder_forward(kr_encoder* enc, const int64_t* input_ids, const int64_t* attention_mask, int B, int S,
                        int pool, float* out, void* stream);
+/* The same with token_type_ids [B,S] int64 (HF BertModel.forward's third input; NULL = all zero = kr_encoder_forward).  No KiRAG caller passes non-zero
+ * types (the collators encode single texts), but the encoders' forward signature has the argument (encoders.py:67,106).  A value outside
+ * [0, type_vocab) is reported as KR_EINVAL through the same deferred channel as token ids. */
+int kr_encoder_forward_tt(kr_encoder* enc, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids, int B, int S,
+                          int pool, float* out, void* stream);
 /* kr_encoder_forward with a DEVICE `out` pointer only enqueues work on `stream` and returns (no host synchronisation); with a host `out`
  * it returns when the result is in the caller's buffer.  The one thing a forward can get wrong at run time - a token id outside [0, vocab)
  * - is recorded by the kernels (the offending token is read as id 0) and reported as KR_EINVAL by the host-output call itself, or, for

@@ -76,6 +76,7 @@ SIGNATURES = {
     "kr_encoder_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "kr_encoder_finalize": (C.c_int, [C.c_void_p]),
     "kr_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "kr_encoder_forward_tt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "kr_encoder_last_hidden": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "kr_encoder_check": (C.c_int, [C.c_void_p]),
 }

@@ -79,9 +79,9 @@ struct Encoder {
     float* stage = nullptr; size_t stage_elems = 0;   // fp32 upload staging for load_weight
     // workspace
     int64_t capT = 0; int capB = 0; int64_t capBS = 0; int64_t ldv = 0;
-    int64_t *d_ids = nullptr, *d_mask = nullptr;
+    int64_t *d_ids = nullptr, *d_mask = nullptr, *d_tt = nullptr;   // d_tt: token_type_ids of the batch (only written when the caller passes them)
     int *seq_off = nullptr, *seq_nk = nullptr, *seq_nq = nullptr, *seq_cls = nullptr, *seq_has0 = nullptr, *d_T = nullptr, *d_err = nullptr;
-    int *tok_id = nullptr, *tok_pos = nullptr;
+    int *tok_id = nullptr, *tok_pos = nullptr, *tok_type = nullptr;
     float *out = nullptr;
     uint8_t *xlo = nullptr;    // low half of the residual stream, one byte per element (lo_encode): written by every LayerNorm with use_lo, else by the last one only
     bool use_lo = false;       // KIRAG_AMD_RESIDUAL_LO=1 at kr_encoder_create
@@ -166,9 +166,10 @@ __global__ __launch_bounds__(64) void k_seq_scan(const int* __restrict__ nk, con
 }
 
 // one wave per sequence: packed token list (attended positions in order; the optional query-only row for position 0 last)
-__global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int S, int vocab, int align,
-                                                    const int* __restrict__ off, const int* __restrict__ nk, const int* __restrict__ nq,
-                                                    int* __restrict__ tok_id, int* __restrict__ tok_pos, int* __restrict__ err) {
+// tt: token_type_ids of the batch or nullptr (= all zero, what every KiRAG caller passes); a value outside [0, type_vocab) sets error bit 2 and is read as 0
+__global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, const int64_t* __restrict__ tt, int S, int vocab,
+                                                    int type_vocab, int align, const int* __restrict__ off, const int* __restrict__ nk, const int* __restrict__ nq,
+                                                    int* __restrict__ tok_id, int* __restrict__ tok_pos, int* __restrict__ tok_type, int* __restrict__ err) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int o = off[b];
     int run = 0;
@@ -180,7 +181,9 @@ __global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ 
             const int r = run + __popcll(bal & ((1ull << lane) - 1ull));
             int64_t id = ids[(int64_t)b * S + p];
             if (id < 0 || id >= vocab) { atomicOr(err, 1); id = 0; }
-            tok_id[o + r] = (int)id; tok_pos[o + r] = p;
+            int64_t ty = tt ? tt[(int64_t)b * S + p] : 0;
+            if (ty < 0 || ty >= type_vocab) { atomicOr(err, 4); ty = 0; }
+            tok_id[o + r] = (int)id; tok_pos[o + r] = p; tok_type[o + r] = (int)ty;
         }
         run += __popcll(bal);
     }
@@ -188,10 +191,12 @@ __global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ 
     if (lane == 0 && n > nk[b]) {
         int64_t id = ids[(int64_t)b * S];
         if (id < 0 || id >= vocab) { atomicOr(err, 1); id = 0; }
-        tok_id[o + nk[b]] = (int)id; tok_pos[o + nk[b]] = 0;
+        int64_t ty = tt ? tt[(int64_t)b * S] : 0;
+        if (ty < 0 || ty >= type_vocab) { atomicOr(err, 4); ty = 0; }
+        tok_id[o + nk[b]] = (int)id; tok_pos[o + nk[b]] = 0; tok_type[o + nk[b]] = (int)ty;
     }
     const int padded = (n + align - 1) & ~(align - 1);
-    if (lane < padded - n) { tok_id[o + n + lane] = 0; tok_pos[o + n + lane] = 0; }
+    if (lane < padded - n) { tok_id[o + n + lane] = 0; tok_pos[o + n + lane] = 0; tok_type[o + n + lane] = 0; }
 }
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -284,7 +289,7 @@ __device__ __forceinline__ void ln_row_store(float4 (&v)[8], int H, int lane, co
 }
 
 // embeddings: word[id] + position[pos] + token_type[0] -> LayerNorm       (one wave per token)
-__global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id, const int* __restrict__ tok_pos, const int* __restrict__ Tp,
+__global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id, const int* __restrict__ tok_pos, const int* __restrict__ tok_type, const int* __restrict__ Tp,
                                                   const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
                                                   const float* __restrict__ g, const float* __restrict__ bta, float eps, int H,
                                                   uint8_t* __restrict__ xlo, uint16_t* __restrict__ xb) {
@@ -293,6 +298,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id
     if (t >= *Tp) return;
     const float* w = word + (int64_t)tok_id[t] * H;
     const float* p = pos + (int64_t)tok_pos[t] * H;
+    const float* ty = type + (int64_t)tok_type[t] * H;       // token_type_embeddings row (0 for every KiRAG caller)
     float4 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id
         if (i < H) {
             const float4 a = *reinterpret_cast<const float4*>(w + i);
             const float4 b = *reinterpret_cast<const float4*>(p + i);
-            const float4 c = *reinterpret_cast<const float4*>(type + i);
+            const float4 c = *reinterpret_cast<const float4*>(ty + i);
             v[j] = make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
         }
     }
@@ -1289,11 +1295,11 @@ static int dmalloc(P** p, size_t bytes) {
 
 static void free_ws(Encoder* e) {
     if (!e->graphs.empty()) { (void)hipDeviceSynchronize(); drop_graphs(e); }   // captured kernels hold workspace pointers
-    void* ptrs[] = {e->d_ids, e->d_mask, e->seq_off, e->seq_nk, e->seq_nq, e->seq_cls, e->seq_has0, e->tok_id, e->tok_pos, e->xlo, e->y, e->out,
+    void* ptrs[] = {e->d_ids, e->d_mask, e->d_tt, e->tok_type, e->seq_off, e->seq_nk, e->seq_nq, e->seq_cls, e->seq_has0, e->tok_id, e->tok_pos, e->xlo, e->y, e->out,
                     e->xb, e->q, e->k, e->vT, e->ctx, e->h, e->c_ctx, e->c_xb, e->c_y, e->c_h, e->c_xlo, e->c_off, e->c_nk, e->c_cls, e->d_B};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     e->c_ctx = e->c_xb = e->c_y = e->c_h = nullptr; e->c_xlo = nullptr; e->c_off = e->c_nk = e->c_cls = e->d_B = nullptr;
-    e->d_ids = e->d_mask = nullptr; e->seq_off = e->seq_nk = e->seq_nq = e->seq_cls = e->seq_has0 = nullptr; e->tok_id = e->tok_pos = nullptr;
+    e->d_ids = e->d_mask = e->d_tt = nullptr; e->tok_type = nullptr; e->seq_off = e->seq_nk = e->seq_nq = e->seq_cls = e->seq_has0 = nullptr; e->tok_id = e->tok_pos = nullptr;
     e->out = nullptr; e->xlo = nullptr; e->y = e->xb = e->q = e->k = e->vT = e->ctx = e->h = nullptr;
     e->capT = 0; e->capB = 0; e->capBS = 0;
 }
@@ -1312,9 +1318,9 @@ static int ensure_ws(Encoder* e, int B, int S) {
     if (maxT > (int64_t)1 << 24) return fail(KR_EINVAL, "batch of %lld tokens: at most 2^24 per forward (32-bit offsets inside the attention kernels)", (long long)maxT);
     free_ws(e);
     const int64_t capT = round_up(maxT, 256), capB = B, capBS = (int64_t)B * S;   // multiple of the 256-token tile: see k_proj
-    KR_TRY(dmalloc(&e->d_ids, capBS * 8)); KR_TRY(dmalloc(&e->d_mask, capBS * 8));
+    KR_TRY(dmalloc(&e->d_ids, capBS * 8)); KR_TRY(dmalloc(&e->d_mask, capBS * 8)); KR_TRY(dmalloc(&e->d_tt, capBS * 8));
     KR_TRY(dmalloc(&e->seq_off, capB * 4)); KR_TRY(dmalloc(&e->seq_nk, capB * 4)); KR_TRY(dmalloc(&e->seq_nq, capB * 4)); KR_TRY(dmalloc(&e->seq_cls, capB * 4)); KR_TRY(dmalloc(&e->seq_has0, capB * 4));
-    KR_TRY(dmalloc(&e->tok_id, capT * 4)); KR_TRY(dmalloc(&e->tok_pos, capT * 4));
+    KR_TRY(dmalloc(&e->tok_id, capT * 4)); KR_TRY(dmalloc(&e->tok_pos, capT * 4)); KR_TRY(dmalloc(&e->tok_type, capT * 4));
     KR_TRY(dmalloc(&e->xlo, capT * H)); KR_TRY(dmalloc(&e->y, capT * H * 2)); KR_TRY(dmalloc(&e->out, (size_t)capB * H * 4));
     KR_TRY(dmalloc(&e->xb, capT * H * 2)); KR_TRY(dmalloc(&e->q, capT * H * 2));
     KR_TRY(dmalloc(&e->k, (capT + 64) * H * 2));    // 64 rows of slack: k_attn_dma reads whole 64-key chunks (the rows past a sequence are masked)
@@ -1679,7 +1685,7 @@ __global__ __launch_bounds__(256) void k_gather_cls(const uint16_t* __restrict__
 }
 
 // every kernel of one forward, enqueued on `st` (inputs already in e->d_ids / e->d_mask, result left in e->out)
-static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
+static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, bool has_tt = false) {
     const int H = e->cfg.hidden, FF = e->cfg.intermediate;
     const float eps = e->cfg.ln_eps;
     hipLaunchKernelGGL(k_seq_len, dim3(B), dim3(64), 0, st, e->d_mask, B, S, e->seq_nk, e->seq_has0);
@@ -1688,8 +1694,8 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
             // > 128 tokens: the LDS-DMA attention kernel (KIRAG_AMD_ATTN_LDS=1: A/B against the register-staged one)
     const int align = long_seq ? 8 : 4;                                            // sequence offsets: multiple of 8 tokens so that V^T chunks start 16-B aligned
     hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(64), 0, st, e->seq_nk, e->seq_has0, B, pool, align, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->d_err);
-    hipLaunchKernelGGL(k_fill_tokens, dim3(B), dim3(64), 0, st, e->d_ids, e->d_mask, S, e->cfg.vocab, align, e->seq_off, e->seq_nk, e->seq_nq, e->tok_id,
-                       e->tok_pos, e->d_err);
+    hipLaunchKernelGGL(k_fill_tokens, dim3(B), dim3(64), 0, st, e->d_ids, e->d_mask, has_tt ? e->d_tt : nullptr, S, e->cfg.vocab, e->cfg.type_vocab, align, e->seq_off,
+                       e->seq_nk, e->seq_nq, e->tok_id, e->tok_pos, e->tok_type, e->d_err);
     const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + align - 1) & ~(align - 1));   // upper bound of the packed token count (each sequence is padded to `align`)
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
     // LayerNorm streams: y (dead after the kernel) and the low half (next read by the next LayerNorm, ~600 MiB of traffic later) are loaded / stored
@@ -1703,7 +1709,7 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
       const char* g = getenv("KIRAG_AMD_LN_GRID"); if (g && atoi(g) > 0) ln_mult = (unsigned)atoi(g); }
 #endif
     const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu_all * ln_mult);   // k_ln is grid-stride (its parameters stay in registers across rows)
-    hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
+    hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->tok_type, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->use_lo ? e->xlo : nullptr, e->xb);
     uint8_t* const lo_rw = e->use_lo ? e->xlo : nullptr;       // low half read / written by the inner LayerNorms
     const bool shortcut = pool == KR_POOL_CLS && e->cls_shortcut && e->c_ctx != nullptr;
@@ -1769,9 +1775,9 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
 // attributes, which must not happen during capture); capture and replay use an internal stream (the caller's may be the legacy default stream,
 // which cannot be captured), ordered against the caller's stream by events.  Any failure falls back to eager launches for good.
 constexpr int64_t GRAPH_MAX_TOKENS = 4096;
-static int run_forward(Encoder* e, int B, int S, int pool, hipStream_t st) {
+static int run_forward(Encoder* e, int B, int S, int pool, hipStream_t st, bool has_tt = false) {
     const int64_t maxT = (int64_t)B * (S + 8);
-    if (e->graphs_off || maxT > GRAPH_MAX_TOKENS) return enqueue_forward(e, B, S, pool, st);
+    if (e->graphs_off || maxT > GRAPH_MAX_TOKENS || has_tt) return enqueue_forward(e, B, S, pool, st, has_tt);
     const uint64_t key = ((uint64_t)B << 32) | ((uint64_t)S << 8) | (uint64_t)pool;
     GraphEntry* ent = nullptr;
     for (auto& g : e->graphs) if (g.key == key) { ent = &g; break; }
@@ -1812,6 +1818,7 @@ static int report_token_error(Encoder* e, hipStream_t st) {
     *e->h_err = 0;
     KR_HIP(hipMemsetAsync(e->d_err, 0, sizeof(int), st));
     if (w & 1) return fail(KR_EINVAL, "input_ids contain a token id outside [0, %d)", e->cfg.vocab);
+    if (w & 4) return fail(KR_EINVAL, "token_type_ids contain a value outside [0, %d)", e->cfg.type_vocab);
 #ifdef KR_ENC_BUILD_F16
     return fail(KR_ERANGE, "non-finite activations in the forward: a value left the f16 operand range (|x| > 65504) or the weights hold NaN / Inf; "
                            "the embeddings of this batch are not usable (KIRAG_AMD_ENCODER_DTYPE=bf16 has the fp32 exponent range)");
@@ -1820,7 +1827,7 @@ static int report_token_error(Encoder* e, hipStream_t st) {
 #endif
 }
 
-int enc_forward(void* h, const int64_t* input_ids, const int64_t* attention_mask, int B, int S, int pool, float* out, void* stream) {
+int enc_forward(void* h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids, int B, int S, int pool, float* out, void* stream) {
     if (!h) return fail(KR_EINVAL, "encoder is NULL");
     Encoder* e = reinterpret_cast<Encoder*>(h);
     if (!e->ready) return fail(KR_ESTATE, "encoder weights incomplete: call kr_encoder_finalize after loading every tensor");
@@ -1842,7 +1849,8 @@ int enc_forward(void* h, const int64_t* input_ids, const int64_t* attention_mask
     const int H = e->cfg.hidden;
     KR_HIP(hipMemcpyAsync(e->d_ids, input_ids, (size_t)B * S * 8, hipMemcpyDefault, st));
     KR_HIP(hipMemcpyAsync(e->d_mask, attention_mask, (size_t)B * S * 8, hipMemcpyDefault, st));
-    KR_TRY(run_forward(e, B, S, pool, st));
+    if (token_type_ids) KR_HIP(hipMemcpyAsync(e->d_tt, token_type_ids, (size_t)B * S * 8, hipMemcpyDefault, st));
+    KR_TRY(run_forward(e, B, S, pool, st, token_type_ids != nullptr));
     KR_HIP(hipMemcpyAsync(out, e->out, (size_t)B * H * 4, hipMemcpyDefault, st));
     e->lastB = B; e->lastS = S; e->last_stream = st;
     KR_HIP(hipMemcpyAsync(e->h_err, e->d_err, sizeof(int), hipMemcpyDeviceToHost, st));

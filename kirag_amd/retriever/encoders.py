@@ -101,56 +101,41 @@ class HipBertForward:
         _lib.check(self._lib.kr_encoder_finalize(self._h))
         self.fingerprint = None
 
-    def forward_np(self, input_ids, attention_mask, pool: int):
+    def forward_np(self, input_ids, attention_mask, pool: int, token_type_ids=None):
         """numpy in / numpy out (host pointers straight through the C ABI)."""
         import numpy as np
         ids = np.ascontiguousarray(input_ids, dtype=np.int64); mask = np.ascontiguousarray(attention_mask, dtype=np.int64)
         B, S = ids.shape
         out = np.empty((B, self.hidden), np.float32)
-        _lib.check(self._lib.kr_encoder_forward(self._h, ids.ctypes.data, mask.ctypes.data, B, S, pool, out.ctypes.data, None))
+        if token_type_ids is None:
+            _lib.check(self._lib.kr_encoder_forward(self._h, ids.ctypes.data, mask.ctypes.data, B, S, pool, out.ctypes.data, None))
+        else:
+            tt = np.ascontiguousarray(token_type_ids, dtype=np.int64)
+            assert tt.shape == ids.shape
+            _lib.check(self._lib.kr_encoder_forward_tt(self._h, ids.ctypes.data, mask.ctypes.data, tt.ctypes.data, B, S, pool, out.ctypes.data, None))
         return out
 
-    def forward(self, input_ids: Tensor, attention_mask: Tensor, pool: int) -> Tensor:
+    def forward(self, input_ids: Tensor, attention_mask: Tensor, pool: int, token_type_ids: Optional[Tensor] = None) -> Tensor:
+        """Enqueue-only for device tensors.  ``token_type_ids`` (HF BertModel's third input; None = zeros, what every KiRAG caller passes) go to the
+        kernels like the token ids: a value outside ``[0, type_vocab_size)`` is reported by ``check()`` / the next call (``kr_encoder_forward_tt``)."""
         ids = input_ids.to(torch.int64).contiguous()
         mask = attention_mask.to(device=ids.device, dtype=torch.int64).contiguous()
         B, S = ids.shape
         out = torch.empty((B, self.hidden), dtype=torch.float32, device=ids.device)
-        _lib.check(self._lib.kr_encoder_forward(self._h, ids.data_ptr(), mask.data_ptr(), B, S, pool, out.data_ptr(),
-                                                _lib.current_stream_ptr() if ids.is_cuda else None))
+        stream = _lib.current_stream_ptr() if ids.is_cuda else None
+        if token_type_ids is None:
+            _lib.check(self._lib.kr_encoder_forward(self._h, ids.data_ptr(), mask.data_ptr(), B, S, pool, out.data_ptr(), stream))
+        else:
+            tt = token_type_ids.to(device=ids.device, dtype=torch.int64).contiguous()
+            if tuple(tt.shape) != (B, S):
+                raise ValueError(f"token_type_ids must be [B,S] = {(B, S)}, got {tuple(tt.shape)}")
+            _lib.check(self._lib.kr_encoder_forward_tt(self._h, ids.data_ptr(), mask.data_ptr(), tt.data_ptr(), B, S, pool, out.data_ptr(), stream))
         return out
 
     def check(self) -> None:
-        """Wait for the last device-output forward and raise if it saw a token id outside the vocabulary (``kr_encoder_check``) or a
-        non-zero ``token_type_ids`` entry (deferred like the token ids: see ``defer_token_type_check``)."""
-        try:
-            self.poll_token_type(block=True)
-        finally:                                               # a pending token-type error must not leave a pending out-of-vocabulary / overflow error unreported
-            _lib.check(self._lib.kr_encoder_check(self._h))
-
-    _TT_MSG = "token_type_ids != 0 is not used by any KiRAG caller and is not implemented on the HIP path"
-
-    def defer_token_type_check(self, token_type_ids: Tensor) -> None:
-        """``token_type_ids`` on the DEVICE: testing them with ``bool(t.any())`` would synchronise the host with the stream on every forward (the
-        module surface is enqueue-only).  The test runs on the stream instead, its one-byte result goes to pinned memory, and it is looked at when it
-        has arrived: at a later forward, or in ``check()`` at the latest — the same contract as out-of-vocabulary token ids."""
-        flag = torch.empty(1, dtype=torch.bool, pin_memory=True)
-        flag.copy_((token_type_ids != 0).any().reshape(1), non_blocking=True)
-        ev = torch.cuda.Event(); ev.record()
-        pend = self.__dict__.setdefault("_tt_pending", [])
-        pend.append((ev, flag))
-
-    def poll_token_type(self, block: bool = False) -> None:
-        pend = self.__dict__.get("_tt_pending")
-        while pend:
-            ev, flag = pend[0]
-            if block:
-                ev.synchronize()
-            elif not ev.query():
-                return
-            pend.pop(0)
-            if bool(flag[0]):
-                pend.clear()
-                raise NotImplementedError(self._TT_MSG)
+        """Wait for the last device-output forward and raise if it saw a token id outside the vocabulary, a token type outside the type vocabulary, or
+        non-finite activations (``kr_encoder_check``)."""
+        _lib.check(self._lib.kr_encoder_check(self._h))
 
     def last_hidden(self, B: int, S: int) -> Tensor:
         out = torch.empty((B, S, self.hidden), dtype=torch.float32)
@@ -172,8 +157,6 @@ class _HipSentenceEncoder(BertModel):
             raise RuntimeError(
                 f"{type(self).__name__} in eval mode runs on the MI355X HIP path only; its parameters are on {p.device}. "
                 "Move the model to a GPU (kirag_amd has no CPU fallback).")
-        if token_type_ids is not None and not token_type_ids.is_cuda and bool((token_type_ids != 0).any()):
-            raise NotImplementedError(HipBertForward._TT_MSG)          # host tensor: tested here
         if input_ids.dim() != 2:
             raise ValueError(f"input_ids must be [B,S], got {tuple(input_ids.shape)}")
         idx = p.device.index if p.device.index is not None else torch.cuda.current_device()
@@ -181,10 +164,7 @@ class _HipSentenceEncoder(BertModel):
             self._hip = HipBertForward(self.config, idx)
         self._hip.sync(self)
         with torch.cuda.device(idx):
-            self._hip.poll_token_type()                                # deferred tests of earlier forwards that have arrived
-            if token_type_ids is not None and token_type_ids.is_cuda:
-                self._hip.defer_token_type_check(token_type_ids)       # device tensor: no host synchronisation on the forward path
-            return self._hip.forward(input_ids.to(p.device), attention_mask, self._pool)
+            return self._hip.forward(input_ids.to(p.device), attention_mask, self._pool, token_type_ids)   # token types go to the kernels (kr_encoder_forward_tt)
 
     def invalidate_hip_weights(self) -> None:
         if self._hip is not None:

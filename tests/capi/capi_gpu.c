@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     BIND(kr_index_search) BIND(kr_index_search_async) BIND(kr_index_search_finish) BIND(kr_index_search_finish_ex) BIND(kr_index_search_pending)
     BIND(kr_index_stats)
     BIND(kr_encoder_create_ex) BIND(kr_encoder_operand_dtype) BIND(kr_encoder_residual_lo) BIND(kr_encoder_destroy) BIND(kr_encoder_load_weight)
-    BIND(kr_encoder_finalize) BIND(kr_encoder_forward) BIND(kr_encoder_check)
+    BIND(kr_encoder_finalize) BIND(kr_encoder_forward) BIND(kr_encoder_forward_tt) BIND(kr_encoder_check)
     if (p_kr_abi_version() != KR_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }
     if (p_kr_device_count() < 1) { printf("no GPU visible\n"); return 3; }
 
@@ -124,6 +124,15 @@ int main(int argc, char** argv) {
         const double bar = modes[m][0] == KR_ENC_F16 ? tol : 4.0 * tol;
         if (!(worst <= bar)) { printf("encoder mode %d: max |err| %.3e > %.3e\n", m, worst, bar); return 1; }
         printf("encoder mode (dtype %d, lo %d): max |err| %.2e\n", modes[m][0], modes[m][1], worst);
+        /* token types: NULL and all-zero types are kr_encoder_forward bit for bit */
+        {
+            float* emb2 = malloc((size_t)B * H * 4); int64_t* tt0 = calloc((size_t)B * S, 8);
+            CHECK(p_kr_encoder_forward_tt(enc, ids, mask, NULL, B, S, pool, emb2, NULL));
+            if (memcmp(emb, emb2, (size_t)B * H * 4)) { printf("forward_tt(NULL) differs\n"); return 1; }
+            CHECK(p_kr_encoder_forward_tt(enc, ids, mask, tt0, B, S, pool, emb2, NULL));
+            if (memcmp(emb, emb2, (size_t)B * H * 4)) { printf("forward_tt(zeros) differs\n"); return 1; }
+            free(emb2); free(tt0);
+        }
         /* a token id outside the vocabulary: reported by the host-output call itself */
         const int64_t keep = ids[1];
         ids[1] = cfg.vocab + 7;

@@ -292,27 +292,49 @@ def test_config4_flow_streamed_bge_encode_into_resident_shard_then_search(golden
         assert all(res3[r][0] == res[r][0] and np.array_equal(res3[r][1], res[r][1]) for r in range(4))
 
 
-def test_token_type_ids_are_checked_without_a_host_synchronisation(golden):
-    """token_type_ids != 0 is not implemented on the HIP path and must be refused — but testing a DEVICE tensor with bool(t.any()) would synchronise the host
-    with the stream on every forward of the module surface.  Host tensors are tested at once; device tensors on the stream, reported by a later forward or
-    by check() at the latest (the contract of out-of-vocabulary token ids)."""
+def test_token_type_ids_go_through_the_hip_path(golden):
+    """HF BertModel.forward's third input.  No KiRAG caller passes non-zero token types (the collators encode single texts), but E5Encoder / BGEEncoder.forward have
+    the argument (encoders.py:67,106); until round 4 the HIP path refused non-zero values.  Now they reach the embedding kernel (kr_encoder_forward_tt): checked
+    against the numpy oracle's bert_forward and against the module's own PyTorch forward; host and device tensors alike, no host synchronisation on the forward;
+    a value outside the type vocabulary is a deferred KR_EINVAL like a token id outside the vocabulary."""
     from transformers import BertConfig
+    from kirag_amd import _lib
     from kirag_amd.retriever.encoders import E5Encoder
+    from oracle import encoder_np as E
     g = golden("g4_g8_retriever.npz")
     H, L, heads, FF, vocab, max_pos = [int(v) for v in g["cfg"]]
     cfg = BertConfig(vocab_size=vocab, hidden_size=H, num_hidden_layers=L, num_attention_heads=heads, intermediate_size=FF, max_position_embeddings=max_pos)
+    torch.manual_seed(3)
     m = E5Encoder(cfg, add_pooling_layer=False).cuda().eval()
-    ids = torch.randint(5, vocab, (4, 12)); mask = torch.ones_like(ids)
-    zeros = torch.zeros_like(ids); bad = zeros.clone(); bad[2, 3] = 1
-    ref = m(ids.cuda(), mask.cuda(), zeros.cuda())
+    with torch.no_grad():
+        m.embeddings.token_type_embeddings.weight.mul_(25.0)    # make the two type rows matter (HF initialises them at N(0, 0.02))
+    rng = np.random.default_rng(5)
+    ids = torch.from_numpy(rng.integers(5, vocab, (6, 20))); mask = torch.ones_like(ids); mask[1, 13:] = 0; mask[4, :7] = 0
+    tt = torch.from_numpy(rng.integers(0, 2, (6, 20)))
+    zeros = torch.zeros_like(ids)
+    out_tt = m(ids.cuda(), mask.cuda(), tt.cuda())
+    out_0 = m(ids.cuda(), mask.cuda(), zeros.cuda())
     m._hip.check()
-    assert torch.equal(m(ids.cuda(), mask.cuda(), zeros), ref) and torch.equal(m(ids.cuda(), mask.cuda()), ref)
-    with pytest.raises(NotImplementedError):
-        m(ids.cuda(), mask.cuda(), bad)                         # host tensor: refused before anything is enqueued
-    out = m(ids.cuda(), mask.cuda(), bad.cuda())                # device tensor: the forward itself only enqueues
-    assert out.shape == ref.shape
-    with pytest.raises(NotImplementedError):
+    assert torch.equal(m(ids.cuda(), mask.cuda(), tt), out_tt)                       # a host tensor of types gives the same bits
+    assert torch.equal(m(ids.cuda(), mask.cuda()), out_0) and torch.equal(m(ids.cuda(), mask.cuda(), zeros), out_0)
+    assert (out_tt - out_0).abs().max() > 1e-2                                       # the types are not ignored
+    # the numpy oracle (BertModel semantics, retriever/encoders.py:67-77)
+    w = {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items()}
+    hid = E.bert_forward(w, ids.numpy(), mask.numpy(), heads, token_type_ids=tt.numpy())
+    ref = E.average_pool(hid, mask.numpy()); ref = ref / np.linalg.norm(ref, axis=1, keepdims=True)
+    assert np.abs(out_tt.cpu().numpy() - ref).max() < 4e-3
+    # the module's own PyTorch forward (what train mode runs)
+    with torch.no_grad():
+        lh = m._torch_pooled(ids.cuda(), mask.cuda(), tt.cuda())
+    mm = mask.cuda()[..., None].float()
+    tref = torch.nn.functional.normalize((lh * mm).sum(1) / mm.sum(1), dim=1)
+    assert (out_tt - tref).abs().max() < 4e-3
+    # a type outside [0, type_vocab_size): the forward only enqueues, check() reports it once, the handle stays usable
+    bad = tt.clone(); bad[2, 3] = 7
+    out = m(ids.cuda(), mask.cuda(), bad.cuda())
+    assert out.shape == out_tt.shape
+    with pytest.raises(_lib.KiragAmdError, match="token_type_ids"):
         m._hip.check()
-    m._hip.check()                                              # reported once
-    assert torch.equal(m(ids.cuda(), mask.cuda(), zeros.cuda()), ref)
+    m._hip.check()
+    assert torch.equal(m(ids.cuda(), mask.cuda(), tt.cuda()), out_tt)
     m._hip.check()
