@@ -108,8 +108,8 @@ class ShardedSearcher:
         something every rank knows (``bench.py``: k against the smallest shard), never from one rank's shard alone."""
         import torch
         k = int(k); nq = int(q.shape[0])
-        if not (torch.is_tensor(q) and q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()):
-            raise ValueError("search_deferred needs a contiguous float32 CUDA tensor of queries")
+        if not (torch.is_tensor(q) and q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()) or nq == 0:
+            raise ValueError("search_deferred needs a non-empty contiguous float32 CUDA tensor of queries")
         import torch.distributed as dist
         if not dist.is_initialized() or k > int(self.index.ntotal) or self.world * k > self.DEVICE_MERGE_MAX or not hasattr(self.index, "search_async"):
             raise ValueError("search_deferred: needs a process group, k <= rows of every shard and world * k <= %d" % self.DEVICE_MERGE_MAX)

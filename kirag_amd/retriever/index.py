@@ -138,6 +138,8 @@ class FlatIPIndex:
             raise ValueError(f"top_docs={k} must satisfy 0 < k <= ntotal={self.ntotal}")
         assert tuple(scores_out.shape) == (nq, k) and tuple(rows_out.shape) == (nq, k)
         assert scores_out.is_contiguous() and rows_out.is_contiguous() and scores_out.dtype == torch.float32 and rows_out.dtype == torch.int64
+        if nq == 0:
+            raise ValueError("search_async needs at least one query")              # (kr_index_search_async would return without an outstanding call)
         if not isinstance(getattr(self, "_pending", None), list):
             self._pending = []
         self._pending.append((q, scores_out, rows_out))                            # keep-alive until finish()
