@@ -146,6 +146,7 @@ struct Index {
     // environment switches, read ONCE at kr_index_create (round 2 called getenv() on every search)
     bool no_q32 = false, no_fine = false, no_mark = false, no_vmm = false;
     int epiv = 0;   // -DKR_EXPERIMENT builds: k_coarse epilogue variant (KIRAG_AMD_EPIV)
+    int trim[2] = {0, 0};   // -DKR_EXPERIMENT builds: mantissa bits rounded away in the corpus / query 16-bit copies (KIRAG_AMD_TRIM_X / _Q)
     // asynchronous search (kr_index_search_async ... kr_index_search_finish): pass 1 of every block is enqueued, the per-query certificate flags
     // land in pinned memory behind it; finish() reads them and runs the rare passes 2 / 3
     // Up to PEND_MAX calls may be outstanding on ONE stream (the row-sharded search enqueues the W batches of a block back to back and looks at their
@@ -169,6 +170,17 @@ struct Index {
 // ---------------------------------------------------------------------------------------------------------
 // add: fp32 rows -> 16-bit copy + quantisation-error bounds
 // ---------------------------------------------------------------------------------------------------------
+#ifdef KR_EXPERIMENT
+// experiment (KIRAG_AMD_TRIM_X / KIRAG_AMD_TRIM_Q): round the 16-bit copies to fewer mantissa bits (data-dependent MFMA power; the bounds are
+// computed from the stored values, so the certificate stays exact and only the candidate count changes)
+__device__ int g_trim_x = 0, g_trim_q = 0;
+__device__ inline uint16_t trim16(uint16_t o, int t) { return t > 0 ? (uint16_t)((o + (1u << (t - 1))) & ~((1u << t) - 1u)) : o; }
+#define TRIMX(o) trim16(o, g_trim_x)
+#define TRIMQ(o) trim16(o, g_trim_q)
+#else
+#define TRIMX(o) (o)
+#define TRIMQ(o) (o)
+#endif
 template <class T>
 __global__ __launch_bounds__(256) void k_add_rows(const float* __restrict__ xf, uint16_t* __restrict__ xc, int64_t n, int d, int dpad,
                                                   float* __restrict__ bounds) {
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(256) void k_add_rows(const float* __restrict__ xf, 
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < d) v = *reinterpret_cast<const float4*>(src + i);
             ushort4 o;
-            o.x = T::from_f32(v.x); o.y = T::from_f32(v.y); o.z = T::from_f32(v.z); o.w = T::from_f32(v.w);
+            o.x = TRIMX(T::from_f32(v.x)); o.y = TRIMX(T::from_f32(v.y)); o.z = TRIMX(T::from_f32(v.z)); o.w = TRIMX(T::from_f32(v.w));
             const float cx = T::to_f32(o.x), cy = T::to_f32(o.y), cz = T::to_f32(o.z), cw = T::to_f32(o.w);
             e2 += (v.x - cx) * (v.x - cx) + (v.y - cy) * (v.y - cy) + (v.z - cz) * (v.z - cz) + (v.w - cw) * (v.w - cw);
             c2 += cx * cx + cy * cy + cz * cz + cw * cw;
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < nq && i < d) v = *reinterpret_cast<const float4*>(qf + (int64_t)q * d + i);
         ushort4 o;
-        o.x = T::from_f32(v.x); o.y = T::from_f32(v.y); o.z = T::from_f32(v.z); o.w = T::from_f32(v.w);
+        o.x = TRIMQ(T::from_f32(v.x)); o.y = TRIMQ(T::from_f32(v.y)); o.z = TRIMQ(T::from_f32(v.z)); o.w = TRIMQ(T::from_f32(v.w));
         const float cx = T::to_f32(o.x), cy = T::to_f32(o.y), cz = T::to_f32(o.z), cw = T::to_f32(o.w);
         q2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         e2 += (v.x - cx) * (v.x - cx) + (v.y - cy) * (v.y - cy) + (v.z - cz) * (v.z - cz) + (v.w - cw) * (v.w - cw);
@@ -1324,6 +1336,9 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
     KR_HIP(hipMemcpyAsync(ix->q_f, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyDefault, st));
     CoarseArgs a; fill_args(ix, a);
     const size_t blk_cnt_bytes = ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int);
+#ifdef KR_EXPERIMENT
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_trim_q), &ix->trim[1], sizeof(int), 0, hipMemcpyHostToDevice, st);
+#endif
     hipLaunchKernelGGL(k_prep_queries<T>, dim3(p.nq_pad), dim3(64), 0, st, ix->q_f, ix->q_c, nq, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr,
                        ix->cnt, ix->flags);
     a.nq_pad = p.nq_pad; a.nq = nq;
@@ -1662,6 +1677,7 @@ int kr_index_create(int d, int metric, int coarse_dtype, int device, kr_index** 
     ix->no_mark = getenv("KIRAG_AMD_NO_MARK") != nullptr; ix->no_vmm = getenv("KIRAG_AMD_NO_VMM") != nullptr;
 #ifdef KR_EXPERIMENT
     { const char* v = getenv("KIRAG_AMD_EPIV"); ix->epiv = v ? atoi(v) : 0; }
+    { const char* v = getenv("KIRAG_AMD_TRIM_X"); ix->trim[0] = v ? atoi(v) : 0; v = getenv("KIRAG_AMD_TRIM_Q"); ix->trim[1] = v ? atoi(v) : 0; }
 #endif
     *out = reinterpret_cast<kr_index*>(ix);
     return 0;
@@ -1710,6 +1726,9 @@ int kr_index_add(kr_index* h, const float* x, int64_t n, void* stream) {
     float* dst = ix->xf + ix->n * ix->d;
     KR_HIP(hipMemcpyAsync(dst, x, (size_t)n * ix->d * sizeof(float), hipMemcpyDefault, st));
     const unsigned grid = (unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)ix->num_cu * 16);   // grid-stride: 16 blocks of 4 waves per CU
+#ifdef KR_EXPERIMENT
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_trim_x), &ix->trim[0], sizeof(int), 0, hipMemcpyHostToDevice, st);
+#endif
     if (ix->coarse == KR_COARSE_BF16)
         hipLaunchKernelGGL(k_add_rows<BF16>, dim3(grid), dim3(256), 0, st, dst, ix->xc + ix->n * ix->dpad, n, ix->d, ix->dpad, ix->bounds);
     else

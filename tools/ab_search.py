@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of search-kernel variants selected by environment variables, interleaved rounds in ONE process on one device (guide rule 24).
-Usage: python tools/ab_search.py VAR=a,b [rows] [queries]   e.g. KIRAG_AMD_EPIV=0,1"""
+Usage: python tools/ab_search.py VAR=a,b [rows] [queries]   e.g. KIRAG_AMD_EPIV=0,1;  VAR1+VAR2=a,b sets both variables to the same value"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,7 +17,7 @@ cd = CorpusDist("gaussian", d, dev)
 g = torch.Generator(device=dev); g.manual_seed(3)
 ixs = {}
 for v in vals:                      # the library reads its switches when an index is created: one index per variant (same rows)
-    os.environ[var] = v
+    for one in var.split("+"): os.environ[one] = v
     ixs[v] = FlatIPIndex(d, device=0); ixs[v].reserve(n)
 head = None
 for s0 in range(0, n, 250_000):
@@ -34,13 +34,14 @@ for rnd in range(8):
         for _ in range(3):
             ix.search_into(q, k, sc, rows)
         cs, ts = [], []
+        rr0 = ix.stats()["reranked_rows"]
         for _ in range(5):
             ix.search_into(q, k, sc, rows)
             st = ix.stats(); cs.append(st["last_coarse_ms"]); ts.append(st["last_total_ms"])
-        res[v].append((np.median(cs), np.median(ts)))
+        res[v].append((np.median(cs), np.median(ts), (st["reranked_rows"] - rr0) // 5))
         r = rows.cpu().numpy()
         ref = r if ref is None else ref
         assert os.environ.get("AB_NOCHECK") or np.array_equal(r, ref), "variants disagree"   # AB_NOCHECK=1: diagnostic variants with wrong results
 for v in vals:
     a = np.array(res[v])
-    print(f"{var}={v}: coarse median {np.median(a[:, 0]):.3f} ms (min {a[:, 0].min():.3f}), total median {np.median(a[:, 1]):.3f} ms; per round {np.round(a[:, 0], 3).tolist()}")
+    print(f"{var}={v}: coarse median {np.median(a[:, 0]):.3f} ms (min {a[:, 0].min():.3f}), total median {np.median(a[:, 1]):.3f} ms, re-ranked rows per call {int(a[-1, 2])}; per round {np.round(a[:, 0], 3).tolist()}")
