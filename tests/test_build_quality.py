@@ -45,3 +45,14 @@ def test_hot_kernels_keep_their_occupancy(notes):
         assert k["vgpr_count"] <= 168, k
     for k in find("k_attn_dma"):
         assert k["vgpr_count"] <= 256, k
+
+
+def test_no_kernel_uses_v_ashr_pk_u8_i32():
+    """`v_ashr_pk_u8_i32` (shift two ints right, saturate each to a byte, pack) writes only bits 15:0 of its destination on gfx950, while hipcc's
+    selection pattern (shift -> clamp to [0, 255] -> pack two neighbours) assumes a zero upper half and ORs the stale bits into whatever is packed
+    next to it (tools/ashr_pk_check.hip reproduces it: every result differs in bits 31:16).  Round 4 met it in the residual stream's byte codec
+    (encoder.hip: lo_encode clamps BEFORE the shift for that reason); no product kernel may contain the instruction."""
+    import kernel_notes
+    if not os.path.exists(kernel_notes.OBJDUMP):
+        pytest.skip("llvm-objdump not installed")
+    assert kernel_notes.count_instruction(LIB, "v_ashr_pk_u8_i32") == 0

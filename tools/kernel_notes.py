@@ -39,6 +39,24 @@ def code_objects(path, arch="gfx950"):
         pos = i + 1
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def count_instruction(path, mnemonic, arch="gfx950"):
+    """How often `mnemonic` occurs in the disassembly of the `arch` code objects of `path` (tests/test_build_quality.py: instructions this compiler
+    mis-models on gfx950 must not be selected)."""
+    n = 0
+    for co in code_objects(path, arch):
+        with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
+            f.write(co)
+        try:
+            txt = subprocess.run([OBJDUMP, "-d", "--mcpu=" + arch, f.name], capture_output=True, text=True, check=True).stdout
+            n += len(re.findall(r"\b" + re.escape(mnemonic) + r"\b", txt))
+        finally:
+            os.unlink(f.name)
+    return n
+
+
 def kernels(path, arch="gfx950"):
     """List of dicts (one per kernel): name, vgpr_count, agpr_count, sgpr_count, vgpr_spill_count, sgpr_spill_count,
     private_segment_fixed_size, group_segment_fixed_size (all ints except name)."""
