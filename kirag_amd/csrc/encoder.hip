@@ -507,6 +507,7 @@ __device__ __forceinline__ float2 finalize_row(const float2* __restrict__ part, 
     return make_float2(mu, 1.0f / sqrtf(M2 * inv + eps));
 }
 
+#ifdef KR_EXPERIMENT   // the kernels only the fused forward launches (experiment library)
 // row statistics from the partials the dense epilogues wrote: one thread per row
 __global__ __launch_bounds__(256) void k_row_stats(const float2* __restrict__ part, const int* __restrict__ Tp, int G, float eps, float2* __restrict__ st) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -620,6 +621,8 @@ __global__ void k_add_vec(const float* __restrict__ a, const float* __restrict__
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
 }
+
+#endif   // KR_EXPERIMENT
 
 // ---------------------------------------------------------------------------------------------------------
 // projections: C[token, feature] = X[token, :] . W[feature, :]   (rows = tokens, cols = output features)
