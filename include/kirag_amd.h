@@ -33,7 +33,7 @@ extern "C" {
 #define KR_ESTATE (-1)    /* handle not ready (e.g. encoder weights missing) */
 #define KR_ERANGE (-34)   /* the encoder met non-finite activations (a value outside the f16 operand range, or NaN / Inf weights): results unusable */
 
-#define KR_ABI_VERSION 5
+#define KR_ABI_VERSION 6
 int kr_abi_version(void);
 const char* kr_last_error(void);
 int kr_device_count(void);
@@ -135,6 +135,11 @@ int kr_score_topk(const float* q, int nq, const float* x, int64_t n, int d, int 
  *   scores [nshards,nq,k], ids [nshards,nq,k] (GLOBAL ids) -> out_scores/out_ids [nq,k] by (score desc, id asc).
  *   Host pointers only. */
 int kr_topk_merge(const float* scores, const int64_t* ids, int nshards, int nq, int k, float* out_scores, int64_t* out_ids);
+
+/* Decimal ASCII of n int64 ids, joined by `sep`, no trailing separator: the bulk form of the `str(id)` per hit that Indexer.search_knn returns
+ * (index.py:49 builds 100 k Python strings per 1024-query x top-100 block one at a time — as long as the GPU's whole search of the block; the
+ * host mirror splits this buffer instead).  Host pointers.  cap >= 21 * n always suffices; KR_EINVAL when `out` is too small. */
+int kr_format_ids(const int64_t* ids, int64_t n, char sep, char* out, int64_t cap, int64_t* written);
 
 /* The same merge on the device, for lists that are already in HBM (the output of the all-gather): asynchronous on `stream`, no host round trip.
  *   scores + s * score_shard_stride -> list block [nq,k] of shard s (strides in elements), likewise ids; out_* [nq,k] device (or pinned host) pointers.

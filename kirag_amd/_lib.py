@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KIRAG_AMD_LIB") or os.path.join(_HERE, "libkirag_amd.so")   # KIRAG_AMD_LIB: diagnostic builds (tools/stamp_build.sh)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class KiragAmdError(RuntimeError):
@@ -61,6 +61,7 @@ SIGNATURES = {
     "kr_index_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "kr_score_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kr_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "kr_format_ids": (C.c_int, [C.c_void_p, C.c_int64, C.c_char, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "kr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "kr_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "kr_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -102,12 +103,17 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `make -C kirag_amd/csrc` (or __graft_entry__.build()). "
             "kirag_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    # KIRAG_AMD_LIB_OLDER=1 (tools' same-box A/Bs against an earlier round's library through KIRAG_AMD_LIB): symbols the older build lacks are left
+    # unbound and its ABI number is accepted; never set for the product library
+    older = bool(os.environ.get("KIRAG_AMD_LIB")) and os.environ.get("KIRAG_AMD_LIB_OLDER") == "1"
     for name, (res, args) in SIGNATURES.items():
+        if older and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the build does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
     v = lib.kr_abi_version()
-    if v != ABI_VERSION:
+    if v != ABI_VERSION and not (older and v < ABI_VERSION):
         raise ImportError(f"libkirag_amd ABI {v} != expected {ABI_VERSION}: rebuild the library")
     _lib = lib
     return lib

@@ -66,4 +66,22 @@ int kr_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "debug_vmm_min_reserve_mib") == 0) { kr::g_vmm_min_reserve.store(value <= 0 ? (16ull << 30) : ((unsigned long long)value << 20)); return 0; }
     return kr::fail(KR_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
+int kr_format_ids(const int64_t* ids, int64_t n, char sep, char* out, int64_t cap, int64_t* written) {
+    if (n < 0 || (n > 0 && (!ids || !out)) || !written) return kr::fail(KR_EINVAL, "bad arguments");
+    char* p = out;
+    char* const end = out + cap;
+    for (int64_t i = 0; i < n; ++i) {
+        if (end - p < 21) return kr::fail(KR_EINVAL, "kr_format_ids: output buffer of %lld bytes is too small (21 per id always suffice)", (long long)cap);
+        if (i) *p++ = sep;
+        const int64_t v = ids[i];
+        uint64_t u = v < 0 ? 0ull - (uint64_t)v : (uint64_t)v;     // |INT64_MIN| as unsigned: no overflow
+        char tmp[20];
+        int len = 0;
+        do { tmp[len++] = (char)('0' + (int)(u % 10ull)); u /= 10ull; } while (u);
+        if (v < 0) *p++ = '-';
+        while (len) *p++ = tmp[--len];
+    }
+    *written = (int64_t)(p - out);
+    return 0;
+}
 }

@@ -51,7 +51,7 @@ using ShapeBig = GemmShape<256, 256, 2, 4>;     // 8 waves of 128x64, 128 KiB LD
 //   256x256 ping-pong (gemm_nt_pingpong)          launches with >= 5/8 of the CUs' worth of 256x256 tiles
 //   128x128 producer / consumer (gemm_nt_split)   fewer: at most one tile per CU, or more than two
 //   128x128 streaming, 2 slots, 2 blocks per CU   in between (k_proj<.., ShapeSmall, 2>)
-//   32x32 skinny (gemm_nt_skinny)                 a handful of token rows (<= 4 tiles of 32x32 per CU)
+//   32x32 / 64x64 skinny (gemm_nt_skinny)         a handful of token rows (<= 4 tiles of 32x32 per CU)
 
 using ShapeSmall = GemmShape<128, 128, 2, 2>;   // 4 waves of 64x64, 64 KiB ring, two blocks per CU: for launches with too few 256x256 tiles to fill the chip
 
@@ -67,9 +67,6 @@ struct LayerW {
     uint16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;   // bf16 [out, in]
     float *bqkv = nullptr, *bo = nullptr, *bo_eff = nullptr, *b1 = nullptr, *b2 = nullptr;   // bo_eff = bo + Wo.bv
     float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
-    // fused residual stream (Encoder::fused): fp32 originals of the two weight matrices that absorb a LayerNorm (wqkv / w1 then hold the folded 16-bit
-    // rows of k_fold_ln), their epilogue constants c = W . beta + bias, and beta + bias of the two residual epilogues
-    float *wqkv_f = nullptr, *w1_f = nullptr, *cqkv = nullptr, *c1 = nullptr, *rb1 = nullptr, *rb2 = nullptr;
 };
 
 // A/B switches of the projection / attention launches, read from the environment ONCE per forward (enqueue_forward), not per launch: a forward is 96
@@ -83,12 +80,6 @@ struct Knobs {
     int force_tile = 0;    // KIRAG_AMD_PROJ_TILE: 32 / 128 / 130 / 256 force a projection path (tests run every parity case through all of them)
     int ratio8 = 5;        // KIRAG_AMD_SMALL_RATIO: eighths of the CU count below which the 128x128 tiling is used (tools/ab_encoder.py)
     bool attn_lds = false, attn_dma = false;   // KIRAG_AMD_ATTN_LDS / KIRAG_AMD_ATTN_DMA: force one attention kernel (A/B)
-#ifdef KR_EXPERIMENT
-    int skip_from = 99, qkv_nt = -1; bool nt_ctx = false, nt_qkv = false;
-    int ln_pol = 7, ln_grid = 0;
-    int dbg_rows = 0;         // KIRAG_AMD_DBG_ROWS=n with SYNC_EACH: value summaries of the first n token rows after every step of the first two layers
-    bool sync_each = false;   // KIRAG_AMD_SYNC_EACH=1: the fused forward waits after every launch and names it on stderr (which kernel faults?)
-#endif
     void read() {
         auto geti = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         pw = geti("KIRAG_AMD_PATCH_W", 8); if (pw < 1) pw = 8;
@@ -99,14 +90,6 @@ struct Knobs {
         ratio8 = geti("KIRAG_AMD_SMALL_RATIO", 5);
         attn_lds = getenv("KIRAG_AMD_ATTN_LDS") != nullptr;
         attn_dma = geti("KIRAG_AMD_ATTN_DMA", 0) != 0;
-#ifdef KR_EXPERIMENT
-        skip_from = geti("KIRAG_AMD_SKIP_STORES_FROM", 99);
-        qkv_nt = geti("KIRAG_AMD_QKV_NT", -1);
-        nt_ctx = geti("KIRAG_AMD_NT_CTX", 0) != 0;
-        nt_qkv = geti("KIRAG_AMD_NT_QKV", 0) != 0;
-        ln_pol = geti("KIRAG_AMD_LN_POL", 7); ln_grid = geti("KIRAG_AMD_LN_GRID", 0);
-        sync_each = geti("KIRAG_AMD_SYNC_EACH", 0) != 0; dbg_rows = geti("KIRAG_AMD_DBG_ROWS", 0);
-#endif
     }
 };
 
@@ -143,11 +126,6 @@ struct Encoder {
     // CLS pooling: the LAST layer's attention output / FFN only matter for one row per sequence.  Those rows are gathered into compact [B, ...] buffers
     // after the last attention and the rest of the layer runs on B rows instead of T (KIRAG_AMD_CLS_FULL=1 at kr_encoder_create: all rows, A/B and tests)
     bool cls_shortcut = true, last_shortcut = false;
-    // fused residual stream (KIRAG_AMD_FUSED_LN at kr_encoder_create; see "Fused residual stream" below): row statistics of the two live LayerNorm sites,
-    // the group partials the dense epilogues write, and their compact twins for the CLS shortcut
-    bool fused = false;
-    float2 *stA = nullptr, *stB = nullptr, *part = nullptr, *c_stA = nullptr, *c_stB = nullptr, *c_part = nullptr;
-    mutable bool last_skinny = false;   // the last launch_proj took the 32x32-tile path (its residual epilogue leaves the statistics to k_row_stats_direct)
     uint16_t *c_ctx = nullptr, *c_xb = nullptr, *c_y = nullptr, *c_h = nullptr; uint8_t* c_xlo = nullptr;
     int *c_off = nullptr, *c_nk = nullptr, *c_cls = nullptr, *d_B = nullptr;
 };
@@ -282,7 +260,7 @@ __device__ __forceinline__ float unpack_hi16(unsigned int w) {
 // distance in fp32 ulps, signed towards larger magnitude, and 2^LO_SH of those are ulp(hi) / 256 (a unit half as large when hi rounded up into the next
 // binade: still within +-128).  Encode = subtract, add the rounding constant, shift, clamp (4 integer instructions); decode = shift-add + constant (3, the
 // byte extraction included) — a third of the floating-point form (exponent extraction, two constructed powers of two, rint, min, max, conversions) that made
-// the fused residual epilogue VALU-bound.  |x| < 2^-25 (hi = +-0) clamps to a denormal: an absolute error below 2^-25.
+// round 4's fused residual epilogue VALU-bound (profiles/r04/tried_fused_layernorm.txt).  |x| < 2^-25 (hi = +-0) clamps to a denormal: an absolute error below 2^-25.
 #ifdef KR_ENC_BUILD_F16
 constexpr int LO_SH = 5;        // 23 - 10 stored mantissa bits - 8
 #else
@@ -363,64 +341,45 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ tok_id
     ln_row_store(v, H, lane, g, bta, eps, xlo ? xlo + t * H : nullptr, xb + t * H);
 }
 
-// k_ln with 16-byte accesses: a lane owns 8 consecutive elements per 512-element step (one global_load_dwordx4 per tensor and step instead of two
-// 8-byte ones: 8-byte accesses reach 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md).  NS 512-element steps cover a row (H <= 512 NS, H % 8 == 0).
-// Same arithmetic per element as k_ln; the row sums add the elements in a different lane order (tolerances of DESIGN.md section 2 unaffected; rows stay
-// independent of the batch).  KIRAG_AMD_LN8=1 selects the 8-byte kernel (A/B).
-// POL (cache policy of the streams; profiles/r04/tried_ln_policies.txt): bit 0 = y loaded non-temporally (dead after this kernel), bit 1 = the low half loaded
-// non-temporally, bit 2 = the low half stored non-temporally (its next reader is the next LayerNorm, ~600 MiB of traffic later)
-template <int NS, int POL = 0>
-__global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, const float* __restrict__ ybias, const int* __restrict__ Tp, const float* __restrict__ g,
-                                              const float* __restrict__ bta, float eps, int H, const uint8_t* xlo_in, uint8_t* xlo, uint16_t* xb) {
-    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-    const int lane = threadIdx.x & 63;
-    const int T = *Tp;
-    float gg[NS][8], bb[NS][8], yb[NS][8];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int i = lane * 8 + j * 512;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { gg[j][c] = 0.f; bb[j][c] = 0.f; yb[j][c] = 0.f; }
-        if (i < H) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4 a = *reinterpret_cast<const float4*>(g + i + 4 * h), b = *reinterpret_cast<const float4*>(bta + i + 4 * h), c = *reinterpret_cast<const float4*>(ybias + i + 4 * h);
-                gg[j][4 * h] = a.x; gg[j][4 * h + 1] = a.y; gg[j][4 * h + 2] = a.z; gg[j][4 * h + 3] = a.w;
-                bb[j][4 * h] = b.x; bb[j][4 * h + 1] = b.y; bb[j][4 * h + 2] = b.z; bb[j][4 * h + 3] = b.w;
-                yb[j][4 * h] = c.x; yb[j][4 * h + 1] = c.y; yb[j][4 * h + 2] = c.z; yb[j][4 * h + 3] = c.w;
-            }
-        }
-    }
-    const int64_t step = (int64_t)gridDim.x * 4;
-    int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    uint4 a[NS], rh[NS]; uint2 rl[NS];
-    auto load_row = [&](int64_t row) {
+// LayerNorm(y + bias + residual) with 16-byte accesses: a lane owns 8 consecutive elements per 512-element step (one global_load_dwordx4 per tensor and step:
+// 8-byte accesses reach 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md).  NS 512-element steps cover a row (H <= 512 NS, H % 8 == 0).
+// The row arithmetic lives in Ln16<NS> (one definition for every kernel that normalises a row).
+template <int NS>
+struct Ln16 {
+    float gg[NS][8], bb[NS][8], yb[NS][8];     // gamma, beta, the projection's bias (added in fp32) of the lane's elements
+    __device__ __forceinline__ void load_params(const float* __restrict__ g, const float* __restrict__ bta, const float* __restrict__ ybias, int H, int lane) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int i = lane * 8 + j * 512;
-            a[j] = rh[j] = make_uint4(0u, 0u, 0u, 0u); rl[j] = make_uint2(0x80808080u, 0x80808080u);      // byte 128 = a zero low half
-            if (i < H && row < T) {
-                a[j] = (POL & 1) ? __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(y + row * H + i))) : *reinterpret_cast<const uint4*>(y + row * H + i);
-                rh[j] = *reinterpret_cast<const uint4*>(xb + row * H + i);
-                if (xlo_in) rl[j] = (POL & 2) ? __builtin_bit_cast(uint2, __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(xlo_in + row * H + i))) : *reinterpret_cast<const uint2*>(xlo_in + row * H + i);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { gg[j][c] = 0.f; bb[j][c] = 0.f; yb[j][c] = 0.f; }
+            if (i < H) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 a = *reinterpret_cast<const float4*>(g + i + 4 * h), b = *reinterpret_cast<const float4*>(bta + i + 4 * h), c = *reinterpret_cast<const float4*>(ybias + i + 4 * h);
+                    gg[j][4 * h] = a.x; gg[j][4 * h + 1] = a.y; gg[j][4 * h + 2] = a.z; gg[j][4 * h + 3] = a.w;
+                    bb[j][4 * h] = b.x; bb[j][4 * h + 1] = b.y; bb[j][4 * h + 2] = b.z; bb[j][4 * h + 3] = b.w;
+                    yb[j][4 * h] = c.x; yb[j][4 * h + 1] = c.y; yb[j][4 * h + 2] = c.z; yb[j][4 * h + 3] = c.w;
+                }
             }
         }
-    };
-    auto lo16 = [](unsigned int w) { return unpack_lo16(w); };
-    auto hi16 = [](unsigned int w) { return unpack_hi16(w); };
-    load_row(t);
-    for (; t < T; t += step) {
-        float v[NS][8];
+    }
+    // v = (y + bias) + residual, the residual decoded from its 16-bit half and its low-half byte
+    __device__ __forceinline__ void combine(const uint4 (&a)[NS], const uint4 (&rh)[NS], const uint2 (&rl)[NS], float (&v)[NS][8]) const {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const unsigned int aw[4] = {a[j].x, a[j].y, a[j].z, a[j].w}, hw[4] = {rh[j].x, rh[j].y, rh[j].z, rh[j].w}, lw[2] = {rl[j].x, rl[j].y};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {   // elements 2c, 2c + 1: low-half bytes 2c, 2c + 1 of the 8
-                v[j][2 * c] = (lo16(aw[c]) + yb[j][2 * c]) + lo_decode((lw[c >> 1] >> (16 * (c & 1))) & 0xffu, lo16(hw[c]));
-                v[j][2 * c + 1] = (hi16(aw[c]) + yb[j][2 * c + 1]) + lo_decode((lw[c >> 1] >> (16 * (c & 1) + 8)) & 0xffu, hi16(hw[c]));
+                v[j][2 * c] = (unpack_lo16(aw[c]) + yb[j][2 * c]) + lo_decode((lw[c >> 1] >> (16 * (c & 1))) & 0xffu, unpack_lo16(hw[c]));
+                v[j][2 * c + 1] = (unpack_hi16(aw[c]) + yb[j][2 * c + 1]) + lo_decode((lw[c >> 1] >> (16 * (c & 1) + 8)) & 0xffu, unpack_hi16(hw[c]));
             }
         }
-        load_row(t + step);                                   // next row's loads in flight while this one is reduced and stored
+    }
+    // mean / variance over the wave, normalise, store the 16-bit row and (xlo_row != nullptr) its low-half bytes.  NTS: the low half stored non-temporally
+    template <bool NTS>
+    __device__ __forceinline__ void normalize_store(const float (&v)[NS][8], int H, float eps, int lane, uint16_t* xb_row, uint8_t* xlo_row) const {
+        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NS; ++j)
@@ -439,8 +398,6 @@ __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, co
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
         const float rstd = 1.0f / sqrtf(q / (float)H + eps);
-        uint16_t* xb_row = xb + t * H;
-        uint8_t* xlo_row = xlo ? xlo + t * H : nullptr;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int i = lane * 8 + j * 512;
@@ -456,173 +413,50 @@ __global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, co
                     ol[0] = ol[1] = 0u;
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        ol[c >> 1] |= (lo_encode(o[2 * c], lo16(ob[c])) | (lo_encode(o[2 * c + 1], hi16(ob[c])) << 8)) << (16 * (c & 1));
-                    if (POL & 4) __builtin_nontemporal_store(u32x2_t{ol[0], ol[1]}, reinterpret_cast<u32x2_t*>(xlo_row + i));
+                        ol[c >> 1] |= (lo_encode(o[2 * c], unpack_lo16(ob[c])) | (lo_encode(o[2 * c + 1], unpack_hi16(ob[c])) << 8)) << (16 * (c & 1));
+                    if constexpr (NTS) __builtin_nontemporal_store(u32x2_t{ol[0], ol[1]}, reinterpret_cast<u32x2_t*>(xlo_row + i));
                     else *reinterpret_cast<uint2*>(xlo_row + i) = make_uint2(ol[0], ol[1]);
                 }
             }
         }
     }
-}
+};
 
-// ---------------------------------------------------------------------------------------------------------
-// Fused residual stream (KIRAG_AMD_FUSED_LN, "z-stream"): no LayerNorm pass between the GEMMs.
-//   * (xb, xlo) hold z = the PRE-LayerNorm sum of a site (embedding sum, attention output + residual, FFN output + residual) as (hi, lo); a second
-//     array holds the site's row statistics (mean, rstd).
-//   * the LayerNorm is applied where the row is consumed: gamma is folded into the next GEMM's weights, the mean subtraction too (a row of
-//     gamma o W minus its own mean annihilates the row mean of z), so that GEMM's epilogue is  out = rstd[token] * acc + c[feature]  with
-//     c = W . beta + bias (k_fold_ln);  the residual h = (z - mean) * rstd * gamma + beta is recomputed from (hi, lo) inside the next dense
-//     epilogue (store_rows_resid), which adds the projection, re-encodes z' = y + h as (hi, lo) IN PLACE and emits the partial row statistics.
-//   * statistics are CANONICAL: a pure function of the stored bytes with a fixed operation order (group_stats64 per 64 features, finalize_row over
-//     the groups in order), so every tiling / kernel that produces them gives the same bits (batch invariance, the embedding cache).
-// Bytes per element and LayerNorm site: 3 read + 3 written inside the dense epilogue instead of 2 written there + 8 through k_ln16.
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dpp_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)); }      // quad_perm [1,0,3,2]
-__device__ __forceinline__ float dpp_xor2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)); }      // quad_perm [2,3,0,1]
-__device__ __forceinline__ float dpp_hmirror(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true)); }  // lane i <-> 7 - i of its 8
-
-// (sum, M2 about the group mean) of 64 consecutive stored values held 8 per lane by 8 consecutive lanes; every one of the 8 lanes gets the result
-__device__ __forceinline__ void group_stats64(const float (&z)[8], float& s_out, float& q_out) {
-#pragma clang fp contract(off)
-    float s = z[0];
+// one wave per token row, grid-stride.  Same arithmetic per element as round 1's 8-byte k_ln; the row sums add the elements in the lane order of Ln16
+// (rows stay independent of the batch).
+// POL (cache policy of the streams; profiles/r04/tried_ln_policies.txt): bit 0 = y loaded non-temporally (dead after this kernel), bit 1 = the low half loaded
+// non-temporally, bit 2 = the low half stored non-temporally (its next reader is the next LayerNorm, ~600 MiB of traffic later)
+template <int NS, int POL = 0>
+__global__ __launch_bounds__(256) void k_ln16(const uint16_t* __restrict__ y, const float* __restrict__ ybias, const int* __restrict__ Tp, const float* __restrict__ g,
+                                              const float* __restrict__ bta, float eps, int H, const uint8_t* xlo_in, uint8_t* xlo, uint16_t* xb) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+    const int lane = threadIdx.x & 63;
+    const int T = *Tp;
+    Ln16<NS> ln;
+    ln.load_params(g, bta, ybias, H, lane);
+    const int64_t step = (int64_t)gridDim.x * 4;
+    int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint4 a[NS], rh[NS]; uint2 rl[NS];
+    auto load_row = [&](int64_t row) {
 #pragma unroll
-    for (int j = 1; j < 8; ++j) s = s + z[j];
-    s = s + dpp_xor1(s); s = s + dpp_xor2(s); s = s + dpp_hmirror(s);   // after two steps a quad is uniform: the half mirror pairs the two quads
-    const float m = s * 0.015625f;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const float d = z[j] - m; q = __builtin_fmaf(d, d, q); }
-    q = q + dpp_xor1(q); q = q + dpp_xor2(q); q = q + dpp_hmirror(q);
-    s_out = s; q_out = q;
-}
-// (mean, rstd) of a row from its G = H / 64 group partials, groups in order (Chan's merge with equal group sizes)
-__device__ __forceinline__ float2 finalize_row(const float2* __restrict__ part, int G, float eps) {
-#pragma clang fp contract(off)
-    float S = 0.f;
-    for (int g = 0; g < G; ++g) S = S + part[g].x;
-    const float inv = 1.0f / (float)(G * 64);
-    const float mu = S * inv;
-    float M2 = 0.f;
-    for (int g = 0; g < G; ++g) { const float dm = part[g].x * 0.015625f - mu; M2 = M2 + __builtin_fmaf(dm * 64.f, dm, part[g].y); }
-    return make_float2(mu, 1.0f / sqrtf(M2 * inv + eps));
-}
-
-#ifdef KR_EXPERIMENT   // the kernels only the fused forward launches (experiment library)
-// row statistics from the partials the dense epilogues wrote: one thread per row
-__global__ __launch_bounds__(256) void k_row_stats(const float2* __restrict__ part, const int* __restrict__ Tp, int G, float eps, float2* __restrict__ st) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= *Tp) return;
-    st[t] = finalize_row(part + t * G, G, eps);
-}
-
-// row statistics straight from the stored (hi, lo) rows (embedding output, 32x32-tile projections): one wave per row, the same canonical order
-template <int NS>
-__global__ __launch_bounds__(256) void k_row_stats_direct(const uint16_t* __restrict__ xb, const uint8_t* __restrict__ xlo, const int* __restrict__ Tp, int H, float eps,
-                                                          float2* __restrict__ st) {
-    __shared__ float2 part[4][NS * 8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
-    if (t >= *Tp) return;                                  // wave-uniform; no block barrier below
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int i = lane * 8 + j * 512;
-        if (i < H) {
-            const uint4 hw = *reinterpret_cast<const uint4*>(xb + t * H + i);
-            const uint2 lw = xlo ? *reinterpret_cast<const uint2*>(xlo + t * H + i) : make_uint2(0x80808080u, 0x80808080u);
-            const unsigned int hh[4] = {hw.x, hw.y, hw.z, hw.w}, ll[2] = {lw.x, lw.y};
-            float z[8];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                z[2 * c] = lo_decode((ll[c >> 1] >> (16 * (c & 1))) & 0xffu, unpack_lo16(hh[c]));
-                z[2 * c + 1] = lo_decode((ll[c >> 1] >> (16 * (c & 1) + 8)) & 0xffu, unpack_hi16(hh[c]));
+        for (int j = 0; j < NS; ++j) {
+            const int i = lane * 8 + j * 512;
+            a[j] = rh[j] = make_uint4(0u, 0u, 0u, 0u); rl[j] = make_uint2(0x80808080u, 0x80808080u);      // byte 128 = a zero low half
+            if (i < H && row < T) {
+                a[j] = (POL & 1) ? __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(y + row * H + i))) : *reinterpret_cast<const uint4*>(y + row * H + i);
+                rh[j] = *reinterpret_cast<const uint4*>(xb + row * H + i);
+                if (xlo_in) rl[j] = (POL & 2) ? __builtin_bit_cast(uint2, __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(xlo_in + row * H + i))) : *reinterpret_cast<const uint2*>(xlo_in + row * H + i);
             }
-            float sg, qg;
-            group_stats64(z, sg, qg);
-            if ((lane & 7) == 0) part[wave][j * 8 + (lane >> 3)] = make_float2(sg, qg);
         }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the wave's own LDS writes have landed (one wave per row: no barrier needed)
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) st[t] = finalize_row(part[wave], H >> 6, eps);
-}
-
-// the LayerNorm of a site applied for good: (hi, lo) of z -> (hi, lo) of h = (z - mean) * rstd * gamma + beta, in place (before pooling / kr_encoder_last_hidden)
-template <int NS>
-__global__ __launch_bounds__(256) void k_ln_apply(const int* __restrict__ Tp, const float2* __restrict__ st, const float* __restrict__ g, const float* __restrict__ bta, int H,
-                                                  uint8_t* xlo, uint16_t* xb) {
-    const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= *Tp) return;
-    const float2 ms = st[t];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int i = lane * 8 + j * 512;
-        if (i < H) {
-            const uint4 hw = *reinterpret_cast<const uint4*>(xb + t * H + i);
-            const uint2 lw = *reinterpret_cast<const uint2*>(xlo + t * H + i);
-            const unsigned int hh[4] = {hw.x, hw.y, hw.z, hw.w}, ll[2] = {lw.x, lw.y};
-            float gg[8], bb[8];
-            *reinterpret_cast<float4*>(gg) = *reinterpret_cast<const float4*>(g + i); *reinterpret_cast<float4*>(gg + 4) = *reinterpret_cast<const float4*>(g + i + 4);
-            *reinterpret_cast<float4*>(bb) = *reinterpret_cast<const float4*>(bta + i); *reinterpret_cast<float4*>(bb + 4) = *reinterpret_cast<const float4*>(bta + i + 4);
-            unsigned int ob[4], ol[2] = {0u, 0u};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float z0 = lo_decode((ll[c >> 1] >> (16 * (c & 1))) & 0xffu, unpack_lo16(hh[c]));
-                const float z1 = lo_decode((ll[c >> 1] >> (16 * (c & 1) + 8)) & 0xffu, unpack_hi16(hh[c]));
-                const float o0 = fmaf((z0 - ms.x) * ms.y, gg[2 * c], bb[2 * c]), o1 = fmaf((z1 - ms.x) * ms.y, gg[2 * c + 1], bb[2 * c + 1]);
-                ob[c] = pack_bf16x2(o0, o1);
-                ol[c >> 1] |= (lo_encode(o0, unpack_lo16(ob[c])) | (lo_encode(o1, unpack_hi16(ob[c])) << 8)) << (16 * (c & 1));
-            }
-            *reinterpret_cast<uint4*>(xb + t * H + i) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
-            *reinterpret_cast<uint2*>(xlo + t * H + i) = make_uint2(ol[0], ol[1]);
-        }
+    };
+    load_row(t);
+    for (; t < T; t += step) {
+        float v[NS][8];
+        ln.combine(a, rh, rl, v);
+        load_row(t + step);                                   // next row's loads in flight while this one is reduced and stored
+        ln.template normalize_store<(POL & 4) != 0>(v, H, eps, lane, xb + t * H, xlo ? xlo + t * H : nullptr);
     }
 }
-
-// embeddings for the fused stream: word[id] + position[pos] + token_type -> z as (hi, lo), NO LayerNorm (its gamma / beta are folded into layer 0)
-__global__ __launch_bounds__(256) void k_embed_z(const int* __restrict__ tok_id, const int* __restrict__ tok_pos, const int* __restrict__ tok_type, const int* __restrict__ Tp,
-                                                 const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type, int H,
-                                                 uint8_t* __restrict__ xlo, uint16_t* __restrict__ xb) {
-    const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= *Tp) return;
-    const float* w = word + (int64_t)tok_id[t] * H;
-    const float* p = pos + (int64_t)tok_pos[t] * H;
-    const float* ty = type + (int64_t)tok_type[t] * H;
-    for (int i = lane * 4; i < H; i += 256) {
-        const float4 a = *reinterpret_cast<const float4*>(w + i), b = *reinterpret_cast<const float4*>(p + i), c = *reinterpret_cast<const float4*>(ty + i);
-        const float4 o = make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
-        ushort4 ob;
-        ob.x = ET::from_f32(o.x); ob.y = ET::from_f32(o.y); ob.z = ET::from_f32(o.z); ob.w = ET::from_f32(o.w);
-        *reinterpret_cast<ushort4*>(xb + t * H + i) = ob;
-        if (xlo)
-            *reinterpret_cast<unsigned int*>(xlo + t * H + i) = lo_encode(o.x, ET::to_f32(ob.x)) | (lo_encode(o.y, ET::to_f32(ob.y)) << 8) |
-                                                                (lo_encode(o.z, ET::to_f32(ob.z)) << 16) | (lo_encode(o.w, ET::to_f32(ob.w)) << 24);
-    }
-}
-
-// weight fold for the fused stream: row n of W (fp32, [F, K]) -> 16-bit (gamma o W[n,:]) * scale minus its mean, and c[n] = scale * (W[n,:] . beta) + bias[n]
-// (bias already carries the scale).  One wave per output feature; the sums run in a fixed order.
-__global__ __launch_bounds__(256) void k_fold_ln(const float* __restrict__ W, const float* __restrict__ g, const float* __restrict__ bta, const float* __restrict__ bias,
-                                                 float scale, int F, int K, uint16_t* __restrict__ W16, float* __restrict__ c) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= F) return;
-    const float* w = W + (int64_t)n * K;
-    float sw = 0.f, sb = 0.f;
-    for (int k = lane; k < K; k += 64) { sw += w[k] * g[k]; sb += w[k] * bta[k]; }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { sw += __shfl_xor(sw, m, 64); sb += __shfl_xor(sb, m, 64); }
-    const float mean = sw / (float)K;
-    for (int k = lane; k < K; k += 64) W16[(int64_t)n * K + k] = ET::from_f32((w[k] * g[k] - mean) * scale);
-    if (lane == 0) c[n] = scale * sb + bias[n];
-}
-__global__ void k_add_vec(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] + b[i];
-}
-
-#endif   // KR_EXPERIMENT
 
 // ---------------------------------------------------------------------------------------------------------
 // projections: C[token, feature] = X[token, :] . W[feature, :]   (rows = tokens, cols = output features)
@@ -634,19 +468,12 @@ struct ProjArgs {
     int64_t ldx, ldo;   // row pitch (elements) of X and of out0 (EPI_DENSE / EPI_GELU); 0 = K / F
     int pw;   // feature tiles per XCD patch of the tile walk (patch_coord)
     int epi_prio;   // A/B knob, see proj_epilogue
-    int skip_from;  // experiment builds: first token block (of 4) whose global stores are skipped (99 = none)
     int ant;  // activation loads non-temporal (FF2's h: launch_proj)
     int nt;   // epilogue stores non-temporal (large launches: the output is consumed from HBM by the next kernel, keep it out of L2) or plain
               // (small launches: the whole output fits in L2 / Infinity Cache, the next kernel reads it from there)
-    // fused residual stream (EPI_QKV_S / EPI_GELU_S / EPI_RES; see "Fused residual stream" above)
-    const float2* st_in;   // (mean, rstd) per token row of the LayerNorm site the activation operand (QKV_S / GELU_S) or the residual (RES) belongs to
-    const float* ln_g; const float* ln_bb;   // EPI_RES: gamma of that site, and beta + this projection's bias
-    uint8_t* xlo;          // EPI_RES: low half of the residual stream, read and rewritten in place together with out0 (= xb); nullptr = none
-    float2* part;          // EPI_RES: [rows, F / 64] (sum, M2) of each 64-feature group of the new residual row (k_row_stats)
 };
 
-// *_S: the activation operand is a pre-LayerNorm z row, bias = c of k_fold_ln: out = rstd[token] * acc + c[feature];  RES: see store_rows_resid
-enum { EPI_QKV = 0, EPI_DENSE = 1, EPI_GELU = 2, EPI_QKV_S = 3, EPI_RES = 4, EPI_GELU_S = 5 };
+enum { EPI_QKV = 0, EPI_DENSE = 1, EPI_GELU = 2 };
 
 // erf-GELU x Phi(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2), with erfc(a / sqrt 2) = 2^-Q(a), Q(a) = a (c1 + c2 a + c3 a^2 + c4 a^3 + c5 a^4) a weighted
 // minimax fit of -log2 erfc on [0, 8] (weight a erfc(a / sqrt 2) = the sensitivity of the result; fitted offline, c5 > 0 so Q keeps growing and the
@@ -683,7 +510,7 @@ constexpr int EPI_STAGE_BYTES = 4096;
 // consecutive features -> one packed ds_write_b64 (16-B chunk index XOR (token & 7): 2-way instead of 16-way conflicts), read back 16 B
 // per lane: every global store instruction writes eight whole 128-B rows.  f(v, mi, ni, g) maps 4 features (bias / GELU / row scale) before packing.
 template <class Shape, bool NT, class F>
-__device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ out, int64_t ld, int64_t row0, int col0, F&& f, int skip_from = 99) {
+__device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ out, int64_t ld, int64_t row0, int col0, F&& f) {
     static_assert(Shape::TN == 2, "stage geometry assumes 64 features per wave");
     const int c = acc.lane & 31, h = acc.lane >> 5;
     const int r8 = acc.lane >> 3, ch = acc.lane & 7;
@@ -711,9 +538,6 @@ __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage
 #pragma unroll
             for (int p = 0; p < 4; ++p) d[mi & 1][p] = *reinterpret_cast<const uint4*>(st_rd + p * 8 * 128);
         }
-#ifdef KR_EXPERIMENT
-        if (mi > 0 && mi - 1 >= skip_from) continue;   // diagnostic (wrong output): the global stores of the later token blocks are skipped — what would trickling them buy?
-#endif
         if (mi > 0) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {  // rl & 7 == lane >> 3 for every p: one lane-dependent LDS / global base, the rest are wave-uniform steps (8 rows per store)
@@ -728,135 +552,10 @@ __device__ __forceinline__ void store_rows_bf16(AccTile<Shape>& acc, char* stage
 #endif
 }
 
-// fused stream: out = rstd * acc + c as ONE fma per element in every kernel that computes it (explicit: no dependence on the contraction mode)
-__device__ __forceinline__ f32x4 row_scale_bias(f32x4 v, float r, f32x4 c) { return __builtin_elementwise_fma(v, f32x4{r, r, r, r}, c); }
-
-// new residual element: y (the dense output, already rounded to the 16-bit type) + the LayerNorm of the old one; ONE definition for every tiling
-__device__ __forceinline__ float resid_elem(float y, float z_old, float mu, float rstd, float g, float bb) {
-#pragma clang fp contract(off)
-    const float t = (z_old - mu) * rstd;
-    return y + __builtin_fmaf(t, g, bb);
-}
-
-// EPI_RES (fused residual stream): the dense output y (rounded to the 16-bit type exactly like the y array of the LayerNorm path) goes through the same
-// wave-private LDS stage; in the read-back layout a lane holds 8 consecutive features of one token row, and there the residual is finished:
-//     z_old = decode(hi, lo)                         the site's pre-LayerNorm row, read from xb / xlo
-//     h     = (z_old - mean) * rstd * gamma + (beta + bias)
-//     z_new = y + h  ->  (hi, lo) written back IN PLACE;  (sum, M2) of the lane group's 64 stored values -> part[row, feature group]
-// The residual loads of token block mi are issued before block mi is staged and consumed one block later (double-buffered), so only the first round
-// trip of a tile is exposed.
-template <class Shape, bool NT, bool HAS_LO>
-__device__ __forceinline__ void store_rows_resid(AccTile<Shape>& acc, char* stage, const ProjArgs& a, int64_t row0, int col0) {
-    static_assert(Shape::TN == 2, "stage geometry assumes 64 features per wave");
-    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-    int ln = acc.lane;
-    asm volatile("" : "+v"(ln));                     // per-lane address math is recomputed per tile instead of living in registers across the main loop
-    const int c = ln & 31, h = ln >> 5;
-    const int r8 = ln >> 3, ch = ln & 7;
-    const char* st_rd = stage + r8 * 128 + ((ch ^ r8) << 4);
-    const int ld = (int)a.ldo, G = a.F >> 6;
-    // Buffer addressing: the wave's corner (row0, col0) is wave-uniform and goes into the resource base; a lane keeps ONE 32-bit offset per stream and
-    // the (token block, row group) steps are scalar offsets.  With flat 64-bit addresses the 16 (hi, lo) address pairs of a tile stayed live from each
-    // load to the store that rewrites the same bytes: ~60 VGPRs this epilogue does not have (it spilled).
-    // (readfirstlane returns int: both halves go through uint32_t before they are widened, or a low half >= 2^31 sign-extends into the high one)
-    auto uni = [](uint64_t v) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-        return ((uint64_t)hi << 32) | (uint64_t)lo;
-    };
-    const int64_t corner = row0 * ld + col0;
-    constexpr int ROWS = Shape::TM * 32;
-    const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(uni(reinterpret_cast<uint64_t>(a.out0 + corner))), 0, ROWS * ld * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_lo = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(uni(reinterpret_cast<uint64_t>(a.xlo + corner))), 0, HAS_LO ? ROWS * ld : 0, 0x00020000);
-    // statistics / partials: plain global accesses off a wave-uniform base (a scalar pair + a 32-bit lane offset + an immediate; four resources instead of
-    // two cost 28 spilled SGPRs in the 256x256 kernel)
-    const float2* __restrict__ st_base = reinterpret_cast<const float2*>(uni(reinterpret_cast<uint64_t>(a.st_in + row0)));
-    float2* __restrict__ pt_base = reinterpret_cast<float2*>(uni(reinterpret_cast<uint64_t>(a.part + row0 * G + (col0 >> 6))));
-    const int o_lo = r8 * ld + ch * 8, o_hi = o_lo * 2;   // bytes
-    constexpr bool has_lo = HAS_LO;   // compile-time: as a run-time flag it cost a (uniform) branch and a register merge per element pair
-    float gg[8], bb[8];
-    *reinterpret_cast<float4*>(gg) = *reinterpret_cast<const float4*>(a.ln_g + col0 + ch * 8); *reinterpret_cast<float4*>(gg + 4) = *reinterpret_cast<const float4*>(a.ln_g + col0 + ch * 8 + 4);
-    *reinterpret_cast<float4*>(bb) = *reinterpret_cast<const float4*>(a.ln_bb + col0 + ch * 8); *reinterpret_cast<float4*>(bb + 4) = *reinterpret_cast<const float4*>(a.ln_bb + col0 + ch * 8 + 4);
-    u32x4_t d[4], rh[2][4]; u32x2_t rl[2][4]; float2 rs[2][4];
-    // iteration mi: (a) issue the residual loads of block mi, (b) finish block mi - 1 (its y comes from the stage read at the end of the previous
-    // iteration, its residual from the loads of the previous iteration), (c) stage block mi and read it back.  One y buffer: (c) follows (b).
-#pragma unroll
-    for (int mi = 0; mi <= Shape::TM; ++mi) {
-        if (mi < Shape::TM) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int rr = mi * 32 + p * 8;                 // row of the group inside the wave's block (scalar)
-                rh[mi & 1][p] = __builtin_amdgcn_raw_buffer_load_b128(r_hi, o_hi, rr * ld * 2, 0);
-                if constexpr (HAS_LO) rl[mi & 1][p] = __builtin_amdgcn_raw_buffer_load_b64(r_lo, o_lo, rr * ld, 0);
-                rs[mi & 1][p] = st_base[r8 + rr];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (mi > 0) {
-            const int b = (mi - 1) & 1;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int rr = (mi - 1) * 32 + p * 8;
-                const unsigned int yw[4] = {d[p].x, d[p].y, d[p].z, d[p].w}, hw[4] = {rh[b][p].x, rh[b][p].y, rh[b][p].z, rh[b][p].w};
-                const unsigned int lw[2] = {has_lo ? rl[b][p].x : 0x80808080u, has_lo ? rl[b][p].y : 0x80808080u};
-                const float mu = rs[b][p].x, rstd = rs[b][p].y;
-                float zq[8];
-                unsigned int ob[4], ol[2] = {0u, 0u};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float z0 = lo_decode((lw[k >> 1] >> (16 * (k & 1))) & 0xffu, unpack_lo16(hw[k]));
-                    const float z1 = lo_decode((lw[k >> 1] >> (16 * (k & 1) + 8)) & 0xffu, unpack_hi16(hw[k]));
-                    const float n0 = resid_elem(unpack_lo16(yw[k]), z0, mu, rstd, gg[2 * k], bb[2 * k]);
-                    const float n1 = resid_elem(unpack_hi16(yw[k]), z1, mu, rstd, gg[2 * k + 1], bb[2 * k + 1]);
-                    ob[k] = pack_bf16x2(n0, n1);
-                    const float h0 = unpack_lo16(ob[k]), h1 = unpack_hi16(ob[k]);
-                    if (has_lo) {
-                        const unsigned int e0b = lo_encode(n0, h0), e1b = lo_encode(n1, h1);
-                        ol[k >> 1] |= (e0b | (e1b << 8)) << (16 * (k & 1));
-                        zq[2 * k] = lo_decode(e0b, h0); zq[2 * k + 1] = lo_decode(e1b, h1);
-                    } else {
-                        zq[2 * k] = h0; zq[2 * k + 1] = h1;
-                    }
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ob[0], ob[1], ob[2], ob[3]}, r_hi, o_hi, rr * ld * 2, 0);
-                // VMEM store-data hazard: a 16-byte buffer store WITH A SCALAR OFFSET REGISTER still reads its data registers for a few cycles after issue, and
-                // this compiler's hazard recogniser only pads the immediate-offset form.  Without the wait the first VALU instruction of the statistics below
-                // (which reuses data register 0) corrupted dword 0 of the store in lanes 12-15 of every row of 16 (measured: 256x256 tiles, wave group 1).
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 4");
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (HAS_LO) {
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{ol[0], ol[1]}, r_lo, o_lo, rr * ld, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_nop 4");             // the same precaution for the 8-byte store
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                float sg, qg;
-                group_stats64(zq, sg, qg);
-                if (ch == 0) pt_base[(r8 + rr) * G] = make_float2(sg, qg);
-                __builtin_amdgcn_sched_barrier(0);   // one row group at a time
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (mi < Shape::TM) {
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 w;
-                    w.x = pack_bf16x2(acc.v[mi][ni][4 * g], acc.v[mi][ni][4 * g + 1]); w.y = pack_bf16x2(acc.v[mi][ni][4 * g + 2], acc.v[mi][ni][4 * g + 3]);
-                    *reinterpret_cast<uint2*>(stage + c * 128 + (((ni * 4 + g) ^ (c & 7)) << 4) + h * 8) = w;
-                }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) d[p] = __builtin_bit_cast(u32x4_t, *reinterpret_cast<const uint4*>(st_rd + p * 8 * 128));
-        }
-    }
-}
-
 // V^T[feature, token]: each 32x32 tile is staged as [32 features][32 tokens] (80-B rows), lanes = consecutive tokens of a feature row,
 // read back 16 B per lane: a store instruction writes 64-B runs of sixteen V^T rows.
-template <class Shape, bool NT, bool SC = false>
-__device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ outT, int64_t ldT, int64_t t0, int f0,
-                                                      const float* rs = nullptr) {   // SC: rs[mi] = scale of the lane's token in block mi (fused stream: rstd)
+template <class Shape, bool NT>
+__device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char* stage, uint16_t* __restrict__ outT, int64_t ldT, int64_t t0, int f0) {
     // the lane id is made opaque HERE: everything below that depends on it (LDS offsets, the 64-bit V^T addresses) is then recomputed per tile (a few VALU
     // instructions) instead of being hoisted out of the persistent tile loop into registers the main loop has no room for — hipcc spilled them, and the
     // scratch reloads (VMEM, followed by s_waitcnt vmcnt(0)) drained the LDS-DMA ring in every V^T tile (tests/test_capi_and_host.py: no spills allowed)
@@ -869,7 +568,7 @@ __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char*
         for (int ni = 0; ni < Shape::TN; ++ni) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                *reinterpret_cast<uint16_t*>(stage + ((r & 3) + 8 * (r >> 2) + 4 * h) * 80 + c * 2) = ET::from_f32(SC ? acc.v[mi][ni][r] * rs[mi] : acc.v[mi][ni][r]);   // a bare product: nothing to contract
+                *reinterpret_cast<uint16_t*>(stage + ((r & 3) + 8 * (r >> 2) + 4 * h) * 80 + c * 2) = ET::from_f32(acc.v[mi][ni][r]);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int fl = p * 16 + (ln >> 2), ch = ln & 3;
@@ -889,17 +588,13 @@ __device__ __forceinline__ void store_transposed_bf16(AccTile<Shape>& acc, char*
 //   EPI_DENSE: out0[T,F] = acc as bf16 (k_ln adds the bias and the residual in fp32)
 //   EPI_GELU:  out0[T,F] = gelu(acc + bias)
 template <int EPI, class ShapeE, bool NT>
-__device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>& acc, int64_t m0, int64_t n0, char* stage, const float* rs_pf = nullptr) {
+__device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>& acc, int64_t m0, int64_t n0, char* stage) {
     const int64_t t0 = m0 + acc.m_wave;
     const int f0 = (int)n0 + acc.n_wave;          // first feature of this wave's 64 columns; F % 64 == 0, so a wave is never partial
     if (f0 >= a.F) return;
     // A/B knob (KIRAG_AMD_EPI_PRIO, profiles/r03/tried_ab_epi_prio.txt): the two wave groups of the ping-pong loop run their epilogues side by side and the
     // younger group (tile rows 128 ..) loses the issue arbitration (its epilogue takes ~2x as long): 1 = that group at priority 1, 2 = the older group
     if (a.epi_prio && ((a.epi_prio == 1) == (acc.m_wave >= 128))) __builtin_amdgcn_s_setprio(1);
-    if constexpr (EPI == EPI_RES) {
-        if (a.xlo) store_rows_resid<ShapeE, NT, true>(acc, stage, a, t0, f0);      // kernel-uniform
-        else store_rows_resid<ShapeE, NT, false>(acc, stage, a, t0, f0);
-    } else {
     const int h = acc.lane >> 5;
     f32x4 b[2][4];                                // bias of the lane's 32 features: (ni, g) -> features ni*32 + 8g + 4h .. +3
     if constexpr (EPI != EPI_DENSE) {
@@ -908,30 +603,22 @@ __device__ __forceinline__ void proj_epilogue(const ProjArgs& a, AccTile<ShapeE>
 #pragma unroll
             for (int g = 0; g < 4; ++g) b[ni][g] = *reinterpret_cast<const f32x4*>(a.bias + f0 + ni * 32 + 8 * g + 4 * h);
     }
-    float rs[ShapeE::TM];                         // fused stream: rstd of the lane's token in each block
-    if constexpr (EPI == EPI_QKV_S || EPI == EPI_GELU_S) {
-#pragma unroll
-        for (int mi = 0; mi < ShapeE::TM; ++mi) rs[mi] = rs_pf ? rs_pf[mi] : a.st_in[t0 + mi * 32 + (acc.lane & 31)].y;   // rs_pf: loaded during the previous tile (k_proj)
-    }
-    if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_S) {
+    if constexpr (EPI == EPI_QKV) {
         const int region = f0 / a.H;              // H % 64 == 0: a wave's columns never straddle q | k | v
         if (region == 2) {
-            if constexpr (EPI == EPI_QKV_S) store_transposed_bf16<ShapeE, NT, true>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H, rs);
-            else store_transposed_bf16<ShapeE, NT>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H);   // value bias lives in bo_eff
+            store_transposed_bf16<ShapeE, NT>(acc, stage, a.outT, a.ldT, t0, f0 - 2 * a.H);   // value bias lives in bo_eff
         } else {
             store_rows_bf16<ShapeE, NT>(acc, stage, region ? a.out1 : a.out0, a.H, t0, f0 - region * a.H,
-                                    [&](f32x4 v, int mi, int ni, int g) { if constexpr (EPI == EPI_QKV_S) return row_scale_bias(v, rs[mi], b[ni][g]); else return v + b[ni][g]; }, a.skip_from);
+                                    [&](f32x4 v, int mi, int ni, int g) { return v + b[ni][g]; });
         }
     } else if constexpr (EPI == EPI_DENSE) {
-        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.ldo, t0, f0, [&](f32x4 v, int, int, int) { return v; }, a.skip_from);   // the bias is added in k_ln (fp32)
+        store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.ldo, t0, f0, [&](f32x4 v, int, int, int) { return v; });   // the bias is added in k_ln (fp32)
     } else {
         store_rows_bf16<ShapeE, NT>(acc, stage, a.out0, a.ldo, t0, f0, [&](f32x4 v, int mi, int ni, int g) {
-            f32x4 x;
-            if constexpr (EPI == EPI_GELU_S) x = row_scale_bias(v, rs[mi], b[ni][g]); else x = v + b[ni][g];
+            const f32x4 x = v + b[ni][g];
             const f32x2 lo = gelu_erf_fast2(f32x2{x.x, x.y}), hi = gelu_erf_fast2(f32x2{x.z, x.w});
             return f32x4{lo.x, lo.y, hi.x, hi.y};
-        }, a.skip_from);
-    }
+        });
     }
     if (a.epi_prio) __builtin_amdgcn_s_setprio(0);
 }
@@ -948,29 +635,8 @@ __global__ __launch_bounds__(ShapeE::NTHREADS, 2) void k_proj(ProjArgs a) {
         patch_coord(nat, tm_count, tn_count, tm, tn, (uint32_t)a.pw);
         m0 = tm * ShapeE::BM; n0 = tn * ShapeE::BN;
     };
-    // fused stream (EPI_QKV_S / EPI_GELU_S): the row scales of the block's NEXT tile are loaded at the end of an epilogue and wait in 4 registers through
-    // the next main loop; loaded at the start of the epilogue that needs them they cost a memory round trip per tile with nothing to overlap it
-    constexpr bool SCALED = EPI == EPI_QKV_S || EPI == EPI_GELU_S;
-    float rs_pf[ShapeE::TM];
-    bool pf_valid = false;
-    int64_t done = 0;
-    const int64_t total = tm_count * tn_count;
-    gemm_main<ShapeE, STAGES, ANT>(
-        a.X, a.ldx, T, a.W, a.K, a.F, a.K, total, smem, coord,
-        [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) {
-            proj_epilogue<EPI, ShapeE, NT>(a, acc, m0, n0, stage, SCALED && pf_valid ? rs_pf : nullptr);
-            if constexpr (SCALED) {
-                ++done;
-                const int64_t v = (int64_t)blockIdx.x + done * (int64_t)gridDim.x;     // the block's next virtual tile (gemm_nt_pingpong / gemm_nt_stream walk them in this order)
-                pf_valid = v < total;
-                if (pf_valid) {
-                    int64_t m1, n1;
-                    coord(xcd_chunk_map(v, total), m1, n1);
-#pragma unroll
-                    for (int mi = 0; mi < ShapeE::TM; ++mi) rs_pf[mi] = a.st_in[m1 + acc.m_wave + mi * 32 + (acc.lane & 31)].y;
-                }
-            }
-        });
+    gemm_main<ShapeE, STAGES, ANT>(a.X, a.ldx, T, a.W, a.K, a.F, a.K, tm_count * tn_count, smem, coord,
+                                   [&](AccTile<ShapeE>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeE, NT>(a, acc, m0, n0, stage); });
 }
 
 // the same projections on the producer / consumer 128x128 loop (gemm_nt_split): 4 multiplying + 4 staging waves, 4-slot ring + one 4-KiB epilogue
@@ -991,55 +657,44 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_proj_split(ProjArgs a) {
         [&](AccTile<ShapeSplit>& acc, int64_t m0, int64_t n0, int64_t) { proj_epilogue<EPI, ShapeSplit, false>(a, acc, m0, n0, stage); });
 }
 
-// the same projections for a handful of token rows on the skinny loop (gemm_nt_skinny): one 32-token x 32-feature tile per block, grid = (F / 32, T / 32).
-// Epilogue straight from the accumulator (swapped layout: a lane holds 4 consecutive features of one token per register quad): 8-byte row stores,
-// 2-byte stores for V^T — at these sizes the stores are noise next to the operand stream.
-template <int EPI, int RING>
-__global__ __launch_bounds__(SKINNY_THREADS) void k_proj_skinny(ProjArgs a) {
+// the same projections for a handful of token rows on the skinny loop (gemm_nt_skinny): one (32 WM)-token x (32 WN)-feature tile per block,
+// grid = (F / (32 WN), T / (32 WM)).  Epilogue straight from the accumulator (swapped layout: a lane holds 4 consecutive features of one token per register
+// quad): 8-byte row stores, 2-byte stores for V^T — at these sizes the stores are noise next to the operand stream.
+// (Round 5 built the LayerNorm behind a dense projection as the TAIL of this launch — write-through y, an arrival counter per token tile, the last
+// arriver normalises the tile's rows — bit-identical and SLOWER: the one block that finds itself last works through 32 rows alone, 26.8 us per launch
+// against 9.2 + 5.3 for the two launches; profiles/r05/tried_ln_tail.txt.)
+template <int EPI, int RING, int WM = 1, int WN = 1>
+__global__ __launch_bounds__((WM * WN + 4) * 64) void k_proj_skinny(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = *a.Tp;
-    const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
-    if (m0 >= T) return;                                  // block-uniform, before any barrier
-    gemm_nt_skinny<ET, RING, true>(a.X, a.ldx, T, m0, a.W, a.K, a.F, n0, a.K, smem, [&](AccTile<ShapeSkinny>& acc, int64_t t0, int64_t f0) {
+    const int64_t m0 = (int64_t)blockIdx.y * (32 * WM), n0 = (int64_t)blockIdx.x * (32 * WN);
+    f32x4 bias4[4];                                       // multiplying waves: the bias of the lane's 16 features, requested before the main loop
+    gemm_nt_skinny<ET, RING, WM, WN, true>(a.X, a.ldx, a.Tp, m0, a.W, a.K, a.F, n0, a.K, smem,
+        [&](int64_t, int64_t f0) {
+            if constexpr (EPI != EPI_DENSE) {
+                const int h = (threadIdx.x & 63) >> 5;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(a.bias + f0 + 8 * g + 4 * h);   // QKV: the V third's slots are never used
+            }
+        },
+        [&](AccTile<ShapeSkinny>& acc, int64_t t0, int64_t f0) {
         const int c = acc.lane & 31, h = acc.lane >> 5;
-        float rs = 1.f; float2 ms = make_float2(0.f, 1.f);
-        if constexpr (EPI == EPI_QKV_S || EPI == EPI_GELU_S) rs = a.st_in[t0 + c].y;
-        if constexpr (EPI == EPI_RES) ms = a.st_in[t0 + c];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 v = {acc.v[0][0][4 * g], acc.v[0][0][4 * g + 1], acc.v[0][0][4 * g + 2], acc.v[0][0][4 * g + 3]};
             const int f = (int)f0 + 8 * g + 4 * h;        // first of the lane's 4 consecutive features
-            if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_S) {
+            if constexpr (EPI == EPI_QKV) {
                 const int region = (int)f0 / a.H;
                 if (region == 2) {                        // V^T [feature, token]; its bias lives in bo_eff
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) a.outT[(int64_t)(f - 2 * a.H + j) * a.ldT + t0 + c] = ET::from_f32(EPI == EPI_QKV_S ? v[j] * rs : v[j]);
+                    for (int j = 0; j < 4; ++j) a.outT[(int64_t)(f - 2 * a.H + j) * a.ldT + t0 + c] = ET::from_f32(v[j]);
                     continue;
                 }
-                if constexpr (EPI == EPI_QKV_S) v = row_scale_bias(v, rs, *reinterpret_cast<const f32x4*>(a.bias + f));
-                else v = v + *reinterpret_cast<const f32x4*>(a.bias + f);
+                v = v + bias4[g];
                 uint2 w; w.x = pack_bf16x2(v.x, v.y); w.y = pack_bf16x2(v.z, v.w);
                 *reinterpret_cast<uint2*>((region ? a.out1 : a.out0) + (t0 + c) * a.H + (f - region * a.H)) = w;
-            } else if constexpr (EPI == EPI_RES) {        // the same per-element arithmetic as store_rows_resid; the row statistics come from k_row_stats_direct
-                const int64_t e = (t0 + c) * a.ldo + f;
-                const uint2 hw = *reinterpret_cast<const uint2*>(a.out0 + e);
-                const unsigned int lw = a.xlo ? *reinterpret_cast<const unsigned int*>(a.xlo + e) : 0x80808080u;
-                const f32x4 gg = *reinterpret_cast<const f32x4*>(a.ln_g + f), bb = *reinterpret_cast<const f32x4*>(a.ln_bb + f);
-                const unsigned int yw[2] = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, hh[2] = {hw.x, hw.y};
-                unsigned int ob[2], ol = 0u;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const float z0 = lo_decode((lw >> (16 * k)) & 0xffu, unpack_lo16(hh[k])), z1 = lo_decode((lw >> (16 * k + 8)) & 0xffu, unpack_hi16(hh[k]));
-                    const float n0 = resid_elem(unpack_lo16(yw[k]), z0, ms.x, ms.y, gg[2 * k], bb[2 * k]), n1 = resid_elem(unpack_hi16(yw[k]), z1, ms.x, ms.y, gg[2 * k + 1], bb[2 * k + 1]);
-                    ob[k] = pack_bf16x2(n0, n1);
-                    if (a.xlo) ol |= (lo_encode(n0, unpack_lo16(ob[k])) | (lo_encode(n1, unpack_hi16(ob[k])) << 8)) << (16 * k);
-                }
-                *reinterpret_cast<uint2*>(a.out0 + e) = make_uint2(ob[0], ob[1]);
-                if (a.xlo) *reinterpret_cast<unsigned int*>(a.xlo + e) = ol;
             } else {
-                if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_S) {
-                    if constexpr (EPI == EPI_GELU_S) v = row_scale_bias(v, rs, *reinterpret_cast<const f32x4*>(a.bias + f));
-                    else v = v + *reinterpret_cast<const f32x4*>(a.bias + f);
+                if constexpr (EPI == EPI_GELU) {
+                    v = v + bias4[g];
                     const f32x2 lo = gelu_erf_fast2(f32x2{v.x, v.y}), hi = gelu_erf_fast2(f32x2{v.z, v.w});
                     v = f32x4{lo.x, lo.y, hi.x, hi.y};
                 }
@@ -1688,10 +1343,8 @@ static int dmalloc(P** p, size_t bytes) {
 static void free_ws(Encoder* e) {
     if (!e->graphs.empty()) { (void)hipDeviceSynchronize(); drop_graphs(e); }   // captured kernels hold workspace pointers
     void* ptrs[] = {e->d_ids, e->d_mask, e->d_tt, e->tok_type, e->seq_off, e->seq_nk, e->seq_nq, e->seq_cls, e->seq_has0, e->tok_id, e->tok_pos, e->xlo, e->y, e->out,
-                    e->xb, e->q, e->k, e->vT, e->ctx, e->h, e->c_ctx, e->c_xb, e->c_y, e->c_h, e->c_xlo, e->c_off, e->c_nk, e->c_cls, e->d_B,
-                    e->stA, e->stB, e->part, e->c_stA, e->c_stB, e->c_part};
+                    e->xb, e->q, e->k, e->vT, e->ctx, e->h, e->c_ctx, e->c_xb, e->c_y, e->c_h, e->c_xlo, e->c_off, e->c_nk, e->c_cls, e->d_B};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    e->stA = e->stB = e->part = e->c_stA = e->c_stB = e->c_part = nullptr;
     e->c_ctx = e->c_xb = e->c_y = e->c_h = nullptr; e->c_xlo = nullptr; e->c_off = e->c_nk = e->c_cls = e->d_B = nullptr;
     e->d_ids = e->d_mask = e->d_tt = nullptr; e->tok_type = nullptr; e->seq_off = e->seq_nk = e->seq_nq = e->seq_cls = e->seq_has0 = nullptr; e->tok_id = e->tok_pos = nullptr;
     e->out = nullptr; e->xlo = nullptr; e->y = e->xb = e->q = e->k = e->vT = e->ctx = e->h = nullptr;
@@ -1723,20 +1376,12 @@ static int ensure_ws(Encoder* e, int B, int S) {
     KR_TRY(dmalloc(&e->vT, (size_t)H * e->ldv * 2));
     KR_HIP(hipMemset(e->vT, 0, (size_t)H * e->ldv * 2));
     KR_TRY(dmalloc(&e->ctx, capT * H * 2)); KR_TRY(dmalloc(&e->h, capT * (FF + e->h_pad) * 2));
-    if (e->fused) {
-        KR_TRY(dmalloc(&e->stA, capT * sizeof(float2))); KR_TRY(dmalloc(&e->stB, capT * sizeof(float2))); KR_TRY(dmalloc(&e->part, capT * (H / 64) * sizeof(float2)));
-        KR_HIP(hipMemset(e->stA, 0, capT * sizeof(float2))); KR_HIP(hipMemset(e->stB, 0, capT * sizeof(float2)));   // rows past T are read by the last tile (never used)
-    }
     if (e->cls_shortcut) {
         const int64_t capC = round_up(capB, 256);                 // token-indexed buffers come in multiples of the 256-row tile (see k_proj)
         KR_TRY(dmalloc(&e->c_ctx, capC * H * 2)); KR_TRY(dmalloc(&e->c_xb, capC * H * 2)); KR_TRY(dmalloc(&e->c_y, capC * H * 2)); KR_TRY(dmalloc(&e->c_xlo, capC * H));
         KR_TRY(dmalloc(&e->c_h, capC * (FF + e->h_pad) * 2));
         KR_HIP(hipMemset(e->c_ctx, 0, (size_t)capC * H * 2)); KR_HIP(hipMemset(e->c_xb, 0, (size_t)capC * H * 2)); KR_HIP(hipMemset(e->c_xlo, 0x80, (size_t)capC * H));
         KR_TRY(dmalloc(&e->c_off, capB * 4)); KR_TRY(dmalloc(&e->c_nk, capB * 4)); KR_TRY(dmalloc(&e->c_cls, capB * 4)); KR_TRY(dmalloc(&e->d_B, sizeof(int)));
-        if (e->fused) {
-            KR_TRY(dmalloc(&e->c_stA, capC * sizeof(float2))); KR_TRY(dmalloc(&e->c_stB, capC * sizeof(float2))); KR_TRY(dmalloc(&e->c_part, capC * (H / 64) * sizeof(float2)));
-            KR_HIP(hipMemset(e->c_stA, 0, capC * sizeof(float2))); KR_HIP(hipMemset(e->c_stB, 0, capC * sizeof(float2)));
-        }
     }
     e->capT = capT; e->capB = (int)capB; e->capBS = capBS;
     return 0;
@@ -1801,15 +1446,6 @@ static int launch_attn(const Encoder* e, int B, int cap, int nqt, hipStream_t st
         attr_lds = lds;
     }
     const int qgroups = (nqt + (4 / HPB) - 1) / (4 / HPB);   // blocks per (sequence, head group): 4 / HPB q-tiles each
-#ifdef KR_EXPERIMENT
-    { if (e->kn.nt_qkv) {
-          static int attr2[64] = {};
-          if (lds > attr2[e->device & 63]) { KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_lds<HPB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr2[e->device & 63] = lds; }
-          hipLaunchKernelGGL((k_attn_lds<HPB, true>), dim3((unsigned)((heads + HPB - 1) / HPB), (unsigned)B, (unsigned)qgroups), dim3(256), lds, st, e->q, e->k, e->vT,
-                             e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, kchunk, e->ctx);
-          return 0;
-      } }
-#endif
     hipLaunchKernelGGL((k_attn_lds<HPB>), dim3((unsigned)((heads + HPB - 1) / HPB), (unsigned)B, (unsigned)qgroups), dim3(256), lds, st, e->q, e->k, e->vT,
                        e->ldv, e->seq_off, e->seq_nk, e->seq_nq, H, heads, kchunk, e->ctx);
     return 0;
@@ -1824,13 +1460,13 @@ static int launch_attn_dma(const Encoder* e, int B, int nqt, hipStream_t st) {
     return 0;
 }
 
+static int set_lds_once(const void* kern, int lds, int device);
 template <class Shape, int STAGES, bool NT>
 static int launch_proj_shape_nt(int epi, const ProjArgs& a, int blocks, int device, hipStream_t st) {
     constexpr int lds = STAGES * Shape::STAGE_BYTES + Shape::NWAVE * EPI_STAGE_BYTES;   // 160 KiB for the 256x256 tile: the whole LDS of a CU
     // function attributes belong to the device's code-object instance: once per (kernel, device)
-    auto go = [&](auto kern, int slot) -> int {   // every k_proj instantiation has the same pointer type, i.e. this lambda exists once per (Shape, STAGES, NT): flags by slot
-        static bool set[8][64] = {};
-        if (!set[slot][device & 63]) { KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); set[slot][device & 63] = true; }
+    auto go = [&](auto kern, int) -> int {
+        KR_TRY(set_lds_once(reinterpret_cast<const void*>(kern), lds, device));
         int repeat = 1;
 #ifdef KR_STAMP
         { const int sl = (epi % 3) + (a.K > 1024 ? 2 : 0); (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(kr_stamp_slot), &sl, sizeof(int), 0, hipMemcpyHostToDevice, st); }
@@ -1844,17 +1480,27 @@ static int launch_proj_shape_nt(int epi, const ProjArgs& a, int blocks, int devi
         case EPI_QKV: return go(&k_proj<EPI_QKV, Shape, STAGES, NT>, 0);
         case EPI_DENSE: return ant ? go(&k_proj<EPI_DENSE, Shape, STAGES, NT, true>, 1) : go(&k_proj<EPI_DENSE, Shape, STAGES, NT>, 2);
         case EPI_GELU: return go(&k_proj<EPI_GELU, Shape, STAGES, NT>, 3);
-#ifdef KR_EXPERIMENT   // the fused residual stream is built into the experiment library only (make exp; profiles/r04/tried_fused_layernorm.txt)
-        case EPI_QKV_S: return go(&k_proj<EPI_QKV_S, Shape, STAGES, NT>, 4);
-        case EPI_RES: return ant ? go(&k_proj<EPI_RES, Shape, STAGES, NT, true>, 5) : go(&k_proj<EPI_RES, Shape, STAGES, NT>, 6);
-        case EPI_GELU_S: return go(&k_proj<EPI_GELU_S, Shape, STAGES, NT>, 7);
-#endif
         default: return fail(KR_EINVAL, "projection epilogue %d is not built into this library", epi);
     }
 }
 template <class Shape, int STAGES>
 static int launch_proj_shape(int epi, const ProjArgs& a, int blocks, int device, hipStream_t st) {
     return a.nt ? launch_proj_shape_nt<Shape, STAGES, true>(epi, a, blocks, device, st) : launch_proj_shape_nt<Shape, STAGES, false>(epi, a, blocks, device, st);
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device), safe against concurrent first launches from several host threads (a query
+// encoder and a corpus encoder on one device: ADVICE r04) and with the outcome cached, so that a failing attribute is reported by every launch
+static int set_lds_once(const void* kern, int lds, int device) {
+    struct Ent { const void* k; int dev; hipError_t rc; };
+    static std::mutex mu;
+    static std::vector<Ent> done;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Ent& x : done)
+        if (x.k == kern && x.dev == device) { if (x.rc != hipSuccess) return fail(KR_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(x.rc)); return 0; }
+    const hipError_t rc = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    done.push_back({kern, device, rc});
+    if (rc != hipSuccess) return fail(KR_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(rc));
+    return 0;
 }
 
 // tile shape per launch: when the 256x256 tiling has fewer tiles than ~5/8 of the CUs (small batches: the reference's per_gpu_batch_size 4-8, the KiRAG
@@ -1867,51 +1513,42 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, const 
     if (a.ldo == 0) a.ldo = a.F;
     a.pw = kn.pw;
     a.epi_prio = kn.epi_prio;
-    a.skip_from = 99;
     // store policy by output size (see ProjArgs::nt)
     a.nt = kn.store_nt >= 0 ? kn.store_nt : (max_tokens * (int64_t)a.F * 2 > ((int64_t)96 << 20) ? 1 : 0);
     // FF2 (K = FF > H): its activation operand h is a once-through stream four times the size of every other activation (256 MiB at 32 k tokens); loaded
     // non-temporally it leaves the L2 / Infinity Cache to the weights and to the residual stream the LayerNorm behind it reads: -0.7 % forward time at
     // 1000 x 32 tokens, neutral elsewhere (profiles/r04/tried_nt_activations.txt; outputs bit-identical).  KIRAG_AMD_NT_H=0 switches it off (A/B).
     a.ant = (a.K > a.H && kn.nt_h) ? 1 : 0;
-#ifdef KR_EXPERIMENT
-    a.skip_from = kn.skip_from;
-    if (kn.qkv_nt >= 0 && epi == EPI_QKV) a.nt = kn.qkv_nt;   // the q / k / v^T stores alone (three arrays of T x H: read back by the attention kernel right away)
-    if (kn.nt_ctx && epi == EPI_DENSE && a.K == a.H) a.ant = 1;   // the attention output read by the out-projection
-#endif
     const int64_t big_tiles = ((max_tokens + 255) / 256) * ((a.F + 255) / 256);
     const int64_t small_tiles = ((max_tokens + 127) / 128) * ((a.F + 127) / 128);
     const int force = kn.force_tile, ratio8 = kn.ratio8;
     const bool small = force == 128 || (force != 256 && big_tiles * 8 < (int64_t)num_cu * ratio8);   // measured crossover: ~5/8 of the CUs busy with 256x256 tiles
-    // a handful of token rows: 32x32 tiles, one per block (latency chain: the operand stream of the launch spread over as many CUs as it has tiles).
-    // Used while the launch has at most 4 tiles per CU (measured crossover against the 128x128 producer / consumer loop); 32 forces it
+    // a handful of token rows: the skinny loop, one tile per block (latency chain: the operand stream of the launch spread over as many CUs as it has
+    // tiles).  32 x 32 tiles while there is at most one per CU, 64 x 64 (four multiplying waves share every staged K-tile: half the L2 -> LDS bytes per
+    // output element) up to four 32 x 32 tiles' worth per CU — the crossover against the 128x128 producer / consumer loop measured in round 1.
+    // KIRAG_AMD_PROJ_TILE = 32 / 64 forces one of the two.
     const int64_t skinny_tiles = ((max_tokens + 31) / 32) * (a.F / 32);
-    e->last_skinny = false;
-    if (force == 32 || (force == 0 && skinny_tiles <= 4 * (int64_t)num_cu && (max_tokens + 31) / 32 <= 65535)) {
-        e->last_skinny = true;
-        const dim3 grid((unsigned)(a.F / 32), (unsigned)((max_tokens + 31) / 32));
-        auto launch = [&](auto ring_tag) -> int {
-            constexpr int RING = decltype(ring_tag)::value;
-            constexpr int lds = RING * SKINNY_STAGE;
-            auto go = [&](auto kern) -> int {   // every instantiation has the same pointer type, i.e. this lambda exists once: the flags are indexed by epi
-                static bool set[6][64] = {};
-                if (!set[epi][device & 63]) { KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); set[epi][device & 63] = true; }
-                hipLaunchKernelGGL(kern, grid, dim3(SKINNY_THREADS), lds, st, a);
-                return 0;
-            };
+    if (force == 32 || force == 64 || (force == 0 && skinny_tiles <= 4 * (int64_t)num_cu && (max_tokens + 31) / 32 <= 65535)) {
+        const bool one = force == 32 || (force == 0 && skinny_tiles <= num_cu);
+        auto launch = [&](auto shape_tag, auto kern) -> int {
+            constexpr int WM = decltype(shape_tag)::value, RING = WM == 1 ? 16 : 8;
+            using G = SkinnyGeom<WM, WM>;
+            constexpr int lds = RING * G::STAGE;
+            const dim3 grid((unsigned)(a.F / (32 * WM)), (unsigned)((max_tokens + 32 * WM - 1) / (32 * WM)));
+            KR_TRY(set_lds_once(reinterpret_cast<const void*>(kern), lds, device));
+            hipLaunchKernelGGL(kern, grid, dim3(G::THREADS), lds, st, a);
+            return 0;
+        };
+        auto pick = [&](auto shape_tag) -> int {
+            constexpr int WM = decltype(shape_tag)::value, RING = WM == 1 ? 16 : 8;
             switch (epi) {
-                case EPI_QKV: return go(&k_proj_skinny<EPI_QKV, RING>);
-                case EPI_DENSE: return go(&k_proj_skinny<EPI_DENSE, RING>);
-                case EPI_GELU: return go(&k_proj_skinny<EPI_GELU, RING>);
-#ifdef KR_EXPERIMENT
-                case EPI_QKV_S: return go(&k_proj_skinny<EPI_QKV_S, RING>);
-                case EPI_RES: return go(&k_proj_skinny<EPI_RES, RING>);
-                case EPI_GELU_S: return go(&k_proj_skinny<EPI_GELU_S, RING>);
-#endif
+                case EPI_QKV: return launch(shape_tag, &k_proj_skinny<EPI_QKV, RING, WM, WM>);
+                case EPI_DENSE: return launch(shape_tag, &k_proj_skinny<EPI_DENSE, RING, WM, WM>);
+                case EPI_GELU: return launch(shape_tag, &k_proj_skinny<EPI_GELU, RING, WM, WM>);
                 default: return fail(KR_EINVAL, "projection epilogue %d is not built into this library", epi);
             }
         };
-        return skinny_tiles <= num_cu ? launch(std::integral_constant<int, 16>{}) : launch(std::integral_constant<int, 4>{});
+        return one ? pick(std::integral_constant<int, 1>{}) : pick(std::integral_constant<int, 2>{});
     }
     if (!small) return launch_proj_shape<ShapeBig, 2>(epi, a, num_cu, device, st);
     // producer/consumer loop (one persistent block per CU): at most one tile per CU, or more than two (measured: 600 tiles -7 % vs the streaming loop
@@ -1919,8 +1556,7 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, const 
     if (((small_tiles <= num_cu || small_tiles > 2 * num_cu) && force != 128) || force == 130) {
         constexpr int lds = SPLIT_RING * ShapeSplit::STAGE_BYTES + 4 * EPI_STAGE_BYTES;
         auto go = [&](auto kern) -> int {
-            static bool set[6][64] = {};
-            if (!set[epi][device & 63]) { KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); set[epi][device & 63] = true; }
+            KR_TRY(set_lds_once(reinterpret_cast<const void*>(kern), lds, device));
             hipLaunchKernelGGL(kern, dim3(num_cu), dim3(SPLIT_THREADS), lds, st, a);
             return 0;
         };
@@ -1928,11 +1564,6 @@ static int launch_proj(int epi, const ProjArgs& a_in, int64_t max_tokens, const 
             case EPI_QKV: return go(&k_proj_split<EPI_QKV>);
             case EPI_DENSE: return go(&k_proj_split<EPI_DENSE>);
             case EPI_GELU: return go(&k_proj_split<EPI_GELU>);
-#ifdef KR_EXPERIMENT
-            case EPI_QKV_S: return go(&k_proj_split<EPI_QKV_S>);
-            case EPI_RES: return go(&k_proj_split<EPI_RES>);
-            case EPI_GELU_S: return go(&k_proj_split<EPI_GELU_S>);
-#endif
             default: return fail(KR_EINVAL, "projection epilogue %d is not built into this library", epi);
         }
     }
@@ -1958,16 +1589,8 @@ int enc_create(const kr_bert_cfg* cfg, int device, int residual_lo, void** out) 
     { const char* v = getenv("KIRAG_AMD_CLS_FULL"); e->cls_shortcut = !(v && atoi(v) != 0); }
     { const char* v = getenv("KIRAG_AMD_GRAPH"); e->graphs_off = !(v && atoi(v) != 0); }   // opt-in: measured SLOWER than eager launches on ROCm 7.2 (see run_forward)
     { const char* v = getenv("KIRAG_AMD_HPAD"); e->h_pad = v ? (atoi(v) / 8) * 8 : 0; }
-    { const char* v = getenv("KIRAG_AMD_FUSED_LN"); e->fused = v && atoi(v) != 0; }
-#ifndef KR_EXPERIMENT
-    if (e->fused) { delete e; return fail(KR_EINVAL, "KIRAG_AMD_FUSED_LN=1: the fused residual stream is built into the experiment library only (make -C kirag_amd/csrc exp, KIRAG_AMD_LIB)"); }
-#endif   // diagnostic (tools/stamp_hpad.py): a row pitch of h that is not a power of two made no difference
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) e->num_cu = (p.multiProcessorCount / 8) * 8; }
     e->num_cu_all = e->num_cu;
-#ifdef KR_EXPERIMENT
-    // experiment (profiles/r04/tried_cu_split.txt): persistent projection grids on a SUBSET of the CUs, so that a search running on another stream keeps the rest
-    { const char* v = getenv("KIRAG_AMD_ENC_CUS"); if (v && atoi(v) >= 8) e->num_cu = std::min(e->num_cu, (atoi(v) / 8) * 8); }
-#endif
     e->L.resize(cfg->layers);
     e->got.assign(T_LAYER0 + (size_t)cfg->layers * L_COUNT, 0);
     const size_t H = cfg->hidden, FF = cfg->intermediate;
@@ -1979,7 +1602,6 @@ int enc_create(const kr_bert_cfg* cfg, int device, int residual_lo, void** out) 
         A(&l.wqkv, 3 * H * H * 2); A(&l.wo, H * H * 2); A(&l.w1, FF * H * 2); A(&l.w2, H * FF * 2);
         A(&l.bqkv, 3 * H * 4); A(&l.bo, H * 4); A(&l.bo_eff, H * 4); A(&l.b1, FF * 4); A(&l.b2, H * 4);
         A(&l.ln1g, H * 4); A(&l.ln1b, H * 4); A(&l.ln2g, H * 4); A(&l.ln2b, H * 4);
-        if (e->fused) { A(&l.wqkv_f, 3 * H * H * 4); A(&l.w1_f, FF * H * 4); A(&l.cqkv, 3 * H * 4); A(&l.c1, FF * 4); A(&l.rb1, H * 4); A(&l.rb2, H * 4); }
     }
     if (rc) { enc_destroy(e); return rc; }
     *out = e;
@@ -1999,7 +1621,7 @@ void enc_destroy(void* h) {
     void* ptrs[] = {e->word, e->pos, e->type, e->elng, e->elnb, e->stage, e->d_T, e->d_err};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& l : e->L) {
-        void* lp[] = {l.wqkv, l.wo, l.w1, l.w2, l.bqkv, l.bo, l.bo_eff, l.b1, l.b2, l.ln1g, l.ln1b, l.ln2g, l.ln2b, l.wqkv_f, l.w1_f, l.cqkv, l.c1, l.rb1, l.rb2};
+        void* lp[] = {l.wqkv, l.wo, l.w1, l.w2, l.bqkv, l.bo, l.bo_eff, l.b1, l.b2, l.ln1g, l.ln1b, l.ln2g, l.ln2b};
         for (void* p : lp) if (p) (void)hipFree(p);
     }
     delete e;
@@ -2031,18 +1653,17 @@ int enc_load_weight(void* h, const char* hf_name, const float* data, int64_t num
         LayerW& l = e->L[(slot - T_LAYER0) / L_COUNT];
         switch ((slot - T_LAYER0) % L_COUNT) {
             // log2(e) / sqrt(d_h) is folded into the query projection: the attention scores come out in log2 units and the softmax is a bare exp2
-            // fused stream: these four matrices absorb a LayerNorm at kr_encoder_finalize (k_fold_ln), which needs the fp32 values
-            case L_QW: if (e->fused) to_f32(l.wqkv_f, 1.f); else to_bf16(l.wqkv, 0.125f * 1.4426950408889634f); break;
+            case L_QW: to_bf16(l.wqkv, 0.125f * 1.4426950408889634f); break;
             case L_QB: to_f32(l.bqkv, 0.125f * 1.4426950408889634f); break;
-            case L_KW: if (e->fused) to_f32(l.wqkv_f + H * H, 1.f); else to_bf16(l.wqkv + H * H, 1.f); break;
+            case L_KW: to_bf16(l.wqkv + H * H, 1.f); break;
             case L_KB: to_f32(l.bqkv + H, 1.f); break;
-            case L_VW: if (e->fused) to_f32(l.wqkv_f + 2 * H * H, 1.f); else to_bf16(l.wqkv + 2 * H * H, 1.f); break;
+            case L_VW: to_bf16(l.wqkv + 2 * H * H, 1.f); break;
             case L_VB: to_f32(l.bqkv + 2 * H, 1.f); break;
             case L_OW: to_bf16(l.wo, 1.f); break;
             case L_OB: to_f32(l.bo, 1.f); break;
             case L_LN1G: to_f32(l.ln1g, 1.f); break;
             case L_LN1B: to_f32(l.ln1b, 1.f); break;
-            case L_IW: if (e->fused) to_f32(l.w1_f, 1.f); else to_bf16(l.w1, 1.f); break;
+            case L_IW: to_bf16(l.w1, 1.f); break;
             case L_IB: to_f32(l.b1, 1.f); break;
             case L_FW: to_bf16(l.w2, 1.f); break;
             case L_FB: to_f32(l.b2, 1.f); break;
@@ -2066,24 +1687,6 @@ int enc_finalize(void* h) {
     if (e->stage) { (void)hipFree(e->stage); e->stage = nullptr; e->stage_elems = 0; }
     KR_TRY(select_device(e->device));
     const int H = e->cfg.hidden;
-#ifdef KR_EXPERIMENT
-    if (e->fused) {
-        const int FF = e->cfg.intermediate;
-        const float qs = 0.125f * 1.4426950408889634f;
-        for (size_t li = 0; li < e->L.size(); ++li) {
-            LayerW& l = e->L[li];
-            const float* gp = li ? e->L[li - 1].ln2g : e->elng;      // the LayerNorm whose output this layer's QKV projection (and attention residual) reads
-            const float* bp = li ? e->L[li - 1].ln2b : e->elnb;
-            for (int r = 0; r < 3; ++r)
-                hipLaunchKernelGGL(k_fold_ln, dim3((H + 3) / 4), dim3(256), 0, 0, l.wqkv_f + (size_t)r * H * H, gp, bp, l.bqkv + r * H, r == 0 ? qs : 1.f, H, H,
-                                   l.wqkv + (size_t)r * H * H, l.cqkv + r * H);
-            hipLaunchKernelGGL(k_fold_ln, dim3((FF + 3) / 4), dim3(256), 0, 0, l.w1_f, l.ln1g, l.ln1b, l.b1, 1.f, FF, H, l.w1, l.c1);
-            hipLaunchKernelGGL(k_fold_vbias, dim3((H + 127) / 128), dim3(128), 0, 0, l.wo, l.bo, l.cqkv + 2 * H, l.bo_eff, H);   // the value rows' c moves behind the softmax like b_v
-            hipLaunchKernelGGL(k_add_vec, dim3((H + 255) / 256), dim3(256), 0, 0, bp, l.bo_eff, l.rb1, H);
-            hipLaunchKernelGGL(k_add_vec, dim3((H + 255) / 256), dim3(256), 0, 0, l.ln1b, l.b2, l.rb2, H);
-        }
-    } else
-#endif
     for (auto& l : e->L) hipLaunchKernelGGL(k_fold_vbias, dim3((H + 127) / 128), dim3(128), 0, 0, l.wo, l.bo, l.bqkv + 2 * H, l.bo_eff, H);
     KR_HIP(hipGetLastError());
     KR_HIP(hipDeviceSynchronize());
@@ -2096,10 +1699,9 @@ int enc_finalize(void* h) {
 __global__ __launch_bounds__(256) void k_gather_cls(const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ xb, const uint8_t* __restrict__ xlo,
                                                     const int* __restrict__ seq_off, const int* __restrict__ seq_cls, const int* __restrict__ seq_nk, int H, uint16_t* __restrict__ c_ctx,
                                                     uint16_t* __restrict__ c_xb, uint8_t* __restrict__ c_xlo, int* __restrict__ c_off, int* __restrict__ c_nk,
-                                                    int* __restrict__ c_cls, int* __restrict__ d_B, const float2* __restrict__ st = nullptr, float2* __restrict__ c_st = nullptr) {
+                                                    int* __restrict__ c_cls, int* __restrict__ d_B) {
     const int b = blockIdx.x;
     const int64_t src = (int64_t)seq_off[b] + seq_cls[b];
-    if (st && threadIdx.x == 0) c_st[b] = st[src];          // fused stream: the row statistics travel with the row
     for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
         *reinterpret_cast<uint4*>(c_ctx + (int64_t)b * H + i) = *reinterpret_cast<const uint4*>(ctx + src * H + i);
         *reinterpret_cast<uint4*>(c_xb + (int64_t)b * H + i) = *reinterpret_cast<const uint4*>(xb + src * H + i);
@@ -2112,13 +1714,7 @@ __global__ __launch_bounds__(256) void k_gather_cls(const uint16_t* __restrict__
 }
 
 // every kernel of one forward, enqueued on `st` (inputs already in e->d_ids / e->d_mask, result left in e->out)
-#ifdef KR_EXPERIMENT
-static int enqueue_forward_fused(Encoder* e, int B, int S, int pool, hipStream_t st, bool has_tt);
-#endif
 static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, bool has_tt = false) {
-#ifdef KR_EXPERIMENT
-    if (e->fused) return enqueue_forward_fused(e, B, S, pool, st, has_tt);
-#endif
     const int H = e->cfg.hidden, FF = e->cfg.intermediate;
     const float eps = e->cfg.ln_eps;
     e->kn.read();
@@ -2137,11 +1733,6 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, b
     // per CU instead of 4: -0.25 % (profiles/r04/tried_ln_policies.txt; outputs bit-identical)
     auto ln_kernel = H <= 512 ? &k_ln16<1, 7> : H <= 1024 ? &k_ln16<2, 7> : &k_ln16<4, 7>;
     unsigned ln_mult = 8u;
-#ifdef KR_EXPERIMENT
-    { const int pol = e->kn.ln_pol;
-      if (H > 512 && H <= 1024) ln_kernel = pol == 0 ? &k_ln16<2, 0> : pol == 1 ? &k_ln16<2, 1> : pol == 3 ? &k_ln16<2, 3> : pol == 5 ? &k_ln16<2, 5> : pol == 6 ? &k_ln16<2, 6> : ln_kernel;
-      if (e->kn.ln_grid > 0) ln_mult = (unsigned)e->kn.ln_grid; }
-#endif
     const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu_all * ln_mult);   // k_ln is grid-stride (its parameters stay in registers across rows)
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->tok_type, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
                        e->use_lo ? e->xlo : nullptr, e->xb);
@@ -2200,144 +1791,6 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, b
     KR_HIP(hipGetLastError());
     return 0;
 }
-
-// the same forward on the fused residual stream (Encoder::fused): no LayerNorm kernels inside the stack
-#ifdef KR_EXPERIMENT   // ---- everything up to the matching #endif: the fused residual stream's forward (experiment library only)
-// debug: value summaries of the main buffers (first `rows` token rows) after a step
-static void dbg_dump(Encoder* e, const char* name, hipStream_t st, int64_t rows) {
-    const int H = e->cfg.hidden;
-    (void)hipStreamSynchronize(st);
-    auto sum16 = [&](const char* what, const uint16_t* p, int64_t n) {
-        std::vector<uint16_t> h((size_t)n);
-        (void)hipMemcpy(h.data(), p, (size_t)n * 2, hipMemcpyDeviceToHost);
-        double mx = 0; int64_t bad = 0;
-        for (auto& v : h) {
-#ifdef KR_ENC_BUILD_F16
-            const int ex = (v >> 10) & 31; const double f = ex == 31 ? NAN : std::ldexp((double)((v & 1023) | (ex ? 1024 : 0)), (ex ? ex : 1) - 25);
-#else
-            uint32_t u = (uint32_t)v << 16; float ff; memcpy(&ff, &u, 4); const double f = ff;
-#endif
-            if (!(f == f) || std::isinf(f) || std::fabs(f) > 1000.0) { if (bad < 24 && n == rows * H) fprintf(stderr, "      odd %s[%lld, %lld] = 0x%04x\n", what, (long long)((&v - h.data()) / H), (long long)((&v - h.data()) % H), v); ++bad; }
-            else mx = std::max(mx, std::fabs(f));
-        }
-        fprintf(stderr, "    %-6s max|x| %.4g non-finite %lld / %lld\n", what, mx, (long long)bad, (long long)n);
-    };
-    auto sumst = [&](const char* what, const float2* p, int64_t n) {
-        std::vector<float2> h((size_t)n);
-        (void)hipMemcpy(h.data(), p, (size_t)n * 8, hipMemcpyDeviceToHost);
-        double mmu = 0, mrs = 0, nrs = 1e30; int64_t bad = 0;
-        for (auto v : h) { if (!(v.x == v.x) || !(v.y == v.y) || std::isinf(v.y)) ++bad; else { mmu = std::max(mmu, (double)std::fabs(v.x)); mrs = std::max(mrs, (double)v.y); nrs = std::min(nrs, (double)v.y); } }
-        fprintf(stderr, "    %-6s max|mean| %.4g rstd in [%.4g, %.4g] bad %lld / %lld\n", what, mmu, nrs, mrs, (long long)bad, (long long)n);
-    };
-    if (const char* fn = getenv("KIRAG_AMD_DBG_FILE")) {     // the first residual output of the forward, raw: xb then xlo (compare tilings on the host)
-        static int once = 0;
-        if (!once && !strcmp(name, "proj RES")) {
-            once = 1;
-            std::vector<uint8_t> hb((size_t)rows * H * 3);
-            (void)hipMemcpy(hb.data(), e->xb, (size_t)rows * H * 2, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(hb.data() + (size_t)rows * H * 2, e->xlo, (size_t)rows * H, hipMemcpyDeviceToHost);
-            if (FILE* f = fopen(fn, "wb")) { fwrite(hb.data(), 1, hb.size(), f); fclose(f); }
-        }
-        static int once2 = 0;
-        if (!once2 && !strcmp(name, "row stats")) {          // ... and the statistics the device derived for those rows (appended)
-            once2 = 1;
-            std::vector<float2> hs((size_t)rows);
-            (void)hipMemcpy(hs.data(), e->stB, (size_t)rows * 8, hipMemcpyDeviceToHost);
-            if (FILE* f = fopen(fn, "ab")) { fwrite(hs.data(), 8, hs.size(), f); fclose(f); }
-        }
-    }
-    fprintf(stderr, "[fused] after %s\n", name);
-    sum16("xb", e->xb, rows * H); sum16("q", e->q, rows * H); sum16("k", e->k, rows * H); sum16("ctx", e->ctx, rows * H); sum16("h", e->h, rows * e->cfg.intermediate);
-    sumst("stA", e->stA, rows); sumst("stB", e->stB, rows);
-    fflush(stderr);
-}
-#define KR_DBG(name) do { if (e->kn.sync_each) { const hipError_t de = hipStreamSynchronize(st); fprintf(stderr, "[fused] %s: %s\n", name, hipGetErrorString(de)); fflush(stderr); \
-                          if (e->kn.dbg_rows > 0 && dbg_layer < 2) dbg_dump(e, name, st, e->kn.dbg_rows); } } while (0)
-static int enqueue_forward_fused(Encoder* e, int B, int S, int pool, hipStream_t st, bool has_tt) {
-    const int H = e->cfg.hidden, FF = e->cfg.intermediate, G = H / 64;
-    const float eps = e->cfg.ln_eps;
-    e->kn.read();
-    int dbg_layer = 0; (void)dbg_layer;
-    hipLaunchKernelGGL(k_seq_len, dim3(B), dim3(64), 0, st, e->d_mask, B, S, e->seq_nk, e->seq_has0);
-    const int nqt_max = (S + (pool == KR_POOL_CLS ? 1 : 0) + 31) / 32;
-    const bool long_seq = (nqt_max > 4 && !e->kn.attn_lds) || e->kn.attn_dma;
-    const int align = long_seq ? 8 : 4;
-    hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(64), 0, st, e->seq_nk, e->seq_has0, B, pool, align, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->d_err);
-    hipLaunchKernelGGL(k_fill_tokens, dim3(B), dim3(64), 0, st, e->d_ids, e->d_mask, has_tt ? e->d_tt : nullptr, S, e->cfg.vocab, e->cfg.type_vocab, align, e->seq_off,
-                       e->seq_nk, e->seq_nq, e->tok_id, e->tok_pos, e->tok_type, e->d_err);
-    const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + align - 1) & ~(align - 1));
-    const unsigned row_grid = (unsigned)((maxT + 3) / 4);
-    auto stats_direct = H <= 512 ? &k_row_stats_direct<1> : H <= 1024 ? &k_row_stats_direct<2> : &k_row_stats_direct<4>;
-    auto ln_apply = H <= 512 ? &k_ln_apply<1> : H <= 1024 ? &k_ln_apply<2> : &k_ln_apply<4>;
-    uint8_t* const lo_rw = e->use_lo ? e->xlo : nullptr;
-    hipLaunchKernelGGL(k_embed_z, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->tok_type, e->d_T, e->word, e->pos, e->type, H, lo_rw, e->xb);
-    KR_DBG("embed_z");
-    hipLaunchKernelGGL(stats_direct, dim3(row_grid), dim3(256), 0, st, e->xb, lo_rw, e->d_T, H, eps, e->stA);
-    KR_DBG("stats_direct(embed)");
-    const bool shortcut = pool == KR_POOL_CLS && e->cls_shortcut && e->c_ctx != nullptr;
-    e->last_shortcut = shortcut;
-    // one residual site: dense projection + residual in place, then the row statistics of the new site (from the epilogue's partials, or from the rows
-    // themselves behind the 32x32-tile kernel)
-    auto resid = [&](const uint16_t* W, const uint16_t* X, int K, int64_t ldx, const float* g, const float* bb, const float2* st_in, float2* st_out, const int* Tp,
-                     int64_t rows, uint16_t* xb, uint8_t* xlo, float2* part) -> int {
-        ProjArgs a{};
-        a.Tp = Tp; a.H = H; a.W = W; a.X = X; a.F = H; a.K = K; a.ldx = ldx; a.ldo = 0; a.out0 = xb; a.xlo = xlo; a.st_in = st_in; a.ln_g = g; a.ln_bb = bb; a.part = part;
-        KR_TRY(launch_proj(EPI_RES, a, rows, e, st));
-        KR_DBG("proj RES");
-        if (e->last_skinny) hipLaunchKernelGGL(stats_direct, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xb, xlo, Tp, H, eps, st_out);
-        else hipLaunchKernelGGL(k_row_stats, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, part, Tp, G, eps, st_out);
-        KR_DBG("row stats");
-        return 0;
-    };
-    for (size_t li = 0; li < e->L.size(); ++li) {
-        const LayerW& l = e->L[li];
-        const bool last = li + 1 == e->L.size();
-        dbg_layer = (int)li;
-        const float* gp = li ? e->L[li - 1].ln2g : e->elng;       // gamma of the site the layer starts from (its beta is inside rb1 / cqkv)
-        ProjArgs a{};
-        a.Tp = e->d_T; a.H = H;
-        a.W = l.wqkv; a.X = e->xb; a.F = 3 * H; a.K = H; a.bias = l.cqkv; a.out0 = e->q; a.out1 = e->k; a.outT = e->vT; a.ldT = e->ldv; a.st_in = e->stA;
-        KR_TRY(launch_proj(EPI_QKV_S, a, maxT, e, st));
-        KR_DBG("proj QKV_S");
-        {
-            const int cap = (int)round_up(S, 32);
-            const int nqt = nqt_max;
-            if (long_seq) KR_TRY(launch_attn_dma(e, B, nqt, st));
-            else if (nqt >= 3) KR_TRY(launch_attn<1>(e, B, cap, nqt, st));
-            else if (nqt == 2) KR_TRY(launch_attn<2>(e, B, cap, nqt, st));
-            else KR_TRY(launch_attn<4>(e, B, cap, nqt, st));
-        }
-        KR_DBG("attention");
-        const bool compact = last && shortcut;                    // only the CLS rows matter from here on: B rows instead of T (same kernels, same arithmetic per row)
-        const int* Tp = e->d_T; int64_t rows = maxT;
-        uint16_t *xb = e->xb, *ctx = e->ctx, *hbuf = e->h; uint8_t* xlo = lo_rw; float2 *sA = e->stA, *sB = e->stB, *part = e->part;
-        if (compact) {
-            hipLaunchKernelGGL(k_gather_cls, dim3(B), dim3(256), 0, st, e->ctx, e->xb, lo_rw, e->seq_off, e->seq_cls, e->seq_nk, H, e->c_ctx, e->c_xb, e->c_xlo, e->c_off,
-                               e->c_nk, e->c_cls, e->d_B, e->stA, e->c_stA);
-            Tp = e->d_B; rows = B; xb = e->c_xb; ctx = e->c_ctx; hbuf = e->c_h; xlo = e->use_lo ? e->c_xlo : nullptr; sA = e->c_stA; sB = e->c_stB; part = e->c_part;
-        }
-        KR_TRY(resid(l.wo, ctx, H, 0, gp, l.rb1, sA, sB, Tp, rows, xb, xlo, part));                       // attention.output.dense + residual -> site LN1
-        a = ProjArgs{};
-        a.Tp = Tp; a.H = H; a.W = l.w1; a.X = xb; a.F = FF; a.K = H; a.bias = l.c1; a.out0 = hbuf; a.ldo = FF + e->h_pad; a.st_in = sB;
-        KR_TRY(launch_proj(EPI_GELU_S, a, rows, e, st));                                                // intermediate.dense + GELU
-        KR_DBG("proj GELU_S");
-        KR_TRY(resid(l.w2, hbuf, FF, FF + e->h_pad, l.ln1g, l.rb2, sB, sA, Tp, rows, xb, xlo, part));      // output.dense + residual -> site LN2
-        if (last) {
-            // the last LayerNorm for good: pooling and kr_encoder_last_hidden read h = LN(z) as (hi, lo); without a low half in the stream the
-            // value is re-encoded from hi alone and gets one here (like the LayerNorm path's last k_ln16)
-            uint8_t* out_lo = compact ? e->c_xlo : e->xlo;
-            if (!e->use_lo) KR_HIP(hipMemsetAsync(out_lo, 0x80, (size_t)(compact ? B : maxT) * H, st));
-            hipLaunchKernelGGL(ln_apply, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, Tp, sA, l.ln2g, l.ln2b, H, out_lo, xb);
-            if (compact) hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->c_xb, e->c_xlo, e->c_off, e->c_nk, e->c_cls, H, pool, e->out, e->d_err);
-            else hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out, e->d_err);
-        }
-    }
-    KR_DBG("ln_apply + pool");
-    KR_HIP(hipGetLastError());
-    return 0;
-}
-#undef KR_DBG
-#endif   // KR_EXPERIMENT (fused forward)
 
 // Small batches are launch-bound (a 1 x 32-token forward is ~175 launches of 6-13 us).  With KIRAG_AMD_GRAPH=1 (read at kr_encoder_create; OFF by
 // default) the kernel sequence of a (B, S, pool) shape is replayed as ONE hipGraph from its second forward on.  Measured on MI355X / ROCm 7.2

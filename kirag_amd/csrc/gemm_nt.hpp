@@ -365,74 +365,113 @@ __device__ __forceinline__ void gemm_nt_split(const uint16_t* __restrict__ A, in
 }
 
 // =====================================================================================================================
-// skinny main loop: ONE 32x32 output tile per block, for launches with a handful of token rows (a query or two, the reference's batches of 4-8 passages).
-// Such a GEMM is a latency chain, not a throughput problem: a CU that streams B bytes of operands with R bytes in flight needs (B / R) memory round
-// trips, so the time falls with the number of CUs the operand stream is spread over — 32 x 32 tiles give F/32 x T/32 of them (FF2 at 32 tokens: 32 CUs
-// x 512 KiB instead of 8 CUs x 2 MiB with 128x128 tiles) — and with the ring depth.  Split-K would spread further but changes the summation order;
-// here every output element is still ONE accumulator chain over k in increasing order with the same MFMA instruction, so rows stay bit-identical to
-// the other loops.
-// Block = 5 waves: wave 0 multiplies (2 ds_read_b128 + 1 MFMA per k-step, fragments two k-steps ahead), waves 1..4 stage (per K-tile 4 + 4 pieces
-// of 1 KiB: 32 rows x 128 B of each operand, 2 pieces per staging wave) into a ring of RING K-tiles of 8 KiB; one s_barrier per K-tile, same
+// skinny main loop: ONE (32 WM) x (32 WN) output tile per block, for launches with a handful of token rows (a query or two, the reference's batches of
+// 4-8 passages, the KiRAG loop's chain queries).  Such a GEMM is a latency chain, not a throughput problem: a CU that streams B bytes of operands with R
+// bytes in flight needs (B / R) memory round trips, so the time falls with the number of CUs the operand stream is spread over — 32 x 32 tiles give
+// F/32 x T/32 of them (FF2 at 32 tokens: 32 CUs x 512 KiB instead of 8 CUs x 2 MiB with 128x128 tiles) — and with the ring depth.  Split-K would spread
+// further but changes the summation order; here every output element is still ONE accumulator chain over k in increasing order with the same MFMA
+// instruction, so rows stay bit-identical to the other loops.
+// Block = WM*WN multiplying waves (each owns one 32x32 sub-tile: 2 ds_read_b128 + 1 MFMA per k-step, fragments two k-steps ahead) + 4 staging waves
+// (per K-tile 4 WM + 4 WN pieces of 1 KiB: 32 rows x 128 B per 32 rows of each operand) into a ring of RING K-tiles; one s_barrier per K-tile, same
 // protocol as gemm_nt_split with the ring depth as the only difference (tiles g, g+1 resident at barrier g, tile g+RING-1 issued after it).
+//   1 x 1 (32 x 32):  launches with at most one such tile per CU — RING 16 x 8 KiB = 128 KiB, 13 K-tiles in flight, one block per CU
+//   2 x 2 (64 x 64):  more tiles than CUs (round 5; before: 32 x 32 tiles with a 4-deep ring, up to five blocks per CU): the four multiplying waves share
+//                     every staged K-tile, i.e. HALF the L2 -> LDS bytes per output element — FF2 at 1024 tokens moved 512 MiB through 32 x 32 tiles
+//                     (1024 tiles x 512 KiB) and was bound by exactly that; RING 8 x 16 KiB = 128 KiB
+// Round 5 (profiles/r05/tried_skinny_prologue.txt): the epilogue's constants are requested by `pre` before the first barrier; issuing weight pieces BEFORE
+// the wait for the row count (*Mp lives in device memory) was built and measured: the first two K-tiles' +-0, all prologue tiles' +2 us per launch (vmcnt
+// retires in order: the first A piece then stands behind 15 cold weight pieces) — the order stays (A, B) tile by tile behind the row count.
 // =====================================================================================================================
 using ShapeSkinny = GemmShape<32, 32, 1, 1>;
-// ring depth (template parameter RING): 16 x 8 KiB = 128 KiB, 13 K-tiles in flight, one block per CU — for launches with at most one tile per CU;
-// 4 x 8 KiB with up to five co-resident blocks per CU (the same bytes in flight per CU) when there are more tiles than CUs
-constexpr int SKINNY_THREADS = 320;
-constexpr int SKINNY_STAGE = 8192;
+constexpr int SKINNY_STAGE = 8192;                         // bytes per K-tile of the 1 x 1 shape
+template <int WM, int WN> struct SkinnyGeom {
+    static constexpr int NC = WM * WN;                     // multiplying waves
+    static constexpr int THREADS = (NC + 4) * 64;
+    static constexpr int A_BYTES = WM * 4096, B_BYTES = WN * 4096, STAGE = A_BYTES + B_BYTES;
+    static constexpr int PPW = WM + WN;                    // 1-KiB pieces per staging wave and K-tile
+};
+constexpr int SKINNY_THREADS = SkinnyGeom<1, 1>::THREADS;
 
-template <class T, int RING, bool SWAP = false, class Epilogue>
-__device__ __forceinline__ void gemm_nt_skinny(const uint16_t* __restrict__ A, int64_t lda, int64_t M, int64_t m0, const uint16_t* __restrict__ B, int64_t ldb,
-                                               int64_t N, int64_t n0, int K, char* smem, Epilogue&& epi) {
+// s_waitcnt vmcnt(n) for a run-time n (the instruction takes an immediate): FULL — the steady-state count of the ring, ONE compare on the path that runs
+// once per K-tile (a 15-step compare ladder there cost the staging waves more cycles per K-tile than the multiplying wave's four MFMAs: +1.3 us per
+// launch at 32 tokens) — or, in the ring's fill and drain, the largest listed value <= n
+template <int FULL>
+__device__ __forceinline__ void wait_vmcnt_upto(int n) {
+    if (n >= FULL) { wait_vmcnt<FULL>(); return; }
+    if (n >= 16) { if (n >= 24) wait_vmcnt<24>(); else if (n >= 20) wait_vmcnt<20>(); else wait_vmcnt<16>(); }
+    else if (n >= 8) { if (n >= 12) wait_vmcnt<12>(); else if (n >= 10) wait_vmcnt<10>(); else wait_vmcnt<8>(); }
+    else if (n >= 4) { if (n >= 6) wait_vmcnt<6>(); else wait_vmcnt<4>(); }
+    else if (n >= 2) { if (n >= 3) wait_vmcnt<3>(); else wait_vmcnt<2>(); }
+    else if (n >= 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+}
+
+// returns false (every wave, before any barrier) when the block's rows lie beyond *Mp
+template <class T, int RING, int WM = 1, int WN = 1, bool SWAP = false, class Pre, class Epilogue>
+__device__ __forceinline__ bool gemm_nt_skinny(const uint16_t* __restrict__ A, int64_t lda, const int* __restrict__ Mp, int64_t m0, const uint16_t* __restrict__ B, int64_t ldb,
+                                               int64_t N, int64_t n0, int K, char* smem, Pre&& pre, Epilogue&& epi) {
+    using G = SkinnyGeom<WM, WN>;
+    static_assert(RING >= 4 && (RING & (RING - 1)) == 0 && G::PPW * (RING - 1) <= 60, "ring depth: a power of two, its pieces countable by s_waitcnt vmcnt");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = K / 64;
-    if (wave >= 1) {
+    if (wave >= G::NC) {
         // ---------------------------------------------------------------- producers ----------------------------------------------------------------
-        const int lw = wave - 1;                       // piece lw of A and of B: rows 8 lw .. 8 lw + 7
-        const int row = lw * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int64_t a_left = M - m0, b_left = N - n0;
-        const int64_t ra = row >= a_left ? a_left - 1 : row, rb = row >= b_left ? b_left - 1 : row;
-        const char* pa = reinterpret_cast<const char*>(A + (m0 + ra) * lda) + chunk * 16;
-        const char* pb = reinterpret_cast<const char*>(B + (n0 + rb) * ldb) + chunk * 16;
+        const int lw = wave - G::NC;                   // pieces lw, lw + 4, ... of A and of B (a piece = 8 rows x 128 B)
+        const int r8 = lane >> 3;
+        const int64_t b_left = N - n0;
+        const char* pb[WN];
+#pragma unroll
+        for (int i = 0; i < WN; ++i) {
+            const int row = (lw + 4 * i) * 8 + r8;
+            const int64_t rb = row >= b_left ? b_left - 1 : row;
+            pb[i] = reinterpret_cast<const char*>(B + (n0 + rb) * ldb) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        }
+        const int64_t M = *Mp;
+        if (m0 >= M) return false;
+        const int64_t a_left = M - m0;
+        const char* pa[WM];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int row = (lw + 4 * i) * 8 + r8;
+            const int64_t ra = row >= a_left ? a_left - 1 : row;
+            pa[i] = reinterpret_cast<const char*>(A + (m0 + ra) * lda) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        }
         int pf = 0;
         auto stage_next = [&]() {
-            char* sa = smem + (pf & (RING - 1)) * SKINNY_STAGE + lw * 1024;
-            __builtin_amdgcn_global_load_lds((gbl_void*)(pa + (int64_t)pf * 128), (lds_void*)sa, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(pb + (int64_t)pf * 128), (lds_void*)(sa + 4096), 16, 0, 0);
+            char* st = smem + (pf & (RING - 1)) * G::STAGE;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(pa[i] + (int64_t)pf * 128), (lds_void*)(st + (lw + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WN; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(pb[i] + (int64_t)pf * 128), (lds_void*)(st + G::A_BYTES + (lw + 4 * i) * 1024), 16, 0, 0);
             ++pf;
         };
         for (int p = 0; p < RING - 1; ++p)
-            if (pf < nk) stage_next();
-        // tiles 0 and 1 resident: at most min(nk, RING-1) - 2 tiles (2 pieces each) may stay in flight
-        auto wait_keep = [&](int tiles_in_flight) {
-            // counted wait with a run-time count: s_waitcnt takes an immediate, so pick from the few values that occur (ring full, or the tail)
-            if (tiles_in_flight >= RING - 3) wait_vmcnt<2 * (RING - 3)>();
-            else if (RING - 3 > 8 && tiles_in_flight >= 8) wait_vmcnt<16>();
-            else if (RING - 3 > 4 && tiles_in_flight >= 4) wait_vmcnt<8>();
-            else if (RING - 3 > 2 && tiles_in_flight >= 2) wait_vmcnt<4>();
-            else if (RING - 3 > 1 && tiles_in_flight >= 1) wait_vmcnt<2>();
-            else wait_vmcnt<0>();
-        };
-        wait_keep(pf - 2);
-        __builtin_amdgcn_s_barrier();                                        // start barrier
+            if (pf < nk) stage_next();                 // tile by tile (A, B): a tile is complete as soon as its own pieces have landed (vmcnt retires in order)
+        // pieces that may stay in flight when K-tiles 0 .. need must have landed
+        auto allowed = [&](int need) { return G::PPW * (pf - 1 - need); };
+        constexpr int FULL = G::PPW * (RING - 3);      // tiles g, g+1 landed, RING - 3 younger ones in flight
+        wait_vmcnt_upto<FULL>(allowed(nk > 1 ? 1 : 0));
+        __builtin_amdgcn_s_barrier();                                        // start barrier: tiles 0 and 1 resident
         for (int g = 0; g < nk; ++g) {
-            wait_keep(pf - (g + 2));                                         // tiles g, g+1 landed; younger ones may be in flight
+            wait_vmcnt_upto<FULL>(allowed(g + 1 < nk ? g + 1 : nk - 1));     // tiles g, g+1 landed; younger ones may be in flight
             __builtin_amdgcn_s_barrier();
             if (pf < nk) stage_next();                                       // tile g + RING - 1 -> the slot of tile g - 1
         }
-        return;
+        return true;
     }
-    // -------------------------------------------------------------------- consumer -----------------------------------------------------------------
+    // -------------------------------------------------------------------- consumers ----------------------------------------------------------------
+    const int wm = wave / WN, wn = wave % WN;
+    pre(m0 + wm * 32, n0 + wn * 32);                       // the epilogue's constants are requested now and land under the main loop
+    if (m0 >= (int64_t)*Mp) return false;
     const int frow = lane & 31, fh = lane >> 5;
     const int fswz = (frow >> 1) & 7;
+    const int a_byte = (wm * 32 + frow) * 128, b_byte = G::A_BYTES + (wn * 32 + frow) * 128;
     uint4 af[4], bf[4];
     auto load_frags = [&](int g, int ks, int buf) {
-        const char* st = smem + (g & (RING - 1)) * SKINNY_STAGE + frow * 128 + (((2 * ks + fh) ^ fswz) << 4);
-        af[buf] = *reinterpret_cast<const uint4*>(st);
-        bf[buf] = *reinterpret_cast<const uint4*>(st + 4096);
+        const char* st = smem + (g & (RING - 1)) * G::STAGE + (((2 * ks + fh) ^ fswz) << 4);
+        af[buf] = *reinterpret_cast<const uint4*>(st + a_byte);
+        bf[buf] = *reinterpret_cast<const uint4*>(st + b_byte);
     };
     AccTile<ShapeSkinny> acc;
     acc.m_wave = 0; acc.n_wave = 0; acc.lane = lane;
@@ -451,7 +490,8 @@ __device__ __forceinline__ void gemm_nt_skinny(const uint16_t* __restrict__ A, i
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    epi(acc, m0, n0);
+    epi(acc, m0 + wm * 32, n0 + wn * 32);
+    return true;
 }
 
 // =====================================================================================================================

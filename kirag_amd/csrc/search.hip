@@ -145,8 +145,6 @@ struct Index {
     int num_cu = 256;
     // environment switches, read ONCE at kr_index_create (round 2 called getenv() on every search)
     bool no_q32 = false, no_fine = false, no_mark = false, no_vmm = false;
-    int epiv = 0;   // -DKR_EXPERIMENT builds: k_coarse epilogue variant (KIRAG_AMD_EPIV)
-    int trim[2] = {0, 0};   // -DKR_EXPERIMENT builds: mantissa bits rounded away in the corpus / query 16-bit copies (KIRAG_AMD_TRIM_X / _Q)
     // asynchronous search (kr_index_search_async ... kr_index_search_finish): pass 1 of every block is enqueued, the per-query certificate flags
     // land in pinned memory behind it; finish() reads them and runs the rare passes 2 / 3
     // Up to PEND_MAX calls may be outstanding on ONE stream (the row-sharded search enqueues the W batches of a block back to back and looks at their
@@ -170,17 +168,6 @@ struct Index {
 // ---------------------------------------------------------------------------------------------------------
 // add: fp32 rows -> 16-bit copy + quantisation-error bounds
 // ---------------------------------------------------------------------------------------------------------
-#ifdef KR_EXPERIMENT
-// experiment (KIRAG_AMD_TRIM_X / KIRAG_AMD_TRIM_Q): round the 16-bit copies to fewer mantissa bits (data-dependent MFMA power; the bounds are
-// computed from the stored values, so the certificate stays exact and only the candidate count changes)
-__device__ int g_trim_x = 0, g_trim_q = 0;
-__device__ inline uint16_t trim16(uint16_t o, int t) { return t > 0 ? (uint16_t)((o + (1u << (t - 1))) & ~((1u << t) - 1u)) : o; }
-#define TRIMX(o) trim16(o, g_trim_x)
-#define TRIMQ(o) trim16(o, g_trim_q)
-#else
-#define TRIMX(o) (o)
-#define TRIMQ(o) (o)
-#endif
 template <class T>
 __global__ __launch_bounds__(256) void k_add_rows(const float* __restrict__ xf, uint16_t* __restrict__ xc, int64_t n, int d, int dpad,
                                                   float* __restrict__ bounds) {
@@ -196,7 +183,7 @@ __global__ __launch_bounds__(256) void k_add_rows(const float* __restrict__ xf, 
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < d) v = *reinterpret_cast<const float4*>(src + i);
             ushort4 o;
-            o.x = TRIMX(T::from_f32(v.x)); o.y = TRIMX(T::from_f32(v.y)); o.z = TRIMX(T::from_f32(v.z)); o.w = TRIMX(T::from_f32(v.w));
+            o.x = T::from_f32(v.x); o.y = T::from_f32(v.y); o.z = T::from_f32(v.z); o.w = T::from_f32(v.w);
             const float cx = T::to_f32(o.x), cy = T::to_f32(o.y), cz = T::to_f32(o.z), cw = T::to_f32(o.w);
             e2 += (v.x - cx) * (v.x - cx) + (v.y - cy) * (v.y - cy) + (v.z - cz) * (v.z - cz) + (v.w - cw) * (v.w - cw);
             c2 += cx * cx + cy * cy + cz * cz + cw * cw;
@@ -227,7 +214,7 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < nq && i < d) v = *reinterpret_cast<const float4*>(qf + (int64_t)q * d + i);
         ushort4 o;
-        o.x = TRIMQ(T::from_f32(v.x)); o.y = TRIMQ(T::from_f32(v.y)); o.z = TRIMQ(T::from_f32(v.z)); o.w = TRIMQ(T::from_f32(v.w));
+        o.x = T::from_f32(v.x); o.y = T::from_f32(v.y); o.z = T::from_f32(v.z); o.w = T::from_f32(v.w);
         const float cx = T::to_f32(o.x), cy = T::to_f32(o.y), cz = T::to_f32(o.z), cw = T::to_f32(o.w);
         q2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         e2 += (v.x - cx) * (v.x - cx) + (v.y - cy) * (v.y - cy) + (v.z - cz) * (v.z - cz) + (v.w - cw) * (v.w - cw);
@@ -320,10 +307,9 @@ __device__ __forceinline__ void scatter_wave_lists(const CoarseArgs& a, char* sm
 // SMALLQ (at most 128 queries in the block: the KiRAG loop's 1-2 queries per hop, single-question retrieval): 128-row x 128-query tiles on the
 // producer / consumer loop (gemm_nt_split) instead of 256 x 256 on the ping-pong loop.  With a 256-query tile a small batch pays the MFMA time of 256
 // queries (2.0 ms per 5M rows, above the 1.3-1.6 ms the corpus needs to cross HBM); with 128 the scan is HBM-bound.
-// EPIV (experiments, -DKR_EXPERIMENT builds only; the product instantiates 0): 1 = the survivor path laid out as the LIKELY branch (the code before
-// round 4: every register without a survivor, 97 % of them, took a taken branch), 2 = survivors counted but never stored (diagnostic, wrong results),
-// 3 = no filter at all (diagnostic: the ceiling of any epilogue re-scheduling — measured 4.8 % below the real kernel, profiles/r04/tried_coarse_epilogue_ceiling.txt)
-template <class T, bool DIRECT, bool SMALLQ = false, int EPIV = 0>
+// (Round 4's diagnostic epilogue variants — survivors as the likely branch, counted but not stored, no filter at all = the 4.8 % ceiling of any epilogue
+// re-scheduling — are recorded in profiles/r04/tried_coarse_epilogue_ceiling.txt; their code lived behind -DKR_EXPERIMENT up to commit 81642ee.)
+template <class T, bool DIRECT, bool SMALLQ = false>
 __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
     using S = std::conditional_t<SMALLQ, ShapeSplit, ShapeC>;      // S::NWAVE = waves that own accumulators (4 of the 8 with SMALLQ)
     constexpr int RING_BYTES = SMALLQ ? SPLIT_RING * ShapeSplit::STAGE_BYTES : COARSE_STAGES * ShapeC::STAGE_BYTES;
@@ -380,19 +366,14 @@ __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
                     for (int mi = 0; mi < S::TM; ++mi) {
                         // (a block-level pre-test — the max of the lane's 16 scores against the threshold, ONE branch per 32 x 32 block instead of 16
                         // taken ones — was measured 7 % SLOWER in an interleaved A/B on one device, profiles/r02/ab_coarse_blockmax_epilogue.txt)
-                        if constexpr (EPIV == 3) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(acc.v[mi][ni][r]));
-                            continue;
-                        }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ro = mi * 32 + (r & 3) + 8 * (r >> 2);
                             const float s = acc.v[mi][ni][r];
                             const bool p = (s >= t);
                             const unsigned long long mask = __ballot(p);
-                            if (EPIV == 1 ? (mask != 0ull) : __builtin_expect(mask != 0ull, 0)) {   // a survivor is rare (2.8 % of the registers in the final round): fall through without one
-                                if (EPIV != 2 && p) {
+                            if (__builtin_expect(mask != 0ull, 0)) {   // a survivor is rare (2.8 % of the registers in the final round): fall through without one
+                                if (p) {
                                     const unsigned int slot = wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                                     u32x4 e = {__float_as_uint(s), row_base + (uint32_t)ro, q, 0u};
                                     __builtin_amdgcn_raw_buffer_store_b128(e, wlist, slot * 16u, 0, 0);
@@ -405,7 +386,7 @@ __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
             }
         };
     if constexpr (SMALLQ) gemm_nt_split<T, false>(a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem, coord, epi);
-    else gemm_nt_pingpong<T, false, EPIV != 4>(a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem, coord, epi);   // EPIV 4 (experiment): corpus loads with the default cache policy
+    else gemm_nt_pingpong<T, false, true>(a.xc, a.dpad, n_pad, a.qc, a.dpad, a.nq_pad, a.dpad, total, smem, coord, epi);   // corpus loads non-temporal
     if constexpr (!DIRECT) scatter_wave_lists(a, smem, wave_id, wcnt, ShapeC::NTHREADS);
 }
 
@@ -1336,9 +1317,6 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
     KR_HIP(hipMemcpyAsync(ix->q_f, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyDefault, st));
     CoarseArgs a; fill_args(ix, a);
     const size_t blk_cnt_bytes = ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int);
-#ifdef KR_EXPERIMENT
-    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_trim_q), &ix->trim[1], sizeof(int), 0, hipMemcpyHostToDevice, st);
-#endif
     hipLaunchKernelGGL(k_prep_queries<T>, dim3(p.nq_pad), dim3(64), 0, st, ix->q_f, ix->q_c, nq, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr,
                        ix->cnt, ix->flags);
     a.nq_pad = p.nq_pad; a.nq = nq;
@@ -1351,12 +1329,6 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
-#ifdef KR_EXPERIMENT
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS));
-#endif
         return 0;
     }));
     int final_preset = 0;
@@ -1367,12 +1339,6 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
             if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
             else hipLaunchKernelGGL((k_coarse<T, false, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
         } else if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
-#ifdef KR_EXPERIMENT
-        else if (ix->epiv == 1) hipLaunchKernelGGL((k_coarse<T, false, false, 1>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
-        else if (ix->epiv == 2) hipLaunchKernelGGL((k_coarse<T, false, false, 2>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
-        else if (ix->epiv == 3) hipLaunchKernelGGL((k_coarse<T, false, false, 3>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
-        else if (ix->epiv == 4) hipLaunchKernelGGL((k_coarse<T, false, false, 4>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
-#endif
         else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
         return 0;
     }, final_preset, rounds));
@@ -1667,18 +1633,11 @@ int kr_index_create(int d, int metric, int coarse_dtype, int device, kr_index** 
     Index* ix = new Index();
     ix->d = d; ix->dpad = (int)round_up(d, 64); ix->coarse = coarse_dtype; ix->device = device;
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) ix->num_cu = (p.multiProcessorCount / 8) * 8; }
-#ifdef KR_EXPERIMENT
-    { const char* v = getenv("KIRAG_AMD_IDX_CUS"); if (v && atoi(v) >= 8) ix->num_cu = std::min(ix->num_cu, (atoi(v) / 8) * 8); }   // see encoder.hip: KIRAG_AMD_ENC_CUS
-#endif
     hipError_t e = hipMalloc(&ix->bounds, 2 * sizeof(float));
     if (e != hipSuccess) { delete ix; return fail(KR_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
     (void)hipMemset(ix->bounds, 0, 2 * sizeof(float));
     ix->no_q32 = getenv("KIRAG_AMD_NO_Q32") != nullptr; ix->no_fine = getenv("KIRAG_AMD_NO_FINE") != nullptr;
     ix->no_mark = getenv("KIRAG_AMD_NO_MARK") != nullptr; ix->no_vmm = getenv("KIRAG_AMD_NO_VMM") != nullptr;
-#ifdef KR_EXPERIMENT
-    { const char* v = getenv("KIRAG_AMD_EPIV"); ix->epiv = v ? atoi(v) : 0; }
-    { const char* v = getenv("KIRAG_AMD_TRIM_X"); ix->trim[0] = v ? atoi(v) : 0; v = getenv("KIRAG_AMD_TRIM_Q"); ix->trim[1] = v ? atoi(v) : 0; }
-#endif
     *out = reinterpret_cast<kr_index*>(ix);
     return 0;
 }
@@ -1726,9 +1685,6 @@ int kr_index_add(kr_index* h, const float* x, int64_t n, void* stream) {
     float* dst = ix->xf + ix->n * ix->d;
     KR_HIP(hipMemcpyAsync(dst, x, (size_t)n * ix->d * sizeof(float), hipMemcpyDefault, st));
     const unsigned grid = (unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)ix->num_cu * 16);   // grid-stride: 16 blocks of 4 waves per CU
-#ifdef KR_EXPERIMENT
-    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_trim_x), &ix->trim[0], sizeof(int), 0, hipMemcpyHostToDevice, st);
-#endif
     if (ix->coarse == KR_COARSE_BF16)
         hipLaunchKernelGGL(k_add_rows<BF16>, dim3(grid), dim3(256), 0, st, dst, ix->xc + ix->n * ix->dpad, n, ix->d, ix->dpad, ix->bounds);
     else

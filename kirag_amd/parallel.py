@@ -34,6 +34,7 @@ class ShardedSearcher:
 
     DEVICE_MERGE_MAX = 8192      # kr_topk_merge_device holds nshards * k entries per query in LDS
     RING = 8                     # deferred searches that may be outstanding between two finish_deferred() calls (at least the world size)
+    PEND_MAX = 16                # Index::PEND_MAX of csrc/search.hip: asynchronous searches one index keeps outstanding
 
     def __init__(self, index, row_offset: int = 0, world: Optional[int] = None, group=None, collective: str = "torch"):
         """``collective``: "torch" — ``torch.distributed.all_gather_into_tensor`` of the process group + ``kr_topk_merge_device``; "kr_comm" — the
@@ -130,34 +131,54 @@ class ShardedSearcher:
         return ps, pi
 
     def finish_deferred(self):
-        """One host synchronisation for every search enqueued by ``search_deferred`` since the last call (a collective: every rank calls it with the
-        same number of outstanding searches).  Returns their (scores, rows) pinned tensors, oldest first, final."""
+        """Finishes every search enqueued by ``search_deferred`` since the last call (a collective: every rank calls it with the same number of
+        outstanding searches): ONE stream synchronisation for the whole block, then a second, small host round trip — the MAX all-reduce of one int32 per
+        search (did ANY rank re-answer queries of that batch? did any rank fail?) and its ``.cpu()`` — and only for a re-answered batch the exchange again
+        plus a third wait.  Returns their (scores, rows) pinned tensors, oldest first, final.  If a rank's local finish raises, every rank raises here
+        after the all-reduce (nobody is left blocking in it) and the searcher is usable again."""
         import torch
         import torch.distributed as dist
         out = [self._ring[j] for (_, _, _, _, j) in self._outstanding]
         if not self._outstanding:
             return out
         dev = self._outstanding[0][3]
-        torch.cuda.current_stream(dev).synchronize()              # the one wait: everything enqueued (searches, exchanges, D2H) is done
-        flagged = self.index.finish()                             # certificates; re-answers uncertified queries in place (rare)
-        assert len(flagged) == len(self._outstanding), (flagged, len(self._outstanding))
-        redo = torch.tensor([1 if f else 0 for f in flagged], dtype=torch.int32, device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
-        dist.all_reduce(redo, op=dist.ReduceOp.MAX, group=self.group)   # a batch is exchanged again if ANY rank patched its list
-        redo = redo.cpu().tolist()
-        self.redone += sum(1 for r in redo if r)
-        for (q, k, nq, dev, j), r in zip(self._outstanding, redo):
-            if not r:
-                continue
-            mine, loc = self._slots[j]
-            ids = mine[:nq * k * 8].view(torch.int64).view(nq, k)
-            sc = mine[nq * k * 8:nq * k * 12].view(torch.float32).view(nq, k)
-            torch.add(loc, self.row_offset, out=ids)
-            self._exchange(mine, sc, ids, nq, k, dev)
-            ps, pi = self._ring[j]
-            ps.copy_(self._out_s, non_blocking=True); pi.copy_(self._out_i, non_blocking=True)
-        if any(redo):
-            torch.cuda.current_stream(dev).synchronize()
-        self._outstanding = []
+        n_out = len(self._outstanding)
+        # A rank whose local finish fails (a HIP error in passes 2 / 3, or fewer certificate records than searches) must still take part in the collective
+        # below, or the other ranks block in it forever (ADVICE r04): the failure travels as code 2 in the all-reduced tensor and every rank raises after it.
+        err = None
+        flagged = []
+        try:
+            torch.cuda.current_stream(dev).synchronize()          # the one wait: everything enqueued (searches, exchanges, D2H) is done
+            flagged = self.index.finish()                         # certificates; re-answers uncertified queries in place (rare)
+            if len(flagged) != n_out:
+                raise RuntimeError(f"finish_deferred: {len(flagged)} certificate records for {n_out} outstanding searches")
+        except Exception as e:                                    # noqa: BLE001 — re-raised below, after the collective
+            err = e
+        try:
+            codes = [2] * n_out if err is not None else [1 if f else 0 for f in flagged]
+            redo = torch.tensor(codes, dtype=torch.int32, device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
+            # the second (small) host round trip of a block: a 4-byte-per-search MAX all-reduce + .cpu() — a batch is exchanged again if ANY rank patched its list
+            dist.all_reduce(redo, op=dist.ReduceOp.MAX, group=self.group)
+            redo = redo.cpu().tolist()
+            if err is not None:
+                raise err
+            if any(r >= 2 for r in redo):
+                raise RuntimeError("finish_deferred: another rank failed to finish its local searches; this block's results are not usable")
+            self.redone += sum(1 for r in redo if r)
+            for (q, k, nq, dev, j), r in zip(self._outstanding, redo):
+                if not r:
+                    continue
+                mine, loc = self._slots[j]
+                ids = mine[:nq * k * 8].view(torch.int64).view(nq, k)
+                sc = mine[nq * k * 8:nq * k * 12].view(torch.float32).view(nq, k)
+                torch.add(loc, self.row_offset, out=ids)
+                self._exchange(mine, sc, ids, nq, k, dev)
+                ps, pi = self._ring[j]
+                ps.copy_(self._out_s, non_blocking=True); pi.copy_(self._out_i, non_blocking=True)
+            if any(redo):
+                torch.cuda.current_stream(dev).synchronize()
+        finally:
+            self._outstanding = []                                # the C side has popped its ring either way: never leave the two out of step
         return out
 
     def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -213,7 +234,7 @@ class ShardedSearcher:
             self._out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
             self._pin_s = torch.empty((nq, k), dtype=torch.float32, pin_memory=True)
             self._pin_i = torch.empty((nq, k), dtype=torch.int64, pin_memory=True)
-            ring = max(self.RING, W)
+            ring = min(max(self.RING, W), self.PEND_MAX)          # never more than the index keeps outstanding (a 17th kr_index_search_async finishes the oldest itself)
             self._slots = [(torch.empty(block, dtype=torch.uint8, device=dev), torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(ring)]
             self._ring = [(torch.empty((nq, k), dtype=torch.float32, pin_memory=True), torch.empty((nq, k), dtype=torch.int64, pin_memory=True))
                           for _ in range(ring)]

@@ -203,6 +203,22 @@ class FlatIPIndex:
         return {f: getattr(st, f) for f, _ in st._fields_}
 
 
+def ids_to_str_rows(ext: np.ndarray) -> List[List[str]]:
+    """``[[str(v) for v in row] for row in ext]`` (index.py:49 maps every hit to ``str(id)``) without 100 k Python-level ``str`` calls per
+    1024-query x top-100 block: the library writes the ids as ONE ASCII buffer (``kr_format_ids``), which is decoded and split once — 7 ms instead
+    of 25 ms per block on this container's host, the same lists of the same strings (tests/test_capi_and_host.py)."""
+    ext = np.ascontiguousarray(ext, dtype=np.int64)
+    nq, k = ext.shape
+    if ext.size == 0:
+        return [[] for _ in range(nq)]
+    cap = 21 * ext.size
+    buf = C.create_string_buffer(cap)
+    written = C.c_int64(0)
+    _lib.check(_lib.load().kr_format_ids(ext.ctypes.data, int(ext.size), b" ", C.addressof(buf), cap, C.byref(written)))
+    flat = C.string_at(buf, written.value).decode("ascii").split(" ")
+    return [flat[i:i + k] for i in range(0, len(flat), k)]
+
+
 class Indexer(object):
 
     def __init__(self, vector_sz, metric="inner_product", n_subquantizers=0, n_bits=8, device=None, coarse_dtype="bf16", faiss_padding=False):
@@ -226,27 +242,57 @@ class Indexer(object):
         logger.info(f'Total data indexed {len(self.index_id_to_db_id)}')
 
     def search_knn(self, query_vectors, top_docs: int, index_batch_size=1024, verbose: bool = True) -> List[Tuple[List[object], List[float]]]:
+        """index.py:36-53, pipelined: the reference's loop searches a block, THEN builds its id strings, THEN starts the next block — the string pass
+        costs as much host time as the GPU's whole search of the block.  Here block i + 1 is enqueued (``kr_index_search_async``, results into pinned
+        host buffers) before block i's ids are converted, so the device works under the host's conversion; same lists, same order."""
         if isinstance(query_vectors, np.ndarray):
             query_vectors = query_vectors.astype('float32')
+        top_docs = int(top_docs)
+        nq_all = len(query_vectors)
+        blocks = [(s, min(s + index_batch_size, nq_all)) for s in range(0, nq_all, index_batch_size)]
         result = []
-        nbatch = (len(query_vectors) - 1) // index_batch_size + 1
-        for k in range(nbatch):
-            start_idx = k * index_batch_size
-            end_idx = min((k + 1) * index_batch_size, len(query_vectors))
-            q = query_vectors[start_idx: end_idx]
-            if self.faiss_padding and top_docs > self.index.ntotal:
+        if self.faiss_padding and top_docs > self.index.ntotal:
+            for s0, e0 in blocks:
+                q = query_vectors[s0:e0]
                 n = self.index.ntotal
                 scores = np.full((len(q), top_docs), -np.finfo(np.float32).max, np.float32)
                 indexes = np.full((len(q), top_docs), -1, np.int64)
                 if n > 0:
                     s_, i_ = self.index.search(q, n)
                     scores[:, :n] = s_; indexes[:, :n] = i_
-            else:
-                scores, indexes = self.index.search(q, top_docs)
-            # convert to external ids (vectorised form of index.py:49)
-            ext = self.index_id_to_db_id[indexes]
-            db_ids = [[str(v) for v in row] for row in ext.tolist()]
-            result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
+                db_ids = ids_to_str_rows(self.index_id_to_db_id[indexes])
+                result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
+            return result
+        if len(blocks) <= 1:
+            for s0, e0 in blocks:
+                scores, indexes = self.index.search(query_vectors[s0:e0], top_docs)
+                db_ids = ids_to_str_rows(self.index_id_to_db_id[indexes])   # external ids (vectorised form of index.py:49)
+                result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
+            return result
+        import torch
+        if not 0 < top_docs <= self.index.ntotal:
+            raise ValueError(f"top_docs={top_docs} must satisfy 0 < k <= ntotal={self.index.ntotal}")
+        dev = torch.device("cuda", self.index.device)
+        qd = (query_vectors if torch.is_tensor(query_vectors) else torch.from_numpy(np.ascontiguousarray(query_vectors, dtype=np.float32)))
+        qd = qd.detach().to(dev, dtype=torch.float32).contiguous()       # one upload of all queries (nq x 4 KiB)
+        bs = blocks[0][1] - blocks[0][0]
+        slots = [(torch.empty((bs, top_docs), dtype=torch.float32, pin_memory=True), torch.empty((bs, top_docs), dtype=torch.int64, pin_memory=True)) for _ in range(2)]
+
+        def enqueue(j):
+            s0, e0 = blocks[j]
+            ps, pi = slots[j & 1]
+            self.index.search_async(qd[s0:e0], top_docs, ps[:e0 - s0], pi[:e0 - s0])
+
+        with torch.cuda.device(dev):
+            enqueue(0)
+            for j, (s0, e0) in enumerate(blocks):
+                self.index.finish()                                     # block j is final in its pinned slot (the only call outstanding)
+                ps, pi = slots[j & 1]
+                scores = ps[:e0 - s0].numpy().copy(); indexes = pi[:e0 - s0].numpy().copy()
+                if j + 1 < len(blocks):
+                    enqueue(j + 1)                                      # the device searches block j + 1 while the host builds block j's strings
+                db_ids = ids_to_str_rows(self.index_id_to_db_id[indexes])
+                result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
         return result
 
     # ---- on-disk formats (index.py:55-79) --------------------------------------------------------------
@@ -296,6 +342,7 @@ class ShardedIndexer(Indexer):
         self.ntotal_global = 0
         self._local_ids = []
         self._dirty = False
+        self._min_shard_rows = None      # rows of the smallest shard, known to EVERY rank (None: not known — the deferred search path stays off)
 
     def index_data(self, ids, embeddings):
         """Streamed build (``cal_doc_embeddings(..., indexer=this)`` on every rank, BASELINE config 4: "streamed encode + search"): appends this
@@ -306,6 +353,7 @@ class ShardedIndexer(Indexer):
         self.index.add(embeddings)
         self._local_ids.append(np.array(ids, dtype=np.int64))
         self._dirty = True
+        self._min_shard_rows = None
 
     def _dirty_flag(self, async_op: bool):
         """the collective part of the "did any rank append rows?" decision: (flag tensor, work handle or None).  A rank whose share of a streamed build
@@ -332,6 +380,7 @@ class ShardedIndexer(Indexer):
         self.ntotal_global = len(self.index_id_to_db_id)
         self._local_ids = [local]
         self._dirty = False
+        self._min_shard_rows = min(len(p) for p in parts)
 
     def sync_shards(self):
         """Collective: assemble ``index_id_to_db_id``, ``row_offset`` and ``ntotal_global`` after ``index_data`` calls (no-op when no rank appended rows)."""
@@ -359,6 +408,7 @@ class ShardedIndexer(Indexer):
         self.index_id_to_db_id = np.concatenate(parts, axis=0)
         self.ntotal_global = len(self.index_id_to_db_id)
         self._local_ids, self._dirty = [local], False
+        self._min_shard_rows = min(len(p) for p in parts)
 
     def deserialize_from(self, dir_path):
         """Loads this rank's contiguous share of the rows.  Preferred source: the native shard files written by ``serialize`` (fp32 rows + the 16-bit
@@ -384,6 +434,8 @@ class ShardedIndexer(Indexer):
         # later index_data() calls append to this rank's shard: its ids so far are its slice of the loaded map
         self._local_ids = [np.asarray(self.index_id_to_db_id[self.row_offset: self.row_offset + self.index.ntotal], dtype=np.int64)]
         self._dirty = False
+        per = (self.ntotal_global + self.world - 1) // self.world          # the contiguous split both readers use (row_range = (rank, world))
+        self._min_shard_rows = min(max(0, min((r + 1) * per, self.ntotal_global) - min(r * per, self.ntotal_global)) for r in range(self.world))
 
     def serialize(self, dir_path):
         """Collective.  Every rank writes its resident rows as one native shard file (``index_shard_RRRR_of_WWWW.krshard``); rank 0 also writes the
@@ -411,6 +463,32 @@ class ShardedIndexer(Indexer):
         if self.world > 1:
             dist.barrier(group=self.group)
 
+    def _deferred_ok(self, k: int) -> bool:
+        """Collective-safe: depends only on values every rank holds (world, k, the smallest shard's row count, the backend)."""
+        import torch
+        import torch.distributed as dist
+        from ..parallel import ShardedSearcher
+        return (self.world > 1 and dist.is_initialized() and torch.cuda.is_available() and self._min_shard_rows is not None
+                and 0 < k <= self._min_shard_rows and self.world * k <= ShardedSearcher.DEVICE_MERGE_MAX)
+
+    def _search_knn_deferred(self, query_vectors, starts, bs, k, result):
+        import torch
+        sr = self._get_searcher()
+        dev = torch.device("cuda", self.index.device)
+        lo = starts[0]
+        qd = query_vectors[lo:] if torch.is_tensor(query_vectors) else torch.from_numpy(np.ascontiguousarray(query_vectors[lo:], dtype=np.float32))
+        qd = qd.detach().to(dev, dtype=torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            sr.search_deferred(qd[0: bs], k)
+            for j, s0 in enumerate(starts):
+                ps, pi = sr.finish_deferred()[-1]                      # block j final (the only search outstanding)
+                scores, rows = ps.numpy().copy(), pi.numpy().copy()
+                if j + 1 < len(starts):
+                    a = starts[j + 1] - lo
+                    sr.search_deferred(qd[a: a + bs], k)
+                db_ids = ids_to_str_rows(self.index_id_to_db_id[rows])
+                result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
+
     def _get_searcher(self):
         from ..parallel import ShardedSearcher
         sr = getattr(self, "_searcher", None)
@@ -433,7 +511,9 @@ class ShardedIndexer(Indexer):
         elif self._dirty:
             self._assemble()
         result = []
-        for start_idx in range(0, len(query_vectors), index_batch_size):
+        starts = list(range(0, len(query_vectors), index_batch_size))
+        done = 0
+        for start_idx in starts:
             q = query_vectors[start_idx: start_idx + index_batch_size]
             res = None
             if flag is not None:
@@ -447,9 +527,14 @@ class ShardedIndexer(Indexer):
             if not 0 < top_docs <= self.ntotal_global:
                 raise ValueError(f"top_docs={top_docs} must satisfy 0 < k <= ntotal={self.ntotal_global}")
             scores, rows = res if res is not None else self._get_searcher().search(q, top_docs)
-            ext = self.index_id_to_db_id[rows]
-            db_ids = [[str(v) for v in row] for row in ext.tolist()]
+            db_ids = ids_to_str_rows(self.index_id_to_db_id[rows])
             result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
+            done += 1
+            if done < len(starts) and self._deferred_ok(top_docs):
+                # the remaining blocks, pipelined like Indexer.search_knn: block j + 1 (local search + all-gather + device merge + D2H, enqueue only) runs
+                # on the device while the host builds block j's id strings.  Taken from state every rank shares, so the ranks branch alike.
+                self._search_knn_deferred(query_vectors, starts[done:], index_batch_size, top_docs, result)
+                break
         if flag is not None:                                   # no query batch at all: still take the collective decision
             work.wait()
             if bool(int(flag.item())):

@@ -3,6 +3,7 @@
  * Built and run by tests/test_capi_c.py:  gcc -std=c99 -Wall -Wextra -pedantic -Iinclude tests/capi/capi_smoke.c -ldl */
 #include <dlfcn.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -21,7 +22,7 @@ int main(int argc, char** argv) {
     BIND(kr_index_destroy) BIND(kr_index_reserve) BIND(kr_index_add) BIND(kr_index_ntotal) BIND(kr_index_dim) BIND(kr_index_get_rows)
     BIND(kr_index_coarse_dim) BIND(kr_index_coarse_dtype) BIND(kr_index_get_coarse) BIND(kr_index_get_bounds) BIND(kr_index_add_raw)
     BIND(kr_index_search) BIND(kr_index_search_async) BIND(kr_index_search_finish) BIND(kr_index_search_finish_ex) BIND(kr_index_search_pending)
-    BIND(kr_index_stats) BIND(kr_score_topk) BIND(kr_topk_merge) BIND(kr_topk_merge_device) BIND(kr_comm_unique_id) BIND(kr_comm_create)
+    BIND(kr_index_stats) BIND(kr_score_topk) BIND(kr_topk_merge) BIND(kr_format_ids) BIND(kr_topk_merge_device) BIND(kr_comm_unique_id) BIND(kr_comm_create)
     BIND(kr_comm_destroy) BIND(kr_comm_rank) BIND(kr_comm_world) BIND(kr_shard_allgather_topk) BIND(kr_encoder_create) BIND(kr_encoder_create_ex)
     BIND(kr_encoder_operand_dtype) BIND(kr_encoder_residual_lo) BIND(kr_encoder_destroy) BIND(kr_encoder_load_weight) BIND(kr_encoder_finalize)
     BIND(kr_encoder_forward) BIND(kr_encoder_forward_tt) BIND(kr_encoder_check) BIND(kr_encoder_last_hidden)
@@ -48,6 +49,14 @@ int main(int argc, char** argv) {
     if (!(oi[0] == 1 && oi[1] == 4 && oi[2] == 8 && os[0] == 0.9f && os[1] == 0.9f && os[2] == 0.7f)) {
         printf("merge result wrong: %lld %lld %lld\n", (long long)oi[0], (long long)oi[1], (long long)oi[2]);
         return 1;
+    }
+    /* ids -> decimal ASCII (the bulk form of Indexer.search_knn's str(id) per hit) */
+    {
+        const int64_t v[4] = {0, -7, 1234567890123LL, INT64_MIN};
+        char buf[96]; int64_t n = 0;
+        if (p_kr_format_ids(v, 4, ' ', buf, sizeof buf, &n) != KR_OK || n != 39 || memcmp(buf, "0 -7 1234567890123 -9223372036854775808", 39) != 0) {
+            printf("kr_format_ids wrong: %.*s\n", (int)n, buf); return 1; }
+        if (p_kr_format_ids(v, 4, ' ', buf, 40, &n) != KR_EINVAL) { printf("kr_format_ids accepted a short buffer\n"); return 1; }
     }
     printf("capi_smoke ok (devices visible: %d)\n", p_kr_device_count());
     dlclose(h);

@@ -39,7 +39,7 @@ def test_hot_kernels_keep_their_occupancy(notes):
         assert hits, parts
         return hits
     # ping-pong GEMMs and the coarse scan: two waves per SIMD (<= 256 registers each); the short-sequence attention: three blocks per CU (<= 168)
-    for k in find("k_projILi", "GemmShapeILi256ELi256") + find("k_coarseINS", "ELb0ELi0E"):
+    for k in find("k_projILi", "GemmShapeILi256ELi256") + find("k_coarseINS", "ELb0EEEv"):
         assert k["vgpr_count"] + k.get("agpr_count", 0) <= 256, k
     for k in find("k_attn_ldsILi"):
         assert k["vgpr_count"] <= 168, k

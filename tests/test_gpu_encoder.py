@@ -357,8 +357,9 @@ def test_every_projection_path_on_every_shape(golden, tile, monkeypatch):
 
 
 def test_projection_paths_are_bit_identical(golden, monkeypatch):
-    """Every output element is one MFMA accumulator chain over k in increasing order whatever the tile shape, so the four main loops must agree
-    BIT FOR BIT (the embedding cache and batch-size independence rely on it): full-size golden batch and a ragged tiny-config batch."""
+    """Every output element is one MFMA accumulator chain over k in increasing order whatever the tile shape, so the main loops must agree
+    BIT FOR BIT (the embedding cache and batch-size independence rely on it): full-size golden batch (mean and CLS pooling) and a ragged tiny-config
+    batch, through the 256 x 256 ping-pong loop, the two 128 x 128 loops and both skinny tiles (32 x 32, and round 5's 64 x 64)."""
     g = golden("g2_encoder_large.npz")
     cfg = _cfg(g["cfg"])
     w = E.synth_weights(cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
@@ -369,12 +370,12 @@ def test_projection_paths_are_bit_identical(golden, monkeypatch):
     h2 = _hip(cfg2, E.synth_weights(128, 2, 512, 1000, 512, seed=11))
     ids2, mask2 = E.synth_tokens(700, 48, seed=3, ragged=True, vocab_lo=5, vocab_hi=1000, min_len=3)
     outs = {}
-    for tile in ("256", "128", "130", "32"):
+    for tile in ("256", "128", "130", "32", "64"):
         monkeypatch.setenv("KIRAG_AMD_PROJ_TILE", tile)
-        outs[tile] = (h.forward_np(g["e5.c1.ids"], g["e5.c1.mask"], 0), h2.forward_np(ids2, mask2, 0))
-    for tile in ("128", "130", "32"):
-        assert np.array_equal(outs[tile][0].view(np.uint32), outs["256"][0].view(np.uint32)), tile
-        assert np.array_equal(outs[tile][1].view(np.uint32), outs["256"][1].view(np.uint32)), tile
+        outs[tile] = (h.forward_np(g["e5.c1.ids"], g["e5.c1.mask"], 0), h2.forward_np(ids2, mask2, 0), h.forward_np(g["e5.c1.ids"], g["e5.c1.mask"], 1))
+    for tile in outs:
+        for i in range(3):
+            assert np.array_equal(outs[tile][i].view(np.uint32), outs["256"][i].view(np.uint32)), (tile, i)
 
 
 def test_small_batch_forwards_replayed_as_hip_graphs_are_bit_identical():
