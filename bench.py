@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--search-stream", action="store_true", help="one GPU experiment: enqueue the search of step i on a second stream (overlaps the encode of step i + 1)")
     ap.add_argument("--sync-search", action="store_true", help="one GPU: use the blocking kr_index_search per step instead of search_async + finish")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the small-batch latency block (forwards of the reference's real batch shapes + one KiRAG hop)")
+    ap.add_argument("--no-surface", action="store_true", help="skip the reference-surface search measurement (Indexer.search_knn on --surface-queries queries)")
+    ap.add_argument("--surface", action="store_true", help="(default on at N = 1) report queries/s of Indexer.search_knn next to the C-ABI search on the same queries")
+    ap.add_argument("--surface-queries", type=int, default=4096)
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000, help="corpus rows of the CPU search baseline (BASELINE.md: the 1M point)")
     ap.add_argument("--cpu-full-corpus", action="store_true", help="CPU search baseline over ALL corpus rows (the 5M point: ~20 GB of host memory, minutes)")
     ap.add_argument("--cpu-sample-queries", type=int, default=32)
@@ -135,6 +139,72 @@ def cpu_baseline(args, q_host, with_encoder, dist_kind, index):
     else:
         out["value"] = search_qps
     return out
+
+
+def latency_block(args, encoder, index, dev):
+    """Small-batch latency at the batch shapes the reference really calls the path with: one query (e5.py helpers / KiRAG.retrieve,
+    knowledge_graph/models.py:1645), one 256-token chain query (models.py:1526-1531), compute_corpus_embeddings' default batch of 8 passages
+    (compute_corpus_embeddings.py:43), a triple batch of 125 x 32 — ms per forward, forwards back to back, median of 3 rounds of 30 — and one KiRAG hop on
+    this GPU: encode ONE 256-token chain query, exact top-10 over the resident corpus (enqueue both, one host wait)."""
+    import torch
+    from kirag_amd import bench_support as BS
+    out = {"unit": "ms", "forwards": {}}
+    for B, S in ((1, 32), (1, 256), (8, 128), (125, 32)):
+        ids, mask = BS.synthetic_tokens(dev, B, S, seed=1)
+        for _ in range(3):
+            encoder.forward(ids, mask, 0)
+        rounds = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(30):
+                encoder.forward(ids, mask, 0)
+            torch.cuda.synchronize(); rounds.append((time.perf_counter() - t0) / 30 * 1e3)
+        out["forwards"][f"{B}x{S}"] = float(np.median(rounds))
+    ids, mask = BS.synthetic_tokens(dev, 1, 256, seed=7)
+    k = 10
+    sc = torch.empty((1, k), dtype=torch.float32, pin_memory=True); rw = torch.empty((1, k), dtype=torch.int64, pin_memory=True)
+    hops = []
+    for i in range(23):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        qv = encoder.forward(ids, mask, 0)
+        index.search_async(qv, k, sc, rw)
+        index.finish()
+        if i >= 3:
+            hops.append((time.perf_counter() - t0) * 1e3)
+    out["kirag_hop_nq1"] = {"ms": float(np.median(hops)), "what": f"encode 1 x 256 tokens + exact top-{k} over {index.ntotal} resident rows, results in pinned host memory"}
+    return out
+
+
+def surface_block(args, index, q_vec, dev):
+    """queries/s of the call the reference makes — Indexer.search_knn (retriever/index.py:36-53; DenseRetriever.batch_retrieve, retrievers.py:250-275):
+    numpy queries in, List[(List[str], np.ndarray)] out — next to the C-ABI search (kr_index_search: all blocks enqueued, one host wait, results in pinned
+    memory) on the same queries.  The gap is the reference surface's own host work: 100 k Python strings per 1024-query x top-100 block."""
+    import torch
+    from kirag_amd.retriever.index import Indexer
+    nq, k = args.surface_queries, args.topk
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    reps = (nq + q_vec.shape[0] - 1) // q_vec.shape[0]
+    q = (q_vec.repeat(reps, 1)[:nq] + 0.01 * torch.randn((nq, q_vec.shape[1]), device=dev, generator=g))
+    q = torch.nn.functional.normalize(q, dim=1).contiguous()
+    q_host = q.cpu().numpy()
+    ix = Indexer.__new__(Indexer)
+    ix.faiss_padding = False; ix.index = index
+    ix.index_id_to_db_id = np.arange(index.ntotal, dtype=np.int64) * 3 + 10_000_000_000
+    ps = torch.empty((nq, k), dtype=torch.float32, pin_memory=True); pi = torch.empty((nq, k), dtype=torch.int64, pin_memory=True)
+    t_abi, t_surf = [], []
+    for i in range(4):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        index.search_into(q, k, ps, pi)
+        t = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        res = ix.search_knn(q_host, k, verbose=False)
+        t2 = time.perf_counter() - t0
+        if i:
+            t_abi.append(t); t_surf.append(t2)
+    ok = all(res[r][0] == [str(v) for v in ix.index_id_to_db_id[pi[r].numpy()].tolist()] for r in (0, 1023, 1024, nq - 1))
+    a, b = float(np.median(t_abi)), float(np.median(t_surf))
+    return {"queries": nq, "topk": k, "search_knn_queries_per_s": nq / b, "c_abi_queries_per_s": nq / a, "ratio": a / b, "search_knn_ms": b * 1e3, "c_abi_ms": a * 1e3,
+            "lists_match_c_abi": bool(ok)}
 
 
 def plumbing_only(args, world, rank):
@@ -439,6 +509,10 @@ def main():
             "encode": enc_info,
             "search_stats": {kk: st[kk] for kk in ("queries", "certified", "fallback", "fine", "exact", "overflow", "reranked_rows", "coarse_rounds", "fine_rounds", "marked_passes", "marked_rows")},
         }
+        if world == 1 and encoder is not None and not args.no_latency:
+            out["latency"] = latency_block(args, encoder, index, dev)
+        if world == 1 and not args.no_surface:
+            out["surface"] = surface_block(args, index, q_vec, dev)
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(args, q_vec.cpu().numpy(), encoder is not None, args.corpus_dist, index)
         print(json.dumps(out))

@@ -343,6 +343,7 @@ class ShardedIndexer(Indexer):
         self._local_ids = []
         self._dirty = False
         self._min_shard_rows = None      # rows of the smallest shard, known to EVERY rank (None: not known — the deferred search path stays off)
+        self.deferred_blocks = 0         # query blocks answered through the enqueue-only path (tests)
 
     def index_data(self, ids, embeddings):
         """Streamed build (``cal_doc_embeddings(..., indexer=this)`` on every rank, BASELINE config 4: "streamed encode + search"): appends this
@@ -488,6 +489,7 @@ class ShardedIndexer(Indexer):
                     sr.search_deferred(qd[a: a + bs], k)
                 db_ids = ids_to_str_rows(self.index_id_to_db_id[rows])
                 result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
+                self.deferred_blocks += 1
 
     def _get_searcher(self):
         from ..parallel import ShardedSearcher

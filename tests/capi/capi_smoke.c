@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
         char buf[96]; int64_t n = 0;
         if (p_kr_format_ids(v, 4, ' ', buf, sizeof buf, &n) != KR_OK || n != 39 || memcmp(buf, "0 -7 1234567890123 -9223372036854775808", 39) != 0) {
             printf("kr_format_ids wrong: %.*s\n", (int)n, buf); return 1; }
-        if (p_kr_format_ids(v, 4, ' ', buf, 40, &n) != KR_EINVAL) { printf("kr_format_ids accepted a short buffer\n"); return 1; }
+        if (p_kr_format_ids(v, 4, ' ', buf, 38, &n) != KR_EINVAL) { printf("kr_format_ids accepted a short buffer\n"); return 1; }
     }
     printf("capi_smoke ok (devices visible: %d)\n", p_kr_device_count());
     dlclose(h);

@@ -1,13 +1,21 @@
-"""The committed bench line (profiles/r03/bench_plain.json, produced by `python bench.py` on an MI355X) carries every field of the driver's
-contract, with consistent arithmetic.  bench.py itself needs a GPU; this checks the artefact the round ships."""
+"""The committed bench line (profiles/rNN/bench_plain.json of the NEWEST round that has one, produced by `python bench.py` on an MI355X) carries every
+field of the driver's contract, with consistent arithmetic.  bench.py itself needs a GPU; this checks the artefact the round ships."""
+import glob
 import json
 import os
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _newest_bench_line():
+    cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]", "bench_plain.json")))
+    assert cands, "no committed bench line under profiles/rNN/"
+    return cands[-1]
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(REPO, "profiles", "r03", "bench_plain.json")))
+    path = _newest_bench_line()
+    d = json.load(open(path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
@@ -24,6 +32,11 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and d["value"] > 10 * c["value"]
+    if os.path.basename(os.path.dirname(path)) >= "r05":     # round 5 on: the latency block and the reference-surface search ride in the same line
+        lat = d["latency"]
+        assert set(lat["forwards"]) == {"1x32", "1x256", "8x128", "125x32"} and all(0 < v < 50 for v in lat["forwards"].values()) and 0 < lat["kirag_hop_nq1"]["ms"] < 50
+        sf = d["surface"]
+        assert sf["lists_match_c_abi"] is True and abs(sf["ratio"] - sf["search_knn_queries_per_s"] / sf["c_abi_queries_per_s"]) < 1e-6
 
 
 def test_bench_defaults_are_the_metric_configuration():

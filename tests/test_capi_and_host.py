@@ -332,3 +332,22 @@ def test_faiss_flat_file_layout_byte_for_byte(tmp_path):
             I.read_faiss_flat_ip(path)
         assert msg in str(ei.value)
     assert I._SHARD_HEADER.size == 8 + 16 + 24 + 8 and I.shard_file_name(3, 8) == "index_shard_0003_of_0008.krshard"
+
+
+def test_bulk_id_strings_equal_str_per_id():
+    """``ids_to_str_rows`` (one ``kr_format_ids`` buffer, decoded and split once) == ``[[str(v) for v in row] for row in ids]`` — the list
+    ``Indexer.search_knn`` returns per hit (index.py:49) — for every int64 incl. the extremes, negative ids and degenerate shapes."""
+    from kirag_amd.retriever.index import ids_to_str_rows
+    rng = np.random.default_rng(3)
+    a = rng.integers(np.iinfo(np.int64).min, np.iinfo(np.int64).max, size=(37, 11), dtype=np.int64)
+    a[0, :4] = [0, -1, np.iinfo(np.int64).min, np.iinfo(np.int64).max]
+    a[1] = 10 ** np.arange(11)
+    out = ids_to_str_rows(a)
+    assert out == [[str(v) for v in row] for row in a.tolist()] and all(type(v) is str for row in out for v in row)
+    assert ids_to_str_rows(a[:, ::2]) == [[str(v) for v in row] for row in a[:, ::2].tolist()]          # non-contiguous view
+    assert ids_to_str_rows(np.empty((3, 0), np.int64)) == [[], [], []] and ids_to_str_rows(np.empty((0, 5), np.int64)) == []
+    lib = _lib.load()
+    import ctypes as C
+    buf = C.create_string_buffer(8); n = C.c_int64(0)
+    v = np.array([123456789012], np.int64)
+    assert lib.kr_format_ids(v.ctypes.data, 1, b" ", C.addressof(buf), 8, C.byref(n)) == -22         # KR_EINVAL: fewer than 21 bytes left for an id

@@ -103,6 +103,7 @@ def _worker_indexer(rank, world, port, folder, ret):
         assert sh.ntotal_global == 3001 and sh.index.ntotal in (1501, 1500) and sh.row_offset == (0 if rank == 0 else 1501)
         got = sh.search_knn(q, 25, index_batch_size=16, verbose=False)          # 3 query blocks
         assert len(got) == len(expected)
+        assert sh.deferred_blocks == (len(q) + 15) // 16 - 1        # round 5: every block after the first went through search_deferred, one block in flight under the host's id strings
         for (ids, sc), (eids, esc) in zip(got, expected):
             assert ids == eids and np.array_equal(np.asarray(sc).view(np.uint32), np.asarray(esc).view(np.uint32))
         # resident-shard build path: each rank contributes its own rows + ids

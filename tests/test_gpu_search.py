@@ -118,6 +118,36 @@ def test_search_knn_surface_ids_and_block_boundary():
         Indexer(128, metric="l2")
 
 
+def test_search_knn_pipelined_blocks_equal_the_block_by_block_form():
+    """Round 5: ``Indexer.search_knn`` enqueues block i + 1 before it converts block i's ids (two pinned result slots, ``kr_index_search_async`` /
+    ``finish``) and builds the id strings in bulk (``kr_format_ids``).  Three and a half blocks, a small ``index_batch_size``, queries that pass 1 cannot
+    certify (duplicated rows: the finish patches the pinned slot), negative ids, a torch tensor as input — every list identical to the reference's
+    loop (index.py:36-53) evaluated block by block through ``index.search`` + ``str``."""
+    import torch
+    from kirag_amd.retriever.index import Indexer
+    rng = np.random.default_rng(19)
+    x = _unit(rng, 5000, 128)
+    x[4000:4600] = x[17]                                            # 601 identical rows: whoever asks for row 17 gets mass ties (passes 2 / 3)
+    ids = [str(v) for v in (np.arange(5000, dtype=np.int64) * 7 - 9000)]   # negative and positive int64 ids
+    ix = Indexer(128)
+    ix.index_data(ids, x)
+    q = _unit(rng, 3 * 1024 + 500, 128)
+    q[5] = x[17]; q[2047] = x[17]; q[3500] = x[17]
+    for bs, k in ((1024, 10), (300, 100), (1024, 1)):
+        res = ix.search_knn(q, k, index_batch_size=bs, verbose=False)
+        assert len(res) == len(q)
+        for s0 in range(0, len(q), bs):
+            so, io = ix.index.search(q[s0:s0 + bs], k)
+            ext = ix.index_id_to_db_id[io]
+            for r in range(len(io)):
+                assert res[s0 + r][0] == [str(v) for v in ext[r].tolist()], (bs, k, s0 + r)
+                assert res[s0 + r][1].dtype == np.float32 and np.array_equal(res[s0 + r][1], so[r]), (bs, k, s0 + r)
+    res_t = ix.search_knn(torch.from_numpy(q), 10, verbose=False)   # tensor input takes the same path
+    res_n = ix.search_knn(q, 10, verbose=False)
+    assert all(a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(res_t, res_n))
+    assert ix.index.stats()["fine"] + ix.index.stats()["exact"] > 0     # the uncertified queries really went through passes 2 / 3
+
+
 def test_duplicates_tie_rule_and_k_equals_n():
     rng = np.random.default_rng(10)
     x = _unit(rng, 500, 64)
