@@ -156,7 +156,7 @@ G10_TOL = 1e-3
 G10_MODES = [("f16", True), ("f16", False), ("bf16", True), ("bf16", False)]
 
 
-@pytest.mark.parametrize("wname", ["benign", "out3", "out16", "out60"])
+@pytest.mark.parametrize("wname", ["benign", "out16", "out60", "out3"])      # out3 last: the checkpoint-check test below reuses its cached weights
 def test_g10_full_size_long_sequences_big_batch_left_padding_and_outlier_weights(golden, wname):
     """Golden set G10 (generated by importing the reference's E5Encoder / BGEEncoder, tests/golden/make_golden.py g10): the full 24-layer shape at
     S = 256 / 512 (the reference's doc_maxlength default, compute_corpus_embeddings.py:32-33), a 64-sequence batch, left padding — and weights with
@@ -175,6 +175,30 @@ def test_g10_full_size_long_sequences_big_batch_left_padding_and_outlier_weights
             assert sc <= G10_TOL and co <= (5e-5 if m[0] == "f16" else 1e-4) and er <= 3e-3, (m, sc, er, co)   # bf16: 1 - cos ~ 5e-5 (CLS pooling)
     # the default mode is the most accurate one on every weight set (what justifies paying for it)
     assert score <= min(r[0] for r in res.values()) * 1.5 + 1e-5, res
+
+
+def test_checkpoint_check_tool_through_the_hip_encoder_on_out3():
+    """tools/checkpoint_check.py with the HIP encoder as the tested path, on a full-size BertModel holding G10's out3 weights: the
+    four precision modes against the module's own fp32 forward.  The default must stay inside north_star's 1e-3, be the most accurate mode, and the
+    8-bit-operand modes must show the outlier channels (bf16 without the low half worst) — the same ordering the golden table has."""
+    import importlib.util, os
+    import torch
+    from transformers import BertConfig, BertModel
+    spec = _g10_spec()
+    w = _g10_weights(spec, "out3")
+    c = spec.CFG
+    m = BertModel(BertConfig(hidden_size=c["H"], num_hidden_layers=c["L"], num_attention_heads=c["heads"], intermediate_size=c["FF"], vocab_size=c["vocab"],
+                             max_position_embeddings=c["max_pos"], type_vocab_size=2, layer_norm_eps=1e-12), add_pooling_layer=False)
+    assert not m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False).missing_keys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sp = importlib.util.spec_from_file_location("checkpoint_check", os.path.join(repo, "tools", "checkpoint_check.py"))
+    cc = importlib.util.module_from_spec(sp); sp.loader.exec_module(cc)
+    out = cc.check_model(m, cc.parse(["(out3)", "--n", "24", "--max-length", "128", "--random-tokens"]))
+    assert out["tested_path"] == "hip" and 100 < out["outlier_ratio"] < 1000 and out["f16_headroom"] > 100
+    err = {(r["operand_dtype"], r["residual_lo"]): r["worst_score_error"] for r in out["modes"]}
+    print("checkpoint_check out3 (HIP):", err)
+    assert err[("f16", True)] <= 1e-3 and err[("f16", True)] <= min(err.values()) * 1.5 + 1e-5
+    assert err[("bf16", False)] > err[("bf16", True)] > err[("f16", True)] and err[("bf16", False)] > err[("f16", False)]
 
 
 def test_batch_invariance_and_padding_layouts(golden):

@@ -95,3 +95,33 @@ def test_g2_large_shape_matches_reference(golden):
     for key, fn in (("e5.c1", E.e5_encode), ("bge.c0", E.bge_encode)):
         out = fn(w, g[key + ".ids"], g[key + ".mask"], c["heads"])
         np.testing.assert_allclose(out, g[key + ".out"], atol=5e-5)
+
+
+def test_checkpoint_check_tool_on_an_outlier_checkpoint(tmp_path):
+    """tools/checkpoint_check.py (a precision self-check a user WITH a real checkpoint can run) end to end on the CPU: a small BERT
+    with the outlier-channel recipe of golden set G10 saved as an HF directory, activation statistics from the module's own fp32 forward, the four precision
+    modes through the torch emulation of the HIP encoder's rounding points.  Must reproduce G10's ordering — f16 + low half best, bf16 worst, the low half
+    helping either operand type — and report an outlier ratio far above a benign model's."""
+    import importlib.util
+    import json
+    import os
+    import torch
+    from transformers import BertConfig, BertModel
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("checkpoint_check", os.path.join(repo, "tools", "checkpoint_check.py"))
+    cc = importlib.util.module_from_spec(spec); spec.loader.exec_module(cc)
+    H, L, FF, vocab = 256, 6, 1024, 2000
+    res = {}
+    for name, w in (("benign", E.synth_weights(H, L, FF, vocab, 512, seed=3)), ("outlier", E.synth_weights_outlier(H, L, FF, vocab, 512, seed=7, gamma_lo=1.5, gamma_hi=3.0))):
+        m = BertModel(BertConfig(hidden_size=H, num_hidden_layers=L, num_attention_heads=H // 64, intermediate_size=FF, vocab_size=vocab, max_position_embeddings=512,
+                                 type_vocab_size=2, layer_norm_eps=1e-12), add_pooling_layer=False)
+        assert not m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False).missing_keys
+        d = tmp_path / name
+        m.save_pretrained(str(d))
+        out = cc.check(str(d), cc.parse([str(d), "--n", "12", "--max-length", "96", "--emulate", "--json", str(tmp_path / (name + ".json"))]))
+        assert json.load(open(tmp_path / (name + ".json")))["recommendation"] == out["recommendation"]
+        res[name] = out
+    err = {(r["operand_dtype"], r["residual_lo"]): r["worst_score_error"] for r in res["outlier"]["modes"]}
+    assert err[("f16", True)] < err[("f16", False)] < err[("bf16", False)] and err[("f16", True)] < err[("bf16", True)] < err[("bf16", False)], err
+    assert err[("f16", True)] < 1e-3 and res["outlier"]["outlier_ratio"] > 5 * res["benign"]["outlier_ratio"] and res["outlier"]["f16_headroom"] > 100
+    assert len(res["outlier"]["layers"]) == L and all(r["finite"] for r in res["outlier"]["modes"])
