@@ -476,6 +476,15 @@ def main():
             if ent:
                 mfma_busy, mfma_src = ent[0]["mfma_busy"], os.path.relpath(cand, REPO)
                 break
+        # sustained shader clock of the same kernel from the committed counter pass (tools/pmc_clock.py: GRBM_GUI_ACTIVE cycles per scan / HIP-event time per
+        # scan of the same run): the 2.5 PFLOP/s nameplate assumes 2.4 GHz, the chip holds ~1.6 GHz under this load
+        clock_ghz, clock_src = None, None
+        for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "clock.json")), reverse=True) if traffic is not None else []:
+            with open(cand) as f:
+                cj = json.load(f)
+            if (cj.get("rows"), cj.get("queries")) == (n, nq) and cj.get("sustained_clock_ghz"):
+                clock_ghz, clock_src = cj["sustained_clock_ghz"], os.path.relpath(cand, REPO)
+                break
         ms_step = dt / args.steps * 1e3
         coarse = float(np.mean(coarse_ms)) * 1e-3           # seconds per coarse scan (sum of its round launches)
         flops = 2.0 * nq * n * d                             # algorithmic: every query against every row of the shard
@@ -503,9 +512,12 @@ def main():
                          "traffic_source": traffic_src, "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src,
                          "algorithmic_gb": n * d * 2 / 1e9, "kernel": "k_coarse", "rows_scanned": n,
                          "launch_ms": coarse * 1e3,
+                         "sustained_clock_ghz": clock_ghz, "sustained_clock_source": clock_src,
+                         "frac_of_clock_adjusted_peak": (flops / coarse / PEAK_MFMA_DENSE_16BIT * 2.4 / clock_ghz) if clock_ghz else None,
                          "note": "one 'launch' = one coarse scan of the shard = the sum of its k_coarse round launches (4 at 5M rows), HIP events "
                                  "around each launch on its stream; algorithmic FLOPs = 2*nq*rows*dim; the bf16 MFMA-only loop measured on this "
-                                 "device sustains ~1.6-1.7 PFLOP/s on random data (tools/gemm_bench.hip)"},
+                                 "device sustains ~1.6-1.7 PFLOP/s on random data (tools/gemm_bench.hip); peak = the 2.4-GHz nameplate, the kernel's counter-measured "
+                                 "sustained clock is in sustained_clock_ghz: frac_of_clock_adjusted_peak = frac * 2.4 / clock = what the chip offers at the clock it holds"},
             "encode": enc_info,
             "search_stats": {kk: st[kk] for kk in ("queries", "certified", "fallback", "fine", "exact", "overflow", "reranked_rows", "coarse_rounds", "fine_rounds", "marked_passes", "marked_rows")},
         }

@@ -129,6 +129,13 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
         t = cpu_inputs.get("input_ids") if isinstance(cpu_inputs, dict) else None
         if vocab is None or not torch.is_tensor(t) or t.is_cuda or t.numel() == 0:
             return
+        # ATTENDED positions only: the HIP forward never reads a masked id (k_fill_tokens packs attended positions), and __main__ may add a
+        # '[PAD]' token whose id == len(tokenizer) >= the model's vocab_size when the tokenizer has no pad token — a padded batch is not an error
+        m = cpu_inputs.get("attention_mask")
+        if torch.is_tensor(m) and m.shape == t.shape:
+            t = t[m.bool()]
+            if t.numel() == 0:
+                return
         lo, hi = int(t.min()), int(t.max())
         if lo < 0 or hi >= vocab:
             raise ValueError(f"input_ids of the batch starting at passage id {ids[0] if ids else '?'} contain a token id outside [0, {vocab}) "

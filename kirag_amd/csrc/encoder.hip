@@ -273,8 +273,12 @@ __device__ __forceinline__ unsigned int lo_encode(float o, float hf) {
     const int t = min(max(d + ((1 << (LO_SH - 1)) + (128 << LO_SH)), 0), (256 << LO_SH) - 1);
     return (unsigned int)t >> LO_SH;
 }
+// A non-finite hi (a LayerNorm output beyond the f16 range, or NaN) decodes to ITSELF: on the bit patterns inf - 4096 would be a finite 3.4e38, and the
+// residual path must hand an overflow on to the next LayerNorm / the pooling, where KR_ERANGE is raised (tests/test_lo_codec_spec.py).
 __device__ __forceinline__ float lo_decode(unsigned int byte, float hf) {
-    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, hf) + (byte << LO_SH) - (128u << LO_SH));
+    const unsigned int hb = __builtin_bit_cast(unsigned int, hf);
+    const float x = __builtin_bit_cast(float, hb + (byte << LO_SH) - (128u << LO_SH));
+    return (hb & 0x7f800000u) == 0x7f800000u ? hf : x;
 }
 
 // LayerNorm of one row held as up to 8 float4 per lane (H <= 2048); writes fp32 and bf16 copies

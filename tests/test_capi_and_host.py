@@ -305,6 +305,37 @@ def test_corpus_encode_rejects_a_bad_batch_before_it_reaches_files_or_the_shard(
             assert all(int(i) < 32 for i in pickle.load(open(os.path.join(folder, f), "rb")))
 
 
+def test_corpus_encode_accepts_an_out_of_vocabulary_id_at_a_masked_position(tmp_path):
+    """the host-side check looked at ALL positions of input_ids, but the HIP forward only reads attended ones, and __main__ adds a '[PAD]'
+    token with id == len(tokenizer) >= vocab_size when the tokenizer has none — every padded batch was rejected.  Only attended ids are validated now."""
+    from kirag_amd import compute_corpus_embeddings as CC
+    from kirag_amd.collators import E5Collator
+
+    class Corpus:
+        def __init__(self, n):
+            self.index_to_passage_id = {i: str(i) for i in range(n)}
+        def __len__(self): return len(self.index_to_passage_id)
+        def __getitem__(self, i): return {"index": i, "passage": f"title:  t{i}, text:  word{i}" + (" some more words" if i % 5 == 0 else "")}
+
+    class Tok(_WordTok):
+        pad_token_id = 200                                   # == vocab_size: a pad token appended to the tokenizer after the model was trained
+        def __call__(self, texts, **kw):
+            out = super().__call__(texts, **kw)
+            out["input_ids"][out["attention_mask"] == 0] = 200
+            return out
+
+    class Shard:
+        def __init__(self): self.ids = []
+        def index_data(self, ids, emb): self.ids += list(ids)
+
+    ret = _FakeRetriever(); ret.encoder = SimpleNamespace(config=SimpleNamespace(vocab_size=200))
+    args = SimpleNamespace(local_rank=-1, save_dir=str(tmp_path), name="n", index_folder="f", per_gpu_batch_size=8, num_passage_per_index_file=16,
+                           encode_batch_size=16)
+    shard = Shard()
+    CC.cal_doc_embeddings(args, ret, Corpus(40), E5Collator(Tok(), 12, 20), rank=0, world=1, device=torch.device("cpu"), indexer=shard)
+    assert shard.ids == [str(i) for i in range(40)]         # every (padded) batch went through
+
+
 def test_faiss_flat_file_layout_byte_for_byte(tmp_path):
     """index.faiss as faiss 1.8 writes an IndexFlatIP (impl/index_write.cpp: fourcc "IxFI"; write_index_header = int d, idx_t ntotal, two idx_t
     dummies of 1 << 20, bool is_trained, int metric_type (0 = METRIC_INNER_PRODUCT, no metric_arg); then WRITEXBVECTOR(codes): size_t count =

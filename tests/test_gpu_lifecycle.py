@@ -136,6 +136,29 @@ def test_f16_overflow_is_reported_not_returned_as_embeddings():
     assert np.isfinite(out).all() and np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
 
 
+def test_last_layer_layernorm_overflow_is_reported(monkeypatch):
+    """an f16 overflow that first appears in the LAST LayerNorm (gamma large enough that |LN output| > 65504) reaches nothing but the pooling:
+    hi = inf in the 16-bit stream, the low byte clamped.  The pooled vector must come out non-finite (the codec hands a non-finite hi through) and the
+    forward must raise KR_ERANGE — with mean pooling and with CLS pooling (full rows and the CLS shortcut) — never return an embedding."""
+    from kirag_amd import _lib
+    from kirag_amd.retriever.encoders import HipBertForward
+    cfg = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
+                          max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    w = E.synth_weights(128, 2, 512, 1000, 512, seed=5)
+    big = dict(w)
+    g = w["encoder.layer.1.output.LayerNorm.weight"].copy(); g[::7] = 4.0e5            # normalised values of O(1) x 4e5: beyond the f16 range
+    big["encoder.layer.1.output.LayerNorm.weight"] = g
+    ids, mask = E.synth_tokens(5, 20, seed=2, ragged=True, vocab_lo=5, vocab_hi=1000, min_len=3)
+    for pool, full in ((0, "0"), (1, "0"), (1, "1")):
+        monkeypatch.setenv("KIRAG_AMD_CLS_FULL", full)
+        h = HipBertForward(cfg, 0, operand_dtype="f16", residual_lo=True); h.load_state(big)
+        with pytest.raises(_lib.KiragAmdError, match="non-finite") as ei:
+            h.forward_np(ids, mask, pool)
+        assert ei.value.code == -34
+        h.load_state(w)
+        assert np.isfinite(h.forward_np(ids, mask, pool)).all()
+
+
 def test_large_index_grows_in_place_without_copies():
     """An index that outgrows 256 MiB moves once into mapped 64-MiB chunks (hipMemAddressReserve / hipMemMap) and from then on grows in place:
     50k-row appends WITHOUT reserve() (the reference's faiss_index_corpus loop, index.py:88-106 style) must not need a second copy of the rows —

@@ -20,7 +20,8 @@ def encode(x, hi, sh):
 
 
 def decode(byte, hi, sh):
-    return ((hi.view(np.uint32).astype(np.int64) + (byte.astype(np.int64) << sh) - (128 << sh)) % 2**32).astype(np.uint32).view(np.float32)
+    x = ((hi.view(np.uint32).astype(np.int64) + (byte.astype(np.int64) << sh) - (128 << sh)) % 2**32).astype(np.uint32).view(np.float32)
+    return np.where((hi.view(np.uint32) & 0x7f800000) == 0x7f800000, hi, x)       # a non-finite hi decodes to itself (round 5)
 
 
 @pytest.mark.parametrize("kind,sh,mant", [("f16", 5, 10), ("bf16", 8, 7)])
@@ -43,3 +44,22 @@ def test_low_byte_is_a_256th_of_the_operand_ulp(kind, sh, mant):
     assert np.array_equal(decode(np.full(hi.shape, 128, np.uint8), hi, sh), hi)
     # decode(encode) is a fixed point: re-encoding a decoded value against the same hi reproduces the byte (the statistics of the fused stream rely on it)
     assert np.array_equal(encode(dec, hi, sh), byte)
+
+
+@pytest.mark.parametrize("kind,sh", [("f16", 5), ("bf16", 8)])
+def test_non_finite_operands_survive_the_codec(kind, sh):
+    """with a LayerNorm output beyond the operand range hi = +-inf, the encoder clamps the byte to 0 and the pure bit-pattern decode returned
+    bits(inf) - 4096 = a FINITE 3.4e38: the residual path swallowed the overflow (it was still caught through the 16-bit stream and the pooled norm).
+    Now a non-finite hi decodes to itself whatever the byte, so the next LayerNorm / the pooling see inf or NaN and KR_ERANGE is raised from either path."""
+    x = np.float32([np.inf, -np.inf, np.nan, 1.0e38 if kind == "bf16" else 7.0e4, -7.0e4])
+    with np.errstate(over="ignore", invalid="ignore"):
+        hi = to_hi(x, kind)
+    for b in (0, 1, 128, 255):
+        dec = decode(np.full(hi.shape, b, np.uint8), hi, sh)
+        nonfinite = ~np.isfinite(hi)
+        assert np.array_equal(dec[nonfinite].view(np.uint32), hi[nonfinite].view(np.uint32))
+    byte = encode(x, hi, sh)
+    dec = decode(byte, hi, sh)
+    assert np.isinf(dec[0]) and np.isinf(dec[1]) and dec[1] < 0 and np.isnan(dec[2])
+    if kind == "f16":
+        assert np.isinf(dec[3]) and np.isinf(dec[4])             # 7e4 > 65504: hi overflowed, and so does the decoded value
