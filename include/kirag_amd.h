@@ -33,7 +33,7 @@ extern "C" {
 #define KR_ESTATE (-1)    /* handle not ready (e.g. encoder weights missing) */
 #define KR_ERANGE (-34)   /* the encoder met non-finite activations (a value outside the f16 operand range, or NaN / Inf weights): results unusable */
 
-#define KR_ABI_VERSION 6
+#define KR_ABI_VERSION 7
 int kr_abi_version(void);
 const char* kr_last_error(void);
 int kr_device_count(void);
@@ -103,6 +103,24 @@ int kr_index_search_async(kr_index* ix, const float* q, int nq, int k, float* sc
 int kr_index_search_finish(kr_index* ix);
 int kr_index_search_finish_ex(kr_index* ix, int64_t* flagged, int cap, int* ncalls);
 int kr_index_search_pending(const kr_index* ix);   /* number of outstanding asynchronous calls */
+
+/* Row-sharded search with the exchange BEFORE the re-rank (replaces the gather of utils/utils.py:145-155 together with kr_topk_merge_device /
+ * kr_shard_allgather_topk).  Every shard certifies and re-ranks its OWN top-k in kr_index_search_async: ~0.3 ms of scattered fp32 row gathers per 1000-query
+ * batch on every rank whatever the number of shards, although only ~k / W of a shard's rows reach the global top-k.  Split form, one block of nq <= 1024 queries,
+ * all three calls enqueue-only on ONE stream with nothing else on the handle in between:
+ *   kr_index_search_coarse_async   pass 1's coarse scan; topk [nq, k + 1] (DEVICE memory) receives the k best coarse scores of this shard per query
+ *                                  (unsorted, -inf where the shard has fewer candidates) followed by the query's error bound on this shard;
+ *   [the host gathers the shards' topk blocks: gathered [nshards][nq][k + 1], rank order irrelevant]
+ *   kr_index_search_global_theta   theta[q] = (k-th best coarse score of ALL shards) - (largest error bound of any shard + this shard's): a row of this shard
+ *                                  with a coarse score below it cannot be in the global exact top-k;
+ *   kr_index_search_rerank_async   certificate + exact re-rank of the candidates above max(local bound, theta); scores / rows [nq, k] as in
+ *                                  kr_index_search_async, but a query may get FEWER than k rows: the tail is (-inf, -1) (kr_topk_merge* treat id < 0 as padding).
+ *                                  theta == NULL: exactly kr_index_search_async's result.
+ * The call is outstanding from the first half on (kr_index_search_finish* as usual; queries pass 1 could not certify are re-answered with the shard's own
+ * exact top-k, which merges just as well); a first half whose second half never comes makes the next finish return KR_ESTATE. */
+int kr_index_search_coarse_async(kr_index* ix, const float* q, int nq, int k, float* topk, void* stream);
+int kr_index_search_global_theta(kr_index* ix, const float* gathered, int nshards, float* theta, void* stream);
+int kr_index_search_rerank_async(kr_index* ix, const float* theta, float* scores, int64_t* rows, void* stream);
 
 typedef struct {
     int64_t queries;          /* queries answered since creation / last reset */

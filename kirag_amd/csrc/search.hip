@@ -156,6 +156,8 @@ struct Index {
         uint32_t* status = nullptr; int status_blocks = 0;   // pinned host: one STATUS_STRIDE record per query block of THIS call
         hipEvent_t ev_done = nullptr;   // behind the last enqueued block of the call
         uint64_t seq = 0;               // the call's number (the workspace-resident theta1 / timing events belong to the newest call only)
+        bool half = false;              // kr_index_search_coarse_async was enqueued, kr_index_search_rerank_async not yet
+        int final_preset = 0, rmax = 0; // ... what the second half needs from the first
     };
     static constexpr int PEND_MAX = 16;
     Pending pend[PEND_MAX];
@@ -824,13 +826,18 @@ __global__ __launch_bounds__(256) void k_select(uint64_t* __restrict__ cand, int
 }
 
 // exactness certificate + fp64 re-rank of the candidates with coarse score >= b_k - 2 eps   (buffer order is arbitrary)
+constexpr int MERGE_MAX = 8192;   // nshards * k entries per query (8 shards x k = 1024): 96 KiB of LDS in the device merge, 64 KiB in k_global_theta
 constexpr int RERANK_MAX = 2048;
 template <int NCH>   // NCH 256-element steps cover a row: d <= 256 NCH
 __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ cand, int cand_cap, const uint32_t* __restrict__ cnt,
                                                 uint32_t* __restrict__ flags, const float* __restrict__ thr, const float* __restrict__ eps,
                                                 const float* __restrict__ qf, const float* __restrict__ xf, int d, int k, int preset, int rmax,
                                                 float* __restrict__ out_s, int64_t* __restrict__ out_r, uint32_t* __restrict__ nrer,
-                                                const int* __restrict__ qmap, int force_exact, float* __restrict__ theta_out) {
+                                                const int* __restrict__ qmap, int force_exact, float* __restrict__ theta_out,
+                                                const float* __restrict__ theta_ext = nullptr) {
+    // theta_ext[q] (row-sharded search, exchange BEFORE the re-rank: kr_index_search_rerank_async): a bound derived from the k-th best coarse score of ALL
+    // shards; rows of this shard below it cannot be in the GLOBAL top-k, so the re-rank looks at max(theta, theta_ext) and may return FEWER than k rows
+    // (the tail is padded with (-inf, -1): the merge of the shards' lists treats id < 0 as padding)
     // theta_out[q] (pass 1 only): b_k - 2 eps of THIS pass = a bound below which a row's score in this pass's arithmetic rules it out of the top-k
     // (-inf when the query has fewer than k candidates); pass 2 pre-scans with it so that its fp64 work touches only slots that can matter
     // qmap != nullptr: the blocks work on a compacted query list (the high-precision pass over flagged queries); results go to row qmap[q]
@@ -853,8 +860,9 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
     if (tid == 0) rc = 0u;
     __syncthreads();
     const float bk = ord_f32(radix_select_desc<256>(s, m, k, hist, tid));               // k-th best coarse score (NaN if fewer than k real scores)
-    const float theta = bk - 2.f * eps[q];
-    if (theta_out && tid == 0) theta_out[q] = (theta == theta) ? theta : -INFINITY;
+    float theta = bk - 2.f * eps[q];
+    if (theta_out && tid == 0) theta_out[q] = (theta == theta) ? theta : -INFINITY;        // the LOCAL bound: pass 2 answers with the shard's own top-k
+    if (theta_ext) { const float te = theta_ext[q]; if (te > theta) theta = te; }
     // the buffer is complete for coarse scores >= thr (everything at or above the threshold of the last round was appended / kept)
     const bool certified = ok && (theta > thr[q]);
     for (int i = tid; i < m; i += 256) {
@@ -864,7 +872,7 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
     __syncthreads();
     const int r_all = (int)rc;
     const int r = r_all < rmax ? r_all : rmax;
-    if (tid == 0) { nrer[q] = (uint32_t)r; if (!certified || r_all > rmax || r_all < k) flags[q] |= 2u; }
+    if (tid == 0) { nrer[q] = (uint32_t)r; if (!certified || r_all > rmax || (r_all < k && !theta_ext)) flags[q] |= 2u; }
     int P = 1; while (P < r) P <<= 1;
     if (P < 1) P = 1;
     __syncthreads();
@@ -899,9 +907,60 @@ __global__ __launch_bounds__(256) void k_rerank(const uint64_t* __restrict__ can
     }
     bitonic_sort_desc(sel, P, tid, 256);
     const int64_t qo = qmap ? (int64_t)qmap[q] : (int64_t)q;
-    for (int j = tid; j < k && j < P; j += 256) {
-        out_s[qo * k + j] = key_score(sel[j]);
-        out_r[qo * k + j] = (int64_t)key_row(sel[j]);
+    for (int j = tid; j < k; j += 256) {
+        if (theta_ext && j >= r) { out_s[qo * k + j] = -INFINITY; out_r[qo * k + j] = -1; }      // fewer than k rows of this shard above the global bound
+        else if (j < P) { out_s[qo * k + j] = key_score(sel[j]); out_r[qo * k + j] = (int64_t)key_row(sel[j]); }
+    }
+}
+
+// Row-sharded search, exchange before the re-rank.  k_local_topk: the k best COARSE scores of this shard's candidate buffer per query (unsorted; -inf when the
+// buffer holds fewer than k) followed by the query's error bound eps — k + 1 floats per query, what a shard contributes to the all-gather.
+__global__ __launch_bounds__(256) void k_local_topk(const uint64_t* __restrict__ cand, int cand_cap, const uint32_t* __restrict__ cnt, const float* __restrict__ eps,
+                                                    int k, int preset, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* s = reinterpret_cast<uint64_t*>(smem);
+    unsigned int* hist = reinterpret_cast<unsigned int*>(s + cand_cap);                 // 256 + 4
+    unsigned int& wc = hist[259];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    float* o = out + (int64_t)q * (k + 1);
+    int m = preset > 0 ? preset : (int)cnt[q];
+    if (m > cand_cap) m = cand_cap;
+    if (tid == 0) o[k] = eps[q];
+    if (m < k) { for (int j = tid; j < k; j += 256) o[j] = -INFINITY; return; }
+    const uint64_t* c = cand + (int64_t)q * cand_cap;
+    for (int i = tid; i < m; i += 256) s[i] = c[i];
+    if (tid == 0) wc = 0u;
+    __syncthreads();
+    const uint32_t vk = radix_select_desc<256>(s, m, k, hist, tid);                      // k-th best (order-preserving bits)
+    for (int i = tid; i < m; i += 256) {
+        const uint32_t v = (uint32_t)(s[i] >> 32);
+        if (v > vk) { const unsigned pos = atomicAdd(&wc, 1u); o[pos] = ord_f32(v); }    // strictly better than the k-th: fewer than k of them
+    }
+    __syncthreads();
+    for (int j = (int)wc + tid; j < k; j += 256) o[j] = ord_f32(vk);                    // the k-th best and its ties fill the rest
+}
+
+// k_global_theta: the gathered [nshards][nq][k + 1] lists -> per query the k-th best coarse score of ALL shards b_G and the largest error bound e_max;
+// theta_ext[q] = b_G - (e_max + eps_local[q]): the k rows with the best coarse scores have exact scores >= b_G - e_max, so a row of the exact global top-k
+// has exact >= b_G - e_max and therefore, on a shard with bound eps_local, coarse >= b_G - e_max - eps_local.
+__global__ __launch_bounds__(256) void k_global_theta(const float* __restrict__ gathered, int nshards, int64_t shard_stride, int k, const float* __restrict__ eps_local,
+                                                      float* __restrict__ theta_ext) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* s = reinterpret_cast<uint64_t*>(smem);
+    unsigned int* hist = reinterpret_cast<unsigned int*>(s + (size_t)nshards * k);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int m = nshards * k;
+    for (int i = tid; i < m; i += 256) {
+        const int w = i / k, j = i - w * k;
+        s[i] = make_key(gathered[w * shard_stride + (int64_t)q * (k + 1) + j], (uint32_t)i);
+    }
+    __syncthreads();
+    const float bg = ord_f32(radix_select_desc<256>(s, m, k, hist, tid));
+    if (tid == 0) {
+        float emax = 0.f;
+        for (int w = 0; w < nshards; ++w) emax = fmaxf(emax, gathered[w * shard_stride + (int64_t)q * (k + 1) + k]);
+        const float t = bg - (emax + eps_local[q]) * 1.000001f;
+        theta_ext[q] = (t == t) ? t : -INFINITY;
     }
 }
 
@@ -1244,11 +1303,12 @@ static int run_rounds(Index* ix, CoarseArgs& a, int64_t n_rows, int nq, int bm, 
     return 0;
 }
 
-static int launch_rerank(Index* ix, int nq, int k, int rmax, int final_preset, const float* qf, const int* qmap, float* theta_out, hipStream_t st) {
+static int launch_rerank(Index* ix, int nq, int k, int rmax, int final_preset, const float* qf, const int* qmap, float* theta_out, hipStream_t st,
+                         const float* theta_ext = nullptr) {
     const size_t rer_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + (size_t)rmax * sizeof(uint64_t) + 264 * sizeof(unsigned int);
     auto rerank = ix->d <= 1024 ? &k_rerank<4> : ix->d <= 2048 ? &k_rerank<8> : &k_rerank<16>;   // row steps held in registers
     hipLaunchKernelGGL(rerank, dim3(nq), dim3(256), rer_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, ix->eps, qf, ix->xf, ix->d, k,
-                       final_preset, rmax, ix->out_s, ix->out_r, ix->nrer, qmap, ix->force_exact, theta_out);
+                       final_preset, rmax, ix->out_s, ix->out_r, ix->nrer, qmap, ix->force_exact, theta_out, theta_ext);
     KR_HIP(hipGetLastError());
     return 0;
 }
@@ -1287,6 +1347,8 @@ static int search_attrs(Index* ix) {
     static DevOnce sel_once;
     return once_per_device(sel_once, ix->device, [&]() -> int {   // cap = 8192 needs 64 KiB + of dynamic LDS
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_local_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_global_theta), hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_MAX * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 8192 * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 8192 * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 8192 * 8 + 264 * 4));
@@ -1309,9 +1371,22 @@ static void fill_args(const Index* ix, CoarseArgs& a) {
 // ---- pass 1 of one block of <= 1024 queries: 16-bit MFMA scan + certified re-rank.  ENQUEUE ONLY: the per-query certificate flags, the re-rank counts and
 // the list-overflow word go to the block's status record in pinned memory, the (optimistic) results straight into the caller's buffers; nothing here waits
 // for the device.  kr_index_search_finish reads the status records and re-answers the flagged queries (slow_passes).
+static int pass1_rerank(Index* ix, int nq, int k, int rmax, int final_preset, float* scores, int64_t* rows, int blk, hipStream_t st, uint32_t* status,
+                        const float* theta_ext);
+template <class T>
+static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipStream_t st, int& rounds, int& final_preset, int& rmax);
 template <class T>
 static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int blk, hipStream_t st, int& rounds, uint32_t* status) {
+    int final_preset = 0, rmax = 0;
+    KR_TRY(pass1_coarse<T>(ix, q, nq, k, blk, st, rounds, final_preset, rmax));
+    return pass1_rerank(ix, nq, k, rmax, final_preset, scores, rows, blk, st, status, nullptr);
+}
+
+// first half: queries -> 16-bit copy + bounds, the coarse rounds; leaves the candidate buffers of the block in the workspace
+template <class T>
+static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipStream_t st, int& rounds, int& final_preset, int& rmax) {
     const BlockPlan p = plan_block(ix, nq, k);
+    rmax = p.rmax;
     KR_TRY(ensure_ws(ix, k, p.cap));
     KR_TRY(search_attrs(ix));
     KR_HIP(hipMemcpyAsync(ix->q_f, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyDefault, st));
@@ -1331,7 +1406,7 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, COARSE_LDS_SMALLQ));
         return 0;
     }));
-    int final_preset = 0;
+    final_preset = 0;
     rounds = 0;
     KR_TRY(run_rounds(ix, a, ix->n, nq, bm, p.K1, p.cap, st, blk < TIMED_BLOCKS ? ix->evc + blk * 32 : nullptr, [&](const CoarseArgs& ca) -> int {
         if (p.q32) return launch_q32<T>(ca, p.kt64, ix->num_cu, ix->device, st);
@@ -1343,7 +1418,13 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
         return 0;
     }, final_preset, rounds));
     ix->st.coarse_rounds += rounds;
-    KR_TRY(launch_rerank(ix, nq, k, p.rmax, final_preset, ix->q_f, nullptr, blk < THETA_BLOCKS ? ix->theta1 + (size_t)blk * QBLK : nullptr, st));
+    return 0;
+}
+
+// second half: exactness certificate + exact re-rank of the candidates, status records and results on their way to the caller
+static int pass1_rerank(Index* ix, int nq, int k, int rmax, int final_preset, float* scores, int64_t* rows, int blk, hipStream_t st, uint32_t* status,
+                        const float* theta_ext) {
+    KR_TRY(launch_rerank(ix, nq, k, rmax, final_preset, ix->q_f, nullptr, blk < THETA_BLOCKS ? ix->theta1 + (size_t)blk * QBLK : nullptr, st, theta_ext));
     uint32_t* rec = status + (size_t)blk * STATUS_STRIDE;
     KR_HIP(hipMemcpyAsync(rec, ix->flags, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     KR_HIP(hipMemcpyAsync(rec + QBLK, ix->nrer, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1521,6 +1602,11 @@ static int finish_one(Index* ix, int64_t* flagged_out) {
     ix->pend_head = (ix->pend_head + 1) % Index::PEND_MAX; --ix->pend_n;
     if (!pd.active) return 0;
     pd.active = false;
+    if (pd.half) {      // the first half of a split search was enqueued and its second half never came: nothing to read, nothing the caller could use
+        pd.half = false;
+        (void)hipStreamSynchronize(pd.st);
+        return fail(KR_ESTATE, "kr_index_search_coarse_async without its kr_index_search_rerank_async: the search was dropped");
+    }
     KR_HIP(hipEventSynchronize(pd.ev_done));
     const bool newest = pd.seq == ix->call_seq;          // theta1 (pass 2's pre-scan bound) and the timing events hold the newest call's values
     const int nblocks = (pd.nq + QBLK - 1) / QBLK;
@@ -1566,11 +1652,68 @@ static int finish_search(Index* ix) {
     return 0;
 }
 
+// ---- row-sharded search, exchange BEFORE the re-rank (one block of <= 1024 queries): the call is split where a shard knows its candidates' coarse scores but
+// has not gathered a single fp32 row yet.  coarse half -> [the host's collective gathers every shard's k best coarse scores] -> global_theta -> re-rank half.
+// The slot of the pending ring belongs to the call from the first half on; finish / finish_ex treat it like any other call once the second half is in.
+static int begin_search_coarse(Index* ix, const float* q, int nq, int k, float* topk_out, hipStream_t st) {
+    KR_TRY(ensure_status(ix, 1));
+    while (ix->pend_n > 0 && (ix->pend[ix->pend_head].st != st || ix->pend_n == Index::PEND_MAX)) KR_TRY(finish_one(ix, nullptr));
+    if (ix->pend_n > 0 && ix->pend[(ix->pend_head + ix->pend_n - 1) % Index::PEND_MAX].half)
+        return fail(KR_ESTATE, "a split search is waiting for its kr_index_search_rerank_async");
+    if (ix->ev_add) KR_HIP(hipStreamWaitEvent(st, ix->ev_add, 0));
+    ix->force_exact = g_force_exact.load();
+    ix->st.last_coarse_ms = 0.0; ix->st.last_total_ms = 0.0; ix->st.last_fine_ms = 0.0;
+    Index::Pending& pd = ix->pend[(ix->pend_head + ix->pend_n) % Index::PEND_MAX];
+    KR_TRY(ensure_slot_status(pd, 1));
+    pd.q = q; pd.nq = nq; pd.k = k; pd.scores = nullptr; pd.rows = nullptr; pd.st = st; pd.rounds.assign(1, 0);
+    pd.seq = ++ix->call_seq;
+    ix->ws_owner = pd.seq;
+    { int K1, cap, rmax; plan_buffers(k, K1, cap, rmax); KR_TRY(ensure_ws(ix, k, cap)); }
+    KR_HIP(hipEventRecord(ix->ev[0], st));
+    int rc;
+    if (ix->coarse == KR_COARSE_BF16) rc = pass1_coarse<BF16>(ix, q, nq, k, 0, st, pd.rounds[0], pd.final_preset, pd.rmax);
+    else rc = pass1_coarse<F16>(ix, q, nq, k, 0, st, pd.rounds[0], pd.final_preset, pd.rmax);
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    hipLaunchKernelGGL(k_local_topk, dim3(nq), dim3(256), (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int), st, ix->cand, ix->cand_cap, ix->cnt, ix->eps, k,
+                       pd.final_preset, topk_out);
+    KR_HIP(hipGetLastError());
+    pd.active = true; pd.half = true;
+    ++ix->pend_n;
+    return 0;
+}
+
+static Index::Pending* half_slot(Index* ix, hipStream_t st) {
+    if (ix->pend_n == 0) return nullptr;
+    Index::Pending& pd = ix->pend[(ix->pend_head + ix->pend_n - 1) % Index::PEND_MAX];
+    return (pd.active && pd.half && pd.st == st && ix->ws_owner == pd.seq) ? &pd : nullptr;
+}
+
+static int search_global_theta(Index* ix, const float* gathered, int nshards, float* theta_out, hipStream_t st) {
+    Index::Pending* pd = half_slot(ix, st);
+    if (!pd) return fail(KR_ESTATE, "no split search is waiting on this stream (kr_index_search_coarse_async first, same stream)");
+    if (nshards <= 0 || (int64_t)nshards * pd->k > MERGE_MAX) return fail(KR_EINVAL, "nshards * k = %lld exceeds %d", (long long)nshards * pd->k, MERGE_MAX);
+    hipLaunchKernelGGL(k_global_theta, dim3(pd->nq), dim3(256), (size_t)nshards * pd->k * sizeof(uint64_t) + 264 * sizeof(unsigned int), st, gathered, nshards,
+                       (int64_t)pd->nq * (pd->k + 1), pd->k, ix->eps, theta_out);
+    KR_HIP(hipGetLastError());
+    return 0;
+}
+
+static int continue_search_rerank(Index* ix, const float* theta_ext, float* scores, int64_t* rows, hipStream_t st) {
+    Index::Pending* pd = half_slot(ix, st);
+    if (!pd) return fail(KR_ESTATE, "no split search is waiting on this stream (kr_index_search_coarse_async first, same stream, nothing else on the handle in between)");
+    pd->scores = scores; pd->rows = rows;
+    const int rc = pass1_rerank(ix, pd->nq, pd->k, pd->rmax, pd->final_preset, scores, rows, 0, st, pd->status, theta_ext);
+    if (rc) { (void)hipStreamSynchronize(st); pd->active = false; pd->half = false; --ix->pend_n; return rc; }
+    pd->half = false;
+    KR_HIP(hipEventRecord(ix->ev[3], st));
+    KR_HIP(hipEventRecord(pd->ev_done, st));
+    return 0;
+}
+
 // device-side final merge of per-shard top-k lists (the gathered lists are already in HBM after the RCCL all-gather): one block per query.
 // Every list is sorted by (score desc, id asc) with id < 0 padding at its tail, ids are globally unique, so the merged position of entry j of
 // list s is j + sum over the other lists t of the number of entries of t that precede it (binary search in LDS): no sort, no atomics on the
 // output, the result is exactly kr_topk_merge's.
-constexpr int MERGE_MAX = 8192;   // nshards * k entries per query (8 shards x k = 1024): 96 KiB of LDS
 __global__ __launch_bounds__(256) void k_merge_lists(const float* __restrict__ scores, int64_t s_stride, const int64_t* __restrict__ ids, int64_t i_stride,
                                                      int nshards, int k, float* __restrict__ out_s, int64_t* __restrict__ out_i) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1826,6 +1969,30 @@ int kr_index_search_async(kr_index* h, const float* q, int nq, int k, float* sco
     if (nq == 0) return 0;
     KR_TRY(select_device(ix->device));
     return begin_search(ix, q, nq, k, scores, rows, reinterpret_cast<hipStream_t>(stream));   // up to PEND_MAX calls outstanding per handle (one stream)
+}
+
+int kr_index_search_coarse_async(kr_index* h, const float* q, int nq, int k, float* topk, void* stream) {
+    if (!h) return fail(KR_EINVAL, "index is NULL");
+    Index* ix = reinterpret_cast<Index*>(h);
+    if (!q || !topk || nq <= 0 || nq > QBLK) return fail(KR_EINVAL, "kr_index_search_coarse_async: 0 < nq <= %d queries, non-NULL pointers", QBLK);
+    if (k <= 0 || (int64_t)k > ix->n || k > EXACT_RC) return fail(KR_EINVAL, "k=%d must satisfy 0 < k <= min(ntotal=%lld, %d)", k, (long long)ix->n, EXACT_RC);
+    if (!is_device_pointer(topk)) return fail(KR_EINVAL, "kr_index_search_coarse_async: topk must be device memory (it feeds the collective)");
+    KR_TRY(select_device(ix->device));
+    return begin_search_coarse(ix, q, nq, k, topk, reinterpret_cast<hipStream_t>(stream));
+}
+
+int kr_index_search_global_theta(kr_index* h, const float* gathered, int nshards, float* theta, void* stream) {
+    if (!h || !gathered || !theta) return fail(KR_EINVAL, "NULL argument");
+    Index* ix = reinterpret_cast<Index*>(h);
+    KR_TRY(select_device(ix->device));
+    return search_global_theta(ix, gathered, nshards, theta, reinterpret_cast<hipStream_t>(stream));
+}
+
+int kr_index_search_rerank_async(kr_index* h, const float* theta, float* scores, int64_t* rows, void* stream) {
+    if (!h || !scores || !rows) return fail(KR_EINVAL, "NULL argument");
+    Index* ix = reinterpret_cast<Index*>(h);
+    KR_TRY(select_device(ix->device));
+    return continue_search_rerank(ix, theta, scores, rows, reinterpret_cast<hipStream_t>(stream));
 }
 
 int kr_index_search_finish(kr_index* h) {

@@ -36,10 +36,13 @@ class ShardedSearcher:
     RING = 8                     # deferred searches that may be outstanding between two finish_deferred() calls (at least the world size)
     PEND_MAX = 16                # Index::PEND_MAX of csrc/search.hip: asynchronous searches one index keeps outstanding
 
-    def __init__(self, index, row_offset: int = 0, world: Optional[int] = None, group=None, collective: str = "torch"):
+    def __init__(self, index, row_offset: int = 0, world: Optional[int] = None, group=None, collective: str = "torch", exchange_first: bool = True):
         """``collective``: "torch" — ``torch.distributed.all_gather_into_tensor`` of the process group + ``kr_topk_merge_device``; "kr_comm" — the
         library's own exchange step (``kr_shard_allgather_topk``: RCCL all-gather + merge behind the C ABI, include/kirag_amd.h); the process group is
-        then only used once, to hand rank 0's communicator id to the other ranks."""
+        then only used once, to hand rank 0's communicator id to the other ranks.
+        ``exchange_first`` (round 5; the deferred path only): the shards exchange their k best COARSE scores per query before anybody re-ranks, so that a rank
+        gathers fp32 rows only for candidates above the GLOBAL k-th best score (~k / W + the error band per query instead of ~2.5 k: the ~0.3 ms of re-rank per
+        1000-query batch every rank paid at any world size); False = every shard certifies its own top-k first (rounds 2-4)."""
         import torch.distributed as dist
         self.index = index
         self.row_offset = int(row_offset)
@@ -48,6 +51,7 @@ class ShardedSearcher:
         if collective not in ("torch", "kr_comm"):
             raise ValueError("collective must be 'torch' or 'kr_comm'")
         self.collective = collective
+        self.exchange_first = bool(exchange_first)
         self._comm = None
         self._outstanding = []
         self.redone = 0              # deferred batches whose exchange was repeated because some rank re-answered queries (finish_deferred)
@@ -122,8 +126,16 @@ class ShardedSearcher:
         mine, loc = self._slots[j]
         ids = mine[:nq * k * 8].view(torch.int64).view(nq, k)
         sc = mine[nq * k * 8:nq * k * 12].view(torch.float32).view(nq, k)
-        self.index.search_async(q, k, sc, loc)               # local rows; finish() may re-write rows of loc / sc for uncertified queries
-        torch.add(loc, self.row_offset, out=ids)
+        if self.exchange_first and self.world > 1:
+            # coarse scan -> all-gather of the shards' k best coarse scores (+ error bound) per query -> the global bound -> re-rank above it: enqueue only
+            tk, tk_all, theta = self._topk_bufs(nq, k, dev)
+            self.index.search_coarse_async(q, k, tk)
+            dist.all_gather_into_tensor(tk_all, tk, group=self.group)
+            self.index.search_global_theta(tk_all, self.world, theta)
+            self.index.search_rerank_async(theta, sc, loc)       # may return fewer than k rows of this shard: (-inf, -1) at the tail
+        else:
+            self.index.search_async(q, k, sc, loc)               # local rows; finish() may re-write rows of loc / sc for uncertified queries
+        self._global_rows(loc, ids)
         self._exchange(mine, sc, ids, nq, k, dev)
         ps, pi = self._ring[j]
         ps.copy_(self._out_s, non_blocking=True); pi.copy_(self._out_i, non_blocking=True)
@@ -171,7 +183,7 @@ class ShardedSearcher:
                 mine, loc = self._slots[j]
                 ids = mine[:nq * k * 8].view(torch.int64).view(nq, k)
                 sc = mine[nq * k * 8:nq * k * 12].view(torch.float32).view(nq, k)
-                torch.add(loc, self.row_offset, out=ids)
+                self._global_rows(loc, ids)
                 self._exchange(mine, sc, ids, nq, k, dev)
                 ps, pi = self._ring[j]
                 ps.copy_(self._out_s, non_blocking=True); pi.copy_(self._out_i, non_blocking=True)
@@ -217,6 +229,23 @@ class ShardedSearcher:
         dist.all_gather_into_tensor(all_s, sc, group=self.group)
         dist.all_gather_into_tensor(all_i, ids, group=self.group)
         return merge_topk(all_s.view(self.world, nq, k).numpy(), all_i.view(self.world, nq, k).numpy(), k)
+
+    def _global_rows(self, loc, ids):
+        """local row numbers -> global ones, padding (-1) kept as padding"""
+        import torch
+        torch.add(loc, self.row_offset, out=ids)
+        if self.exchange_first:
+            ids.masked_fill_(loc < 0, -1)
+
+    def _topk_bufs(self, nq: int, k: int, dev):
+        import torch
+        key = (nq, k, self.world, dev)
+        if getattr(self, "_tk_key", None) != key:
+            self._tk = torch.empty((nq, k + 1), dtype=torch.float32, device=dev)
+            self._tk_all = torch.empty((self.world * nq, k + 1), dtype=torch.float32, device=dev)
+            self._theta = torch.empty((nq,), dtype=torch.float32, device=dev)
+            self._tk_key = key
+        return self._tk, self._tk_all, self._theta
 
     def _buffers(self, nq: int, k: int, dev):
         """persistent device / pinned buffers for (nq, k): this rank's block of the gather buffer, the gathered blocks, the merged result, and one

@@ -146,6 +146,38 @@ class FlatIPIndex:
         _lib.check(self._lib.kr_index_search_async(self._h, int(q.data_ptr()), nq, k, int(scores_out.data_ptr()), int(rows_out.data_ptr()),
                                                    self._stream(q, scores_out, rows_out)))
 
+    def search_coarse_async(self, q, k: int, topk_out) -> None:
+        """First half of the split search of a row shard (``kr_index_search_coarse_async``): the coarse scan of at most 1024 queries, enqueue only;
+        ``topk_out`` (float32 CUDA tensor [nq, k + 1]) receives this shard's k best coarse scores per query and the query's error bound — what the shards
+        exchange BEFORE anybody re-ranks (``ShardedSearcher``)."""
+        import torch
+        if not (torch.is_tensor(q) and q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()):
+            raise ValueError("search_coarse_async needs a contiguous float32 CUDA tensor of queries")
+        nq, k = int(q.shape[0]), int(k)
+        if q.ndim != 2 or q.shape[1] != self.d or not 0 < nq <= 1024:
+            raise ValueError(f"expected [1..1024,{self.d}] queries, got {tuple(q.shape)}")
+        if not 0 < k <= self.ntotal:
+            raise ValueError(f"top_docs={k} must satisfy 0 < k <= ntotal={self.ntotal}")
+        assert tuple(topk_out.shape) == (nq, k + 1) and topk_out.is_cuda and topk_out.is_contiguous() and topk_out.dtype == torch.float32
+        if not isinstance(getattr(self, "_pending", None), list):
+            self._pending = []
+        self._pending.append((q, topk_out))
+        _lib.check(self._lib.kr_index_search_coarse_async(self._h, int(q.data_ptr()), nq, k, int(topk_out.data_ptr()), self._stream(q)))
+
+    def search_global_theta(self, gathered, nshards: int, theta_out) -> None:
+        """``gathered``: the shards' ``topk_out`` blocks one after the other ([nshards * nq, k + 1], any rank order) -> ``theta_out`` [nq]: the bound below
+        which a row of THIS shard cannot be in the global top-k (``kr_index_search_global_theta``; same stream as the two halves)."""
+        assert gathered.is_cuda and gathered.is_contiguous() and theta_out.is_cuda and theta_out.is_contiguous()
+        _lib.check(self._lib.kr_index_search_global_theta(self._h, int(gathered.data_ptr()), int(nshards), int(theta_out.data_ptr()), self._stream(gathered)))
+
+    def search_rerank_async(self, theta, scores_out, rows_out) -> None:
+        """Second half: certificate + exact re-rank above ``theta`` (a float32 CUDA tensor [nq], or None = the shard's own bound only); a query may come back with
+        fewer than k rows, the tail then is (-inf, -1).  Final after ``finish()``."""
+        assert scores_out.is_contiguous() and rows_out.is_contiguous()
+        self._pending.append((theta, scores_out, rows_out))
+        _lib.check(self._lib.kr_index_search_rerank_async(self._h, int(theta.data_ptr()) if theta is not None else None, int(scores_out.data_ptr()),
+                                                          int(rows_out.data_ptr()), self._stream(scores_out, rows_out, *( [theta] if theta is not None else []))))
+
     def finish(self):
         """Finish EVERY outstanding ``search_async`` call (up to 16 may be enqueued back to back on one stream).  Returns, per call and oldest first,
         the number of its queries that pass 1 could not certify: for those the rows of the call's output tensors were re-written by passes 2 / 3 after

@@ -148,6 +148,68 @@ def test_search_knn_pipelined_blocks_equal_the_block_by_block_form():
     assert ix.index.stats()["fine"] + ix.index.stats()["exact"] > 0     # the uncertified queries really went through passes 2 / 3
 
 
+def test_split_search_exchange_before_rerank_two_shards_in_one_process():
+    """Round 5: kr_index_search_coarse_async -> [gather of the shards' k best coarse scores] -> kr_index_search_global_theta ->
+    kr_index_search_rerank_async.  Two row shards of one corpus held by two indexes of ONE process, the gather done by hand: the merged lists must be the
+    unsharded canonical answer bit for bit, every shard must re-rank FEWER rows than its stand-alone search (that is the point) and return padded tails;
+    theta = None must reproduce kr_index_search_async exactly; a first half without its second half is reported by finish."""
+    import torch
+    from kirag_amd import _lib
+    from kirag_amd.retriever.index import FlatIPIndex
+    rng = np.random.default_rng(23)
+    n, d, nq, k = 60000, 256, 200, 100
+    x = _unit(rng, n, d)
+    x[n // 2 + 3] = x[5]                                            # a tie across the shard boundary
+    q = (x[rng.choice(n, nq)] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    so, io = S.search_canonical(q, x, k)
+    cuts = [0, 26000, n]                                            # uneven shards
+    shards = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ix = FlatIPIndex(d); ix.add(torch.from_numpy(x[a:b]).cuda()); shards.append((ix, a))
+    qd = torch.from_numpy(q).cuda()
+    # stand-alone searches: the rows each shard re-ranks when it certifies its own top-k
+    alone = []
+    for ix, a in shards:
+        ix.stats(reset=True); ix.search(qd, k); alone.append(ix.stats()["reranked_rows"])
+    # split form
+    tks = [torch.empty((nq, k + 1), dtype=torch.float32, device="cuda") for _ in shards]
+    for (ix, a), tk in zip(shards, tks):
+        ix.stats(reset=True)
+        ix.search_coarse_async(qd, k, tk)
+    gathered = torch.cat(tks[::-1], dim=0).contiguous()            # "any rank order"
+    outs = []
+    for (ix, a) in shards:
+        theta = torch.empty((nq,), dtype=torch.float32, device="cuda")
+        sc = torch.empty((nq, k), dtype=torch.float32, device="cuda"); rw = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        ix.search_global_theta(gathered, len(shards), theta)
+        ix.search_rerank_async(theta, sc, rw)
+        assert ix.finish() == [0]                                   # one call outstanding, every query certified
+        outs.append((sc.cpu().numpy(), rw.cpu().numpy(), a))
+    split_rows = [ix.stats()["reranked_rows"] for ix, _ in shards]
+    assert all(s_ < 0.6 * a_ for s_, a_ in zip(split_rows, alone)), (split_rows, alone)
+    sc_all = np.stack([o[0] for o in outs]); id_all = np.stack([np.where(o[1] >= 0, o[1] + o[2], -1) for o in outs])
+    assert (id_all < 0).any() and np.isneginf(sc_all[id_all < 0]).all()      # shards really returned fewer than k rows for some queries
+    for o in outs:                                                  # padding only at the tail, lists sorted
+        valid = o[1] >= 0
+        assert (valid[:, :-1] >= valid[:, 1:]).all()
+    ms = np.empty((nq, k), np.float32); mi = np.empty((nq, k), np.int64)
+    _lib.check(_lib.load().kr_topk_merge(np.ascontiguousarray(sc_all).ctypes.data, np.ascontiguousarray(id_all).ctypes.data, len(shards), nq, k, ms.ctypes.data, mi.ctypes.data))
+    assert np.array_equal(mi, io) and np.array_equal(ms.view(np.uint32), so.view(np.uint32))
+    # theta = None: the shard's own answer, exactly kr_index_search_async's
+    ix, a = shards[0]
+    tk = tks[0]
+    sc = torch.empty((nq, k), dtype=torch.float32, device="cuda"); rw = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    ix.search_coarse_async(qd, k, tk); ix.search_rerank_async(None, sc, rw); ix.finish()
+    s1, i1 = ix.search(qd, k)
+    assert np.array_equal(rw.cpu().numpy(), i1) and np.array_equal(sc.cpu().numpy().view(np.uint32), s1.view(np.uint32))
+    # a dropped second half
+    ix.search_coarse_async(qd, k, tk)
+    with pytest.raises(_lib.KiragAmdError, match="rerank"):
+        ix.finish()
+    s2, i2 = ix.search(qd, k)                                       # the handle is usable again
+    assert np.array_equal(i2, i1)
+
+
 def test_duplicates_tie_rule_and_k_equals_n():
     rng = np.random.default_rng(10)
     x = _unit(rng, 500, 64)
