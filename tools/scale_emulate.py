@@ -6,9 +6,9 @@ two encode schedules of bench.py:
   batch    blocks of up to W steps: every rank encodes its 1 / W slice of each batch of the block in ONE forward (default; round 4: a partial last block
            of c < W steps is a forward of c * 1000 / W queries per rank instead of a full batch on c ranks and nothing on the others)
 The driver runs `--steps 20`: at W = 8 that is two full blocks and one block of 4 steps; the K = 20 line uses the measured forward of 4 * 125 = 500 queries.
-The two all-gathers cannot be measured on a one-GPU box; they are ESTIMATED (marked est.) as a ring all-gather at 100 GB/s per direction of the
+The all-gathers cannot be measured on a one-GPU box; they are ESTIMATED (marked est.) as a ring all-gather at 100 GB/s per direction of the
 7 x 153 GB/s xGMI links plus 20 us of latency per collective: per step  queries: 4 MB of query vectors + 1.2 MB x W of results;  batch: 4 MB (its share
-of the block gather) + 1.2 MB x W.  Usage: python tools/scale_emulate.py [total_rows] [steps]"""
+of the block gather) + 1.2 MB x W; round 5 adds the split search's gather of 0.4 MB x W of coarse scores.  Usage: python tools/scale_emulate.py [total_rows] [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -46,8 +46,28 @@ for world in (1, 2, 4, 8):
     ms_e, _ = timed(lambda: enc.forward(ids[:mine], mask[:mine], 0))
     qv = enc.forward(ids, mask, 0)
     sc = torch.empty((nq, k), dtype=torch.float32, device=dev); rows = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    ms_s, _ = timed(lambda: ix.search_into(qv, k, sc, rows))
+    ms_own, _ = timed(lambda: ix.search_into(qv, k, sc, rows))      # every shard certifies and re-ranks its OWN top-k (rounds 2-4)
     coarse = ix.stats()["last_coarse_ms"]
+    ms_s = ms_own
+    rer_own = rer_split = None
+    if world > 1:
+        # round 5: the exchange BEFORE the re-rank (kr_index_search_coarse_async -> all-gather of the k best coarse scores -> global bound -> re-rank above it).
+        # The W shards of the synthetic corpus are statistically alike, so W copies of this shard's list stand in for the gathered lists: the k-th best of the
+        # union of W equal lists is this shard's (k / W)-th best — the bound a real rank would get.  The all-gather itself (nq x (k + 1) floats per rank) is estimated below.
+        tk = torch.empty((nq, k + 1), dtype=torch.float32, device=dev); theta = torch.empty((nq,), dtype=torch.float32, device=dev)
+        gathered = torch.empty((world * nq, k + 1), dtype=torch.float32, device=dev)
+
+        def split():
+            ix.search_coarse_async(qv, k, tk)
+            for w in range(world):
+                gathered[w * nq:(w + 1) * nq].copy_(tk)
+            ix.search_global_theta(gathered, world, theta)
+            ix.search_rerank_async(theta, sc, rows)
+            ix.finish()
+        ix.stats(reset=True); ix.search_into(qv, k, sc, rows); rer_own = ix.stats()["reranked_rows"] / nq
+        ix.stats(reset=True); split(); rer_split = ix.stats()["reranked_rows"] / nq
+        ms_s, _ = timed(split)
+        ix.search_into(qv, k, sc, rows)                                # full local lists for the merge timing below
     # the W gathered lists (here: W copies of the local one, with distinct id ranges) merged on the device + the D2H of the final [nq, k]
     block = (nq * k * 12 + 15) // 16 * 16
     allb = torch.empty(world * block, dtype=torch.uint8, device=dev)
@@ -68,8 +88,9 @@ for world in (1, 2, 4, 8):
     if world == 1:
         ms_full = ms_e                                         # the full-batch encode: what a rank pays once per W steps under the batch schedule
     gather = lambda mb: 0.0 if world == 1 else (0.02 + mb * (world - 1) / world / 100.0)      # ms: ring all-gather of `mb` MB in total at 100 GB/s + 20 us
-    coll_q = gather(4.0) + gather(1.2 * world)                  # queries schedule, per step
-    coll_b = gather(4.0 * world) / world + gather(1.2 * world)  # batch schedule, per step
+    tk_mb = nq * (k + 1) * 4 / 1e6 * world                      # the extra all-gather of the split search: every rank's k best coarse scores + bound per query
+    coll_q = gather(4.0) + gather(1.2 * world) + gather(tk_mb)                  # queries schedule, per step
+    coll_b = gather(4.0 * world) / world + gather(1.2 * world) + gather(tk_mb)  # batch schedule, per step
     tot_q = ms_e + ms_s + ms_m
     tot_b = ms_full / world + ms_s + ms_m
     # K steps = K // W full blocks + one block of c = K % W steps, whose encode is ONE forward of c * nq / W queries per rank
@@ -78,7 +99,8 @@ for world in (1, 2, 4, 8):
     tot_k = ((K // world) * ms_full + ms_part) / K + ms_s + ms_m
     base_k = globals().setdefault("base_k", tot_k)
     base = base or tot_q
-    print(f"W={world}: encode {mine} queries {ms_e:.2f} ms | search 1000 x {n} rows {ms_s:.2f} ms (coarse {coarse:.2f}) | device merge + D2H of the result {ms_m:.2f} ms\n"
+    split_note = "" if world == 1 else f" [own top-k first: {ms_own:.2f} ms, {rer_own:.0f} re-ranked rows per query; exchange first: {rer_split:.0f}]"
+    print(f"W={world}: encode {mine} queries {ms_e:.2f} ms | search 1000 x {n} rows {ms_s:.2f} ms (coarse {coarse:.2f}){split_note} | device merge + D2H of the result {ms_m:.2f} ms\n"
           f"      queries schedule: {tot_q:.2f} ms per step (x{base / tot_q:.2f}); with est. collectives {tot_q + coll_q:.2f} ms (x{base / (tot_q + coll_q):.2f})\n"
           f"      batch schedule:   full-batch encode {ms_full:.2f} ms per {world} steps -> {tot_b:.2f} ms per step (x{base / tot_b:.2f}); "
           f"with est. collectives {tot_b + coll_b:.2f} ms (x{base / (tot_b + coll_b):.2f})\n"
