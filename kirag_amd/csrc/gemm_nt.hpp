@@ -384,6 +384,9 @@ __device__ __forceinline__ void gemm_nt_split(const uint16_t* __restrict__ A, in
 // =====================================================================================================================
 using ShapeSkinny = GemmShape<32, 32, 1, 1>;
 constexpr int SKINNY_STAGE = 8192;                         // bytes per K-tile of the 1 x 1 shape
+#ifndef SKINNY_GROUP
+#define SKINNY_GROUP 2                                     // K-tiles per barrier at most (4 needs a ring of 16 and measured the same as 2: profiles/r05/tried_skinny_prologue.txt); 1 = rounds 1-4
+#endif
 template <int WM, int WN> struct SkinnyGeom {
     static constexpr int NC = WM * WN;                     // multiplying waves
     static constexpr int THREADS = (NC + 4) * 64;
@@ -410,7 +413,7 @@ template <class T, int RING, int WM = 1, int WN = 1, bool SWAP = false, class Pr
 __device__ __forceinline__ bool gemm_nt_skinny(const uint16_t* __restrict__ A, int64_t lda, const int* __restrict__ Mp, int64_t m0, const uint16_t* __restrict__ B, int64_t ldb,
                                                int64_t N, int64_t n0, int K, char* smem, Pre&& pre, Epilogue&& epi) {
     using G = SkinnyGeom<WM, WN>;
-    static_assert(RING >= 4 && (RING & (RING - 1)) == 0 && G::PPW * (RING - 1) <= 60, "ring depth: a power of two, its pieces countable by s_waitcnt vmcnt");
+    static_assert(RING >= 8 && (RING & (RING - 1)) == 0 && G::PPW * (RING - 1) <= 60, "ring depth: a power of two, its pieces countable by s_waitcnt vmcnt");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -446,10 +449,30 @@ __device__ __forceinline__ bool gemm_nt_skinny(const uint16_t* __restrict__ A, i
             for (int i = 0; i < WN; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(pb[i] + (int64_t)pf * 128), (lds_void*)(st + G::A_BYTES + (lw + 4 * i) * 1024), 16, 0, 0);
             ++pf;
         };
-        for (int p = 0; p < RING - 1; ++p)
-            if (pf < nk) stage_next();                 // tile by tile (A, B): a tile is complete as soon as its own pieces have landed (vmcnt retires in order)
         // pieces that may stay in flight when K-tiles 0 .. need must have landed
         auto allowed = [&](int need) { return G::PPW * (pf - 1 - need); };
+        // GRP K-tiles per barrier (round 5): the multiplying waves' four MFMAs per K-tile are 128 cycles, a barrier round trip with five to eight waves is
+        // half of that again.  At barrier j tiles GRP j .. GRP j + GRP - 1 (multiplied in full) and GRP j + GRP (its first fragments are prefetched) are
+        // resident; behind it the slots of the previous GRP tiles are free and GRP new tiles are issued.  Same MFMAs in the same order.
+        auto grouped = [&](auto grp_tag) {
+            constexpr int GRP = decltype(grp_tag)::value;
+            for (int p = 0; p < RING - GRP; ++p)
+                if (pf < nk) stage_next();
+            constexpr int FULLG = G::PPW * (RING - 2 * GRP - 1);   // tiles GRP j .. GRP j + GRP landed, the younger ones in flight
+            wait_vmcnt_upto<FULLG>(allowed(nk > GRP ? GRP : nk - 1));
+            __builtin_amdgcn_s_barrier();                                    // start barrier
+            for (int g = 0; g < nk; g += GRP) {
+                wait_vmcnt_upto<FULLG>(allowed(g + GRP < nk ? g + GRP : nk - 1));
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int i = 0; i < GRP; ++i)
+                    if (pf < nk) stage_next();                               // -> the slots of tiles g - GRP .. g - 1
+            }
+        };
+        if (SKINNY_GROUP >= 4 && RING >= 16 && (nk & 3) == 0) { grouped(std::integral_constant<int, 4>{}); return true; }
+        if (SKINNY_GROUP >= 2 && (nk & 1) == 0) { grouped(std::integral_constant<int, 2>{}); return true; }
+        for (int p = 0; p < RING - 1; ++p)
+            if (pf < nk) stage_next();                 // tile by tile (A, B): a tile is complete as soon as its own pieces have landed (vmcnt retires in order)
         constexpr int FULL = G::PPW * (RING - 3);      // tiles g, g+1 landed, RING - 3 younger ones in flight
         wait_vmcnt_upto<FULL>(allowed(nk > 1 ? 1 : 0));
         __builtin_amdgcn_s_barrier();                                        // start barrier: tiles 0 and 1 resident
@@ -479,6 +502,22 @@ __device__ __forceinline__ bool gemm_nt_skinny(const uint16_t* __restrict__ A, i
     for (int r = 0; r < 16; ++r) acc.v[0][0][r] = 0.f;
     __builtin_amdgcn_s_barrier();                          // start barrier
     load_frags(0, 0, 0); load_frags(0, 1, 1);
+    auto grouped = [&](auto grp_tag) {
+        constexpr int GRP = decltype(grp_tag)::value;
+        for (int g = 0; g < nk; g += GRP) {
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 4 * GRP; ++ks) {         // k-steps of tiles g .. g + GRP - 1; the fragments of k-step ks + 2 are requested now
+                load_frags(g + ((ks + 2) >> 2), (ks + 2) & 3, (ks + 2) & 3);      // the last two: tile g + GRP (past the end: a stale slot, never used)
+                __builtin_amdgcn_sched_barrier(0);
+                acc.v[0][0] = SWAP ? T::mfma(bf[ks & 3], af[ks & 3], acc.v[0][0]) : T::mfma(af[ks & 3], bf[ks & 3], acc.v[0][0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        epi(acc, m0 + wm * 32, n0 + wn * 32);
+    };
+    if (SKINNY_GROUP >= 4 && RING >= 16 && (nk & 3) == 0) { grouped(std::integral_constant<int, 4>{}); return true; }
+    if (SKINNY_GROUP >= 2 && (nk & 1) == 0) { grouped(std::integral_constant<int, 2>{}); return true; }
     for (int g = 0; g < nk; ++g) {
         __builtin_amdgcn_s_barrier();
 #pragma unroll
