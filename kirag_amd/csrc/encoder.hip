@@ -224,6 +224,65 @@ __global__ __launch_bounds__(64) void k_fill_tokens(const int64_t* __restrict__ 
     if (lane < padded - n) { tok_id[o + n + lane] = 0; tok_pos[o + n + lane] = 0; tok_type[o + n + lane] = 0; }
 }
 
+// the three kernels above as ONE single-block launch for small batches (B <= PACK_SMALL_B; a 32-token forward is launch-bound, round 5): wave w counts,
+// then wave 0 scans, then wave w fills — the same per-sequence code in the same order, two launches less per forward
+constexpr int PACK_SMALL_B = 64;
+__global__ __launch_bounds__(1024) void k_pack_small(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, const int64_t* __restrict__ tt, int B, int S, int vocab,
+                                                     int type_vocab, int pool, int align, int* __restrict__ nk, int* __restrict__ has0, int* __restrict__ nq, int* __restrict__ off,
+                                                     int* __restrict__ cls, int* __restrict__ T, int* __restrict__ tok_id, int* __restrict__ tok_pos, int* __restrict__ tok_type,
+                                                     int* __restrict__ err) {
+    __shared__ int s_nk[PACK_SMALL_B], s_h0[PACK_SMALL_B], s_nq[PACK_SMALL_B], s_off[PACK_SMALL_B];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < B; b += 16) {                       // k_seq_len
+        int c = 0;
+        for (int p = lane; p < S; p += 64) c += (mask[(int64_t)b * S + p] != 0) ? 1 : 0;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+        if (lane == 0) { const int h = (mask[(int64_t)b * S] != 0) ? 1 : 0; s_nk[b] = c; s_h0[b] = h; nk[b] = c; has0[b] = h; }
+    }
+    __syncthreads();
+    if (wave == 0) {                                           // k_seq_scan (B <= 64: one pass)
+        const int b = lane;
+        int n = 0;
+        if (b < B) { n = s_nk[b] + ((pool == KR_POOL_CLS && !s_h0[b]) ? 1 : 0); nq[b] = n; s_nq[b] = n; cls[b] = s_h0[b] ? 0 : s_nk[b]; }
+        const int padded = (n + align - 1) & ~(align - 1);
+        int incl = padded;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (b < B) { off[b] = incl - padded; s_off[b] = incl - padded; }
+        if (lane == 63) *T = incl;
+    }
+    __syncthreads();
+    for (int b = wave; b < B; b += 16) {                       // k_fill_tokens
+        const int o = s_off[b];
+        int run = 0;
+        for (int base = 0; base < S; base += 64) {
+            const int p = base + lane;
+            const bool v = (p < S) && (mask[(int64_t)b * S + p] != 0);
+            const unsigned long long bal = __ballot(v);
+            if (v) {
+                const int r = run + __popcll(bal & ((1ull << lane) - 1ull));
+                int64_t id = ids[(int64_t)b * S + p];
+                if (id < 0 || id >= vocab) { atomicOr(err, 1); id = 0; }
+                int64_t ty = tt ? tt[(int64_t)b * S + p] : 0;
+                if (ty < 0 || ty >= type_vocab) { atomicOr(err, 4); ty = 0; }
+                tok_id[o + r] = (int)id; tok_pos[o + r] = p; tok_type[o + r] = (int)ty;
+            }
+            run += __popcll(bal);
+        }
+        const int n = s_nq[b];
+        if (lane == 0 && n > s_nk[b]) {
+            int64_t id = ids[(int64_t)b * S];
+            if (id < 0 || id >= vocab) { atomicOr(err, 1); id = 0; }
+            int64_t ty = tt ? tt[(int64_t)b * S] : 0;
+            if (ty < 0 || ty >= type_vocab) { atomicOr(err, 4); ty = 0; }
+            tok_id[o + s_nk[b]] = (int)id; tok_pos[o + s_nk[b]] = 0; tok_type[o + s_nk[b]] = (int)ty;
+        }
+        const int padded = (n + align - 1) & ~(align - 1);
+        if (lane < padded - n) { tok_id[o + n + lane] = 0; tok_pos[o + n + lane] = 0; tok_type[o + n + lane] = 0; }
+    }
+}
+
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -1263,57 +1322,69 @@ __global__ __launch_bounds__(ADMA_THREADS, 512 / ADMA_THREADS) void k_attn_dma(c
 
 // pooling + L2 normalisation: one block per sequence.  Mean pooling: wave w sums the tokens t = w, w+4, ... (8-byte loads of the (hi, lo)
 // stream, 4 columns per lane and step), the four partial sums are combined in a fixed order (w = 0..3), so the result is deterministic.
-__global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, const uint8_t* __restrict__ xlo, const int* __restrict__ seq_off, const int* __restrict__ seq_nk,
-                                              const int* __restrict__ seq_cls, int H, int pool, float* __restrict__ out, int* __restrict__ err) {
-    __shared__ float part[4][2048];   // H <= 2048
-    __shared__ float red[4];
+// pooling + L2 normalisation: one block of 16 waves per sequence.  Masked mean: wave w sums tokens w, w + 16, ... (in that order), the 16 partial rows are added
+// in wave order — a fixed order per sequence, whatever the batch.  (Rounds 1-4 used 4 waves: the kernel is bound by the VALU work of decoding and adding
+// 262 k elements for a 256-token sequence on ONE block, 37 us — 2.7 % of a one-sequence forward; 16 waves: see profiles/r05.)
+constexpr int POOL_WAVES = 16;
+template <int NJ>     // 256-element steps that cover a row: H <= 256 NJ
+__global__ __launch_bounds__(POOL_WAVES * 64) void k_pool(const uint16_t* __restrict__ xb, const uint8_t* __restrict__ xlo, const int* __restrict__ seq_off,
+                                                         const int* __restrict__ seq_nk, const int* __restrict__ seq_cls, int H, int pool, float* __restrict__ out,
+                                                         int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* part = reinterpret_cast<float*>(smem);                     // [POOL_WAVES][NJ * 256]
+    float* red = part + POOL_WAVES * NJ * 256;                        // [POOL_WAVES]
+    constexpr int HP = NJ * 256;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t off = seq_off[b];
     const int nk = seq_nk[b];
-    float4 acc[8];
+    float4 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int t_begin = pool == KR_POOL_CLS ? (wave == 0 ? seq_cls[b] : 1 << 30) : wave;
     const int t_end = pool == KR_POOL_CLS ? (wave == 0 ? seq_cls[b] + 1 : 0) : nk;
-    // four of the wave's tokens per step: all their loads are issued before the first add (a long sequence is a chain of memory round trips for its
-    // one block); the adds keep the order t, t+4, t+8, ... so the result does not depend on the unrolling
-    for (int t = t_begin; t < t_end; t += 16) {
-        ushort4 hi[4][8]; unsigned int lo[4][8];
+    // PU of the wave's tokens per step: all their loads are issued before the first add; the adds keep the order t, t + 16, t + 32, ... so the result does
+    // not depend on the unrolling
+    constexpr int PU = NJ <= 4 ? 4 : 2;       // 16 waves per block: 128 registers per lane
+    for (int t = t_begin; t < t_end; t += POOL_WAVES * PU) {
+        ushort4 hi[PU][NJ]; unsigned int lo[PU][NJ];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < PU; ++u)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int i = lane * 4 + j * 256;
-                if (i < H && t + 4 * u < t_end) {
-                    hi[u][j] = *reinterpret_cast<const ushort4*>(xb + (off + t + 4 * u) * H + i);
-                    lo[u][j] = xlo ? *reinterpret_cast<const unsigned int*>(xlo + (off + t + 4 * u) * H + i) : 0x80808080u;
+                if (i < H && t + POOL_WAVES * u < t_end) {
+                    hi[u][j] = *reinterpret_cast<const ushort4*>(xb + (off + t + POOL_WAVES * u) * H + i);
+                    lo[u][j] = xlo ? *reinterpret_cast<const unsigned int*>(xlo + (off + t + POOL_WAVES * u) * H + i) : 0x80808080u;
                 }
             }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < PU; ++u)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int i = lane * 4 + j * 256;
-                if (i < H && t + 4 * u < t_end) {
+                if (i < H && t + POOL_WAVES * u < t_end) {
                     acc[j].x += lo_decode(lo[u][j] & 0xffu, ET::to_f32(hi[u][j].x)); acc[j].y += lo_decode((lo[u][j] >> 8) & 0xffu, ET::to_f32(hi[u][j].y));
                     acc[j].z += lo_decode((lo[u][j] >> 16) & 0xffu, ET::to_f32(hi[u][j].z)); acc[j].w += lo_decode(lo[u][j] >> 24, ET::to_f32(hi[u][j].w));
                 }
             }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int i = lane * 4 + j * 256;
-        if (i < H) *reinterpret_cast<float4*>(&part[wave][i]) = acc[j];
+        if (i < H) *reinterpret_cast<float4*>(&part[wave * HP + i]) = acc[j];
     }
     __syncthreads();
-    float v[8];
+    constexpr int VJ = (NJ * 256 + POOL_WAVES * 64 - 1) / (POOL_WAVES * 64);      // elements per thread of the pooled row
+    float v[VJ];
     float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = tid + j * 256;
+    for (int j = 0; j < VJ; ++j) {
+        const int i = tid + j * POOL_WAVES * 64;
         v[j] = 0.f;
         if (i < H) {
-            const float s = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
+            float s = part[i];
+#pragma unroll
+            for (int w = 1; w < POOL_WAVES; ++w) s += part[w * HP + i];
             v[j] = pool == KR_POOL_CLS ? s : s / (float)nk;   // nk == 0 -> 0/0 = NaN like average_pool (encoders.py:56-58)
             ss += v[j] * v[j];
         }
@@ -1322,15 +1393,18 @@ __global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xb, c
     for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
-    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    float n2 = red[0];
+#pragma unroll
+    for (int w = 1; w < POOL_WAVES; ++w) n2 += red[w];
+    const float nrm = sqrtf(n2);
     // A sequence WITH attended tokens whose pooled vector is not finite: an activation left the 16-bit operand range upstream (f16: |x| > 65504 becomes
     // inf, the next LayerNorm row NaN) or the weights hold NaN / Inf.  Recorded in the sticky error word (bit 1) and reported like an out-of-vocabulary
     // token id (kr_encoder_check: KR_ERANGE) instead of being returned as an embedding.  nk == 0 is the reference's own NaN (average_pool of nothing).
     if (tid == 0 && nk > 0 && !(nrm < INFINITY)) atomicOr(err, 2);
     const float den = fmaxf(nrm, 1e-12f);   // F.normalize eps; NaN norm stays NaN (fmaxf would drop it)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = tid + j * 256;
+    for (int j = 0; j < VJ; ++j) {
+        const int i = tid + j * POOL_WAVES * 64;
         if (i < H) out[(int64_t)b * H + i] = (nrm == nrm) ? v[j] / den : NAN;
     }
 }
@@ -1722,20 +1796,27 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, b
     const int H = e->cfg.hidden, FF = e->cfg.intermediate;
     const float eps = e->cfg.ln_eps;
     e->kn.read();
-    hipLaunchKernelGGL(k_seq_len, dim3(B), dim3(64), 0, st, e->d_mask, B, S, e->seq_nk, e->seq_has0);
     const int nqt_max = (S + (pool == KR_POOL_CLS ? 1 : 0) + 31) / 32;             // q-tiles of the longest possible sequence
     const bool long_seq = (nqt_max > 4 && !e->kn.attn_lds) || e->kn.attn_dma;   // KIRAG_AMD_ATTN_DMA=1: the ring kernel for short sequences too (A/B)
             // > 128 tokens: the LDS-DMA attention kernel (KIRAG_AMD_ATTN_LDS=1: A/B against the register-staged one)
     const int align = long_seq ? 8 : 4;                                            // sequence offsets: multiple of 8 tokens so that V^T chunks start 16-B aligned
-    hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(64), 0, st, e->seq_nk, e->seq_has0, B, pool, align, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->d_err);
-    hipLaunchKernelGGL(k_fill_tokens, dim3(B), dim3(64), 0, st, e->d_ids, e->d_mask, has_tt ? e->d_tt : nullptr, S, e->cfg.vocab, e->cfg.type_vocab, align, e->seq_off,
-                       e->seq_nk, e->seq_nq, e->tok_id, e->tok_pos, e->tok_type, e->d_err);
+    if (B <= PACK_SMALL_B) {
+        hipLaunchKernelGGL(k_pack_small, dim3(1), dim3(1024), 0, st, e->d_ids, e->d_mask, has_tt ? e->d_tt : nullptr, B, S, e->cfg.vocab, e->cfg.type_vocab, pool, align,
+                           e->seq_nk, e->seq_has0, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->tok_id, e->tok_pos, e->tok_type, e->d_err);
+    } else {
+        hipLaunchKernelGGL(k_seq_len, dim3(B), dim3(64), 0, st, e->d_mask, B, S, e->seq_nk, e->seq_has0);
+        hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(64), 0, st, e->seq_nk, e->seq_has0, B, pool, align, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->d_err);
+        hipLaunchKernelGGL(k_fill_tokens, dim3(B), dim3(64), 0, st, e->d_ids, e->d_mask, has_tt ? e->d_tt : nullptr, S, e->cfg.vocab, e->cfg.type_vocab, align, e->seq_off,
+                           e->seq_nk, e->seq_nq, e->tok_id, e->tok_pos, e->tok_type, e->d_err);
+    }
     const int64_t maxT = (int64_t)B * (((S + (pool == KR_POOL_CLS ? 1 : 0)) + align - 1) & ~(align - 1));   // upper bound of the packed token count (each sequence is padded to `align`)
     const unsigned row_grid = (unsigned)((maxT + 3) / 4);
     // LayerNorm streams: y (dead after the kernel) and the low half (next read by the next LayerNorm, ~600 MiB of traffic later) are loaded / stored
     // non-temporally — they do not displace the 16-bit stream the next GEMM reads: -1.3 % forward at 1024 x 128 tokens, -0.1...0.5 % at 1000 x 32; 8 blocks
     // per CU instead of 4: -0.25 % (profiles/r04/tried_ln_policies.txt; outputs bit-identical)
     auto ln_kernel = H <= 512 ? &k_ln16<1, 7> : H <= 1024 ? &k_ln16<2, 7> : &k_ln16<4, 7>;
+    auto pool_kernel = H <= 256 ? &k_pool<1> : H <= 512 ? &k_pool<2> : H <= 1024 ? &k_pool<4> : &k_pool<8>;
+    const int pool_lds = POOL_WAVES * (H <= 256 ? 1 : H <= 512 ? 2 : H <= 1024 ? 4 : 8) * 256 * 4 + POOL_WAVES * 4;
     unsigned ln_mult = 8u;
     const unsigned ln_grid = std::min(row_grid, (unsigned)e->num_cu_all * ln_mult);   // k_ln is grid-stride (its parameters stay in registers across rows)
     hipLaunchKernelGGL(k_embed_ln, dim3(row_grid), dim3(256), 0, st, e->tok_id, e->tok_pos, e->tok_type, e->d_T, e->word, e->pos, e->type, e->elng, e->elnb, eps, H,
@@ -1774,7 +1855,8 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, b
             a.W = l.w2; a.X = e->c_h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->c_y; a.ldx = FF + e->h_pad; a.ldo = 0;
             KR_TRY(launch_proj(EPI_DENSE, a, B, e, st));
             hipLaunchKernelGGL(ln_kernel, dim3(c_ln_grid), dim3(256), 0, st, e->c_y, l.b2, e->d_B, l.ln2g, l.ln2b, eps, H, c_lo, e->c_xlo, e->c_xb);
-            hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->c_xb, e->c_xlo, e->c_off, e->c_nk, e->c_cls, H, pool, e->out, e->d_err);
+            KR_TRY(set_lds_once(reinterpret_cast<const void*>(pool_kernel), pool_lds, e->device));
+            hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(POOL_WAVES * 64), pool_lds, st, e->c_xb, e->c_xlo, e->c_off, e->c_nk, e->c_cls, H, pool, e->out, e->d_err);
             KR_HIP(hipGetLastError());
             return 0;
         }
@@ -1791,7 +1873,8 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, b
         // the LAST LayerNorm always writes the low half: pooling and kr_encoder_last_hidden read the final hidden state with 16 mantissa bits
         hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.b2, e->d_T, l.ln2g, l.ln2b, eps, H, lo_rw, last ? e->xlo : lo_rw, e->xb);
     }
-    hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out, e->d_err);
+    KR_TRY(set_lds_once(reinterpret_cast<const void*>(pool_kernel), pool_lds, e->device));
+    hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(POOL_WAVES * 64), pool_lds, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out, e->d_err);
     KR_HIP(hipGetLastError());
     return 0;
 }

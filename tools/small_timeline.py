@@ -2,7 +2,7 @@
 """Small-batch forward latency, wall vs kernels (python tools/small_timeline.py [trace_dir]).
 Without an argument: back-to-back and one-at-a-time wall time per forward of the reference's real batch shapes (KiRAG hop 1-2 x 256, e5.py helpers 4 x 64,
 compute_corpus_embeddings 8 x 128, one query 1 x 32, a triple batch 125 x 32).  With a rocprofv3 --kernel-trace output directory: per shape (forwards are
-delimited by k_seq_len .. k_pool) the kernel-time sum, the first-start-to-last-end span and the idle time between kernels of the LAST forward of each group."""
+delimited by k_seq_len / k_pack_small .. k_pool) the kernel-time sum, the first-start-to-last-end span and the idle time between kernels of the LAST forward of each group."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = ((1, 32), (1, 256), (2, 256), (4, 64), (8, 128), (125, 32))
@@ -10,10 +10,9 @@ if len(sys.argv) > 1:
     import csv, glob
     rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0])))
     seq = sorted(((r['Kernel_Name'], int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows), key=lambda x: x[1])
-    starts = [i for i, s in enumerate(seq) if 'k_seq_len' in s[0] or 'k_small_forward' in s[0]]
+    starts = [i for i, s in enumerate(seq) if 'k_seq_len' in s[0] or 'k_pack_small' in s[0]]
     fw = []
     for a in starts:
-        if 'k_small_forward' in seq[a][0]: fw.append((a, a)); continue
         ends = [i for i, s in enumerate(seq) if 'k_pool' in s[0] and i > a]
         if ends: fw.append((a, ends[0]))
     groups = {}
