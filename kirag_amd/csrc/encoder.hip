@@ -332,12 +332,17 @@ __device__ __forceinline__ unsigned int lo_encode(float o, float hf) {
     const int t = min(max(d + ((1 << (LO_SH - 1)) + (128 << LO_SH)), 0), (256 << LO_SH) - 1);
     return (unsigned int)t >> LO_SH;
 }
-// A non-finite hi (a LayerNorm output beyond the f16 range, or NaN) decodes to ITSELF: on the bit patterns inf - 4096 would be a finite 3.4e38, and the
-// residual path must hand an overflow on to the next LayerNorm / the pooling, where KR_ERANGE is raised (tests/test_lo_codec_spec.py).
 __device__ __forceinline__ float lo_decode(unsigned int byte, float hf) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, hf) + (byte << LO_SH) - (128u << LO_SH));
+}
+// lo_decode for readers of the FINAL hidden state (pooling, kr_encoder_last_hidden): a non-finite hi (a LayerNorm output beyond the f16 range, or NaN) decodes
+// to ITSELF — on the bit patterns inf - 4096 would be a finite 3.4e38.  Inside the stack the overflow travels with the 16-bit stream itself (the next GEMM reads
+// hi = inf and every LayerNorm behind it sees NaN through y), so the LayerNorm's residual decode keeps the 3-instruction form (its two extra VALU instructions per
+// element cost 0.3 % of the 1000-query step); behind the LAST LayerNorm there is no GEMM, only this decode (tests/test_lo_codec_spec.py,
+// tests/test_gpu_lifecycle.py: an overflow in the last LayerNorm must raise KR_ERANGE).
+__device__ __forceinline__ float lo_decode_final(unsigned int byte, float hf) {
     const unsigned int hb = __builtin_bit_cast(unsigned int, hf);
-    const float x = __builtin_bit_cast(float, hb + (byte << LO_SH) - (128u << LO_SH));
-    return (hb & 0x7f800000u) == 0x7f800000u ? hf : x;
+    return (hb & 0x7f800000u) == 0x7f800000u ? hf : lo_decode(byte, hf);
 }
 
 // LayerNorm of one row held as up to 8 float4 per lane (H <= 2048); writes fp32 and bf16 copies
@@ -1363,8 +1368,8 @@ __global__ __launch_bounds__(POOL_WAVES * 64) void k_pool(const uint16_t* __rest
             for (int j = 0; j < NJ; ++j) {
                 const int i = lane * 4 + j * 256;
                 if (i < H && t + POOL_WAVES * u < t_end) {
-                    acc[j].x += lo_decode(lo[u][j] & 0xffu, ET::to_f32(hi[u][j].x)); acc[j].y += lo_decode((lo[u][j] >> 8) & 0xffu, ET::to_f32(hi[u][j].y));
-                    acc[j].z += lo_decode((lo[u][j] >> 16) & 0xffu, ET::to_f32(hi[u][j].z)); acc[j].w += lo_decode(lo[u][j] >> 24, ET::to_f32(hi[u][j].w));
+                    acc[j].x += lo_decode_final(lo[u][j] & 0xffu, ET::to_f32(hi[u][j].x)); acc[j].y += lo_decode_final((lo[u][j] >> 8) & 0xffu, ET::to_f32(hi[u][j].y));
+                    acc[j].z += lo_decode_final((lo[u][j] >> 16) & 0xffu, ET::to_f32(hi[u][j].z)); acc[j].w += lo_decode_final(lo[u][j] >> 24, ET::to_f32(hi[u][j].w));
                 }
             }
     }
@@ -2036,10 +2041,10 @@ int enc_last_hidden(void* h, float* out, int B, int S) {
 #else
         auto f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float v; std::memcpy(&v, &u, 4); return v; };
 #endif
-        for (size_t i = 0; i < x.size(); ++i) {      // the host twin of lo_decode
+        for (size_t i = 0; i < x.size(); ++i) {      // the host twin of lo_decode_final
             const float hf = f(hi[i]);
             uint32_t bits; std::memcpy(&bits, &hf, 4);
-            bits += ((uint32_t)lo[i] << LO_SH) - (128u << LO_SH);
+            if ((bits & 0x7f800000u) != 0x7f800000u) bits += ((uint32_t)lo[i] << LO_SH) - (128u << LO_SH);
             std::memcpy(&x[i], &bits, 4);
         }
     }

@@ -20,8 +20,10 @@ def encode(x, hi, sh):
 
 
 def decode(byte, hi, sh):
+    """lo_decode_final: what the readers of the final hidden state use (a non-finite hi decodes to itself, round 5); for finite hi identical to the
+    3-instruction lo_decode of the LayerNorm's residual path"""
     x = ((hi.view(np.uint32).astype(np.int64) + (byte.astype(np.int64) << sh) - (128 << sh)) % 2**32).astype(np.uint32).view(np.float32)
-    return np.where((hi.view(np.uint32) & 0x7f800000) == 0x7f800000, hi, x)       # a non-finite hi decodes to itself (round 5)
+    return np.where((hi.view(np.uint32) & 0x7f800000) == 0x7f800000, hi, x)
 
 
 @pytest.mark.parametrize("kind,sh,mant", [("f16", 5, 10), ("bf16", 8, 7)])
@@ -50,7 +52,9 @@ def test_low_byte_is_a_256th_of_the_operand_ulp(kind, sh, mant):
 def test_non_finite_operands_survive_the_codec(kind, sh):
     """with a LayerNorm output beyond the operand range hi = +-inf, the encoder clamps the byte to 0 and the pure bit-pattern decode returned
     bits(inf) - 4096 = a FINITE 3.4e38: the residual path swallowed the overflow (it was still caught through the 16-bit stream and the pooled norm).
-    Now a non-finite hi decodes to itself whatever the byte, so the next LayerNorm / the pooling see inf or NaN and KR_ERANGE is raised from either path."""
+    Now the readers of the FINAL hidden state (pooling, kr_encoder_last_hidden: lo_decode_final) hand a non-finite hi through whatever the byte — behind
+    the last LayerNorm there is no GEMM that would carry the overflow — while the LayerNorm's own residual decode keeps the plain form: inside the stack the
+    16-bit stream itself feeds the next GEMM and every LayerNorm behind it sees NaN through y (tests/test_gpu_lifecycle.py covers both places)."""
     x = np.float32([np.inf, -np.inf, np.nan, 1.0e38 if kind == "bf16" else 7.0e4, -7.0e4])
     with np.errstate(over="ignore", invalid="ignore"):
         hi = to_hi(x, kind)
