@@ -172,6 +172,26 @@ def latency_block(args, encoder, index, dev):
         if i >= 3:
             hops.append((time.perf_counter() - t0) * 1e3)
     out["kirag_hop_nq1"] = {"ms": float(np.median(hops)), "what": f"encode 1 x 256 tokens + exact top-{k} over {index.ntotal} resident rows, results in pinned host memory"}
+    # the same 1 x 32 forward through the reference's own surface: E5Encoder.forward (retriever/encoders.py:67-77) of an nn.Module with the e5-large shape —
+    # what BaseRetriever.query / the e5.py helpers call; one forward at a time (forward + wait), which is how a hop uses it
+    from transformers import BertConfig
+    from kirag_amd.retriever.encoders import E5Encoder
+    c = encoder.cfg if hasattr(encoder, "cfg") else None
+    mod = E5Encoder(BertConfig(vocab_size=c.vocab_size, hidden_size=c.hidden_size, num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                               intermediate_size=c.intermediate_size, max_position_embeddings=c.max_position_embeddings), add_pooling_layer=False).to(dev).eval()
+    ids, mask = BS.synthetic_tokens(dev, 1, 32, seed=1)
+    for _ in range(3):
+        mod(ids, mask)
+    torch.cuda.synchronize()
+    one = []
+    for _ in range(40):
+        t0 = time.perf_counter(); mod(ids, mask); torch.cuda.synchronize(); one.append((time.perf_counter() - t0) * 1e3)
+    raw = []
+    for _ in range(40):
+        t0 = time.perf_counter(); encoder.forward(ids, mask, 0); torch.cuda.synchronize(); raw.append((time.perf_counter() - t0) * 1e3)
+    out["one_at_a_time_1x32"] = {"module_surface_ms": float(np.median(one)), "c_abi_ms": float(np.median(raw)),
+                                 "what": "E5Encoder.forward (nn.Module surface, weight-sync check included) vs HipBertForward.forward, each followed by a device synchronisation"}
+    del mod
     return out
 
 

@@ -126,7 +126,7 @@ class ShardedSearcher:
         mine, loc = self._slots[j]
         ids = mine[:nq * k * 8].view(torch.int64).view(nq, k)
         sc = mine[nq * k * 8:nq * k * 12].view(torch.float32).view(nq, k)
-        if self.exchange_first and self.world > 1:
+        if self.exchange_first and self.world > 1 and nq <= 1024:     # the split search takes one block of at most 1024 queries
             # coarse scan -> all-gather of the shards' k best coarse scores (+ error bound) per query -> the global bound -> re-rank above it: enqueue only
             tk, tk_all, theta = self._topk_bufs(nq, k, dev)
             self.index.search_coarse_async(q, k, tk)

@@ -73,10 +73,25 @@ class HipBertForward:
         mutates ``.data`` while the model stays in eval mode must call ``model.invalidate_hip_weights()``; ``train()`` / ``eval()`` transitions and
         ``load_state_dict`` do it automatically."""
         self.fingerprint = None
+        self._plist = None
+
+    FULL_CHECK_EVERY = 64
 
     def sync(self, module: torch.nn.Module) -> None:
+        """Keep the library's weight copy equal to the module's parameters.  Walking ``named_parameters()`` of a 24-layer BertModel costs ~0.7 ms of host time
+        (391 parameters through the module tree) — as long as the whole 32-token forward it precedes (round 5) — so the walk is cached: every forward compares
+        the tensor VERSIONS of the cached parameter list (~30 us: catches in-place updates, optimizer steps, ``load_state_dict``), and the full
+        (data_ptr, version) fingerprint over a fresh walk runs on the first forward, after ``invalidate()`` (``.to()`` / ``.cuda()`` / ``.half()`` through
+        ``_apply``, ``train()`` / ``eval()`` transitions, ``load_state_dict``) and every ``FULL_CHECK_EVERY`` forwards (a parameter OBJECT replaced by
+        assignment in eval mode is noticed by then at the latest; call ``invalidate_hip_weights()`` to make it immediate)."""
+        cached = getattr(self, "_plist", None)
+        self._since_full = getattr(self, "_since_full", 0) + 1
+        if cached is not None and self.fingerprint is not None and self._since_full < self.FULL_CHECK_EVERY:
+            if tuple(p._version for _, p in cached) == self._versions:
+                return
         params = [(n, p) for n, p in module.named_parameters() if not n.startswith("pooler.")]
         fp = tuple((p.data_ptr(), p._version) for _, p in params)
+        self._plist, self._versions, self._since_full = params, tuple(v for _, v in fp), 0
         if fp == self.fingerprint:
             return
         for name, p in params:
@@ -180,6 +195,13 @@ class _HipSentenceEncoder(BertModel):
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self.invalidate_hip_weights()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .half() / .float(): the parameters move or change type — the cached parameter walk of HipBertForward.sync is stale
+        out = super()._apply(fn, *args, **kwargs)
+        if getattr(self, "_hip", None) is not None:
+            self._hip.invalidate()
         return out
 
     def _torch_pooled(self, input_ids, attention_mask, token_type_ids):

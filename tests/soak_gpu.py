@@ -4,8 +4,10 @@
     clustered / near-duplicate data that sends queries to pass 2) must equal the exact scan (mode 1) AND the fp64-MFMA pass alone (mode 2) in rows and
     score bits; every fourth case with every canonical score forced through the integer super-accumulator; every sixth case with non-unit row norms;
     a sample of scores against torch's fp32 matmul (independent arithmetic);
-  * encoder (tiny config): the four projection main loops (KIRAG_AMD_PROJ_TILE = 256 / 130 / 128 / 32) must agree bit for bit, and a sequence's
-    embedding must not depend on the rest of the batch.
+  * index, every fourth case (round 5): the corpus cut into 2-3 uneven row shards searched in SPLIT form (coarse scan -> gathered coarse scores -> global bound
+    -> re-rank above it), the merged lists must equal the unsharded search bit for bit;
+  * encoder (tiny config): the projection main loops / skinny tile shapes (KIRAG_AMD_PROJ_TILE = 256 / 130 / 128 / 64 / 32) must agree bit for bit, and a
+    sequence's embedding must not depend on the rest of the batch.
 Exits non-zero on the first mismatch; prints one line per 25 cases."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -83,6 +85,32 @@ while time.time() < t_end - budget * 0.35:
         if not oka:
             why.append(("outstanding async searches != blocking search", m, fl))
         ok = ok and oka
+    if cases % 4 == 1 and n >= 2 * k + 2 and nq <= 1024:   # round 5: the row-sharded SPLIT search (exchange of coarse scores before the re-rank), 2-3 uneven shards of this corpus
+        W = int(rng.integers(2, 4))
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(k, n - k + 1, W - 1)]))
+        if all(b - a >= k for a, b in zip(cuts[:-1], cuts[1:])):
+            shards = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                sh = FlatIPIndex(d, device=0); sh.add(x[a:b]); shards.append((sh, a))
+            tks = [torch.empty((nq, k + 1), dtype=torch.float32, device="cuda") for _ in shards]
+            for (sh, a), tk in zip(shards, tks):
+                sh.search_coarse_async(q, k, tk)
+            gathered = torch.cat(tks, dim=0).contiguous()
+            sc_all, id_all = [], []
+            for (sh, a) in shards:
+                th = torch.empty((nq,), dtype=torch.float32, device="cuda")
+                sc = torch.empty((nq, k), dtype=torch.float32, device="cuda"); rw = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+                sh.search_global_theta(gathered, len(shards), th); sh.search_rerank_async(th, sc, rw); sh.finish()
+                r_ = rw.cpu().numpy(); sc_all.append(sc.cpu().numpy()); id_all.append(np.where(r_ >= 0, r_ + a, -1))
+            ms = np.empty((nq, k), np.float32); mi = np.empty((nq, k), np.int64)
+            sc_st, id_st = np.ascontiguousarray(np.stack(sc_all)), np.ascontiguousarray(np.stack(id_all))      # named: they must outlive the call
+            _lib.check(_lib.load().kr_topk_merge(sc_st.ctypes.data, id_st.ctypes.data, len(shards), nq, k, ms.ctypes.data, mi.ctypes.data))
+            oks = np.array_equal(mi, i0) and np.array_equal(ms.view(np.uint32), s0.view(np.uint32))
+            if not oks:
+                bad = np.nonzero((mi != i0).any(1))[0]
+                why.append(("split sharded search != unsharded", cuts, bad[:5].tolist()))
+            ok = ok and oks
+            del shards
     ref = (q[:4] @ x.T).cpu().numpy()                   # independent arithmetic: fp32 matmul scores of the returned rows
     got = np.take_along_axis(ref, i0[:4], axis=1)
     scale = float(np.abs(ref).max()) + 1e-30
@@ -115,7 +143,7 @@ while time.time() < t_end:
         else: mask[b, :lens[b]] = 1
     pool = int(rng.integers(0, 2))
     outs = []
-    for tile in ("256", "130", "128", "32"):
+    for tile in ("256", "130", "128", "64", "32"):
         os.environ["KIRAG_AMD_PROJ_TILE"] = tile
         outs.append(enc.forward_np(ids, mask, pool))
     os.environ.pop("KIRAG_AMD_PROJ_TILE")

@@ -193,7 +193,8 @@ def test_split_search_exchange_before_rerank_two_shards_in_one_process():
         valid = o[1] >= 0
         assert (valid[:, :-1] >= valid[:, 1:]).all()
     ms = np.empty((nq, k), np.float32); mi = np.empty((nq, k), np.int64)
-    _lib.check(_lib.load().kr_topk_merge(np.ascontiguousarray(sc_all).ctypes.data, np.ascontiguousarray(id_all).ctypes.data, len(shards), nq, k, ms.ctypes.data, mi.ctypes.data))
+    sc_all, id_all = np.ascontiguousarray(sc_all), np.ascontiguousarray(id_all)                  # named: the buffers must outlive the call
+    _lib.check(_lib.load().kr_topk_merge(sc_all.ctypes.data, id_all.ctypes.data, len(shards), nq, k, ms.ctypes.data, mi.ctypes.data))
     assert np.array_equal(mi, io) and np.array_equal(ms.view(np.uint32), so.view(np.uint32))
     # theta = None: the shard's own answer, exactly kr_index_search_async's
     ix, a = shards[0]

@@ -338,3 +338,65 @@ def test_token_type_ids_go_through_the_hip_path(golden):
     m._hip.check()
     assert torch.equal(m(ids.cuda(), mask.cuda(), tt.cuda()), out_tt)
     m._hip.check()
+
+
+def test_module_surface_weight_sync_is_cached_and_still_sees_every_change():
+    """Round 5: ``HipBertForward.sync`` used to walk ``named_parameters()`` on EVERY eval forward — ~0.7 ms of host time for a 24-layer BertModel, as
+    long as the 32-token forward behind it.  The walk is cached now (per forward: the tensor versions of the cached list).  Every way the weights can
+    change must still reach the library: in-place updates (version bump), ``load_state_dict``, dtype / device moves through ``_apply``, a parameter object
+    replaced by assignment (``invalidate_hip_weights()`` at once, the periodic full check at the latest), train / eval transitions."""
+    import time
+    from transformers import BertConfig
+    from kirag_amd.retriever.encoders import E5Encoder
+    cfg = BertConfig(vocab_size=500, hidden_size=128, num_hidden_layers=24, num_attention_heads=2, intermediate_size=256, max_position_embeddings=64)
+    torch.manual_seed(7)
+    m = E5Encoder(cfg, add_pooling_layer=False).cuda().eval()
+    rng = np.random.default_rng(1)
+    ids = torch.from_numpy(rng.integers(5, 500, (3, 17))).cuda(); mask = torch.ones_like(ids); mask[1, 9:] = 0
+
+    def hip(): return m(ids, mask).clone()
+
+    def ref():
+        m.train()
+        try:
+            with torch.no_grad():
+                return m(ids, mask).clone()
+        finally:
+            m.eval()
+    out0 = hip()
+    assert (out0 - ref()).abs().max() < 4e-3
+    # the steady state: the cached check is cheap (the full walk of 24 layers is not)
+    t0 = time.perf_counter()
+    for _ in range(50): m._hip.sync(m)
+    cached_us = (time.perf_counter() - t0) / 50 * 1e6
+    t0 = time.perf_counter()
+    for _ in range(10): list(m.named_parameters())
+    walk_us = (time.perf_counter() - t0) / 10 * 1e6
+    print(f"sync with the cached walk {cached_us:.0f} us per forward; one named_parameters() walk {walk_us:.0f} us")
+    assert cached_us < 0.5 * walk_us
+    m._hip.invalidate(); assert torch.equal(hip(), out0)          # after an invalidate: the same weights, the same bits
+    # 1. in-place update (bumps the tensor version)
+    with torch.no_grad():
+        m.encoder.layer[5].output.dense.weight.mul_(1.7)
+    out1 = hip()
+    assert (out1 - out0).abs().max() > 1e-4 and (out1 - ref()).abs().max() < 4e-3
+    # 2. load_state_dict back to the old values -> the old bits
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        m.encoder.layer[5].output.dense.weight.div_(1.7)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd); assert torch.equal(hip(), out1)
+    m.load_state_dict(sd0); assert (hip() - out0).abs().max() < 1e-5
+    # 3. _apply: .half().float() rounds the weights -> different outputs, equal to the module's own forward
+    m.half().float()
+    out3 = hip()
+    assert (out3 - ref()).abs().max() < 4e-3 and not torch.equal(out3, out0)
+    # 4. a parameter object replaced by assignment: noticed at once after invalidate_hip_weights(), and by the periodic full check without it
+    m.embeddings.LayerNorm.weight = torch.nn.Parameter(m.embeddings.LayerNorm.weight.detach() * 1.3)
+    m.invalidate_hip_weights()
+    out4 = hip()
+    assert (out4 - ref()).abs().max() < 4e-3 and (out4 - out3).abs().max() > 1e-4
+    m._hip.FULL_CHECK_EVERY = 3
+    m.embeddings.LayerNorm.bias = torch.nn.Parameter(m.embeddings.LayerNorm.bias.detach() + 0.2)
+    outs = [hip() for _ in range(4)]
+    assert (outs[-1] - ref()).abs().max() < 4e-3 and (outs[-1] - out4).abs().max() > 1e-4
