@@ -348,7 +348,8 @@ def test_module_surface_weight_sync_is_cached_and_still_sees_every_change():
     import time
     from transformers import BertConfig
     from kirag_amd.retriever.encoders import E5Encoder
-    cfg = BertConfig(vocab_size=500, hidden_size=128, num_hidden_layers=24, num_attention_heads=2, intermediate_size=256, max_position_embeddings=64)
+    cfg = BertConfig(vocab_size=500, hidden_size=128, num_hidden_layers=24, num_attention_heads=2, intermediate_size=256, max_position_embeddings=64,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)       # the PyTorch reference below runs in train mode: no dropout
     torch.manual_seed(7)
     m = E5Encoder(cfg, add_pooling_layer=False).cuda().eval()
     rng = np.random.default_rng(1)
@@ -366,6 +367,7 @@ def test_module_surface_weight_sync_is_cached_and_still_sees_every_change():
     out0 = hip()
     assert (out0 - ref()).abs().max() < 4e-3
     # the steady state: the cached check is cheap (the full walk of 24 layers is not)
+    m._hip.sync(m)                                                  # ref() went through train() / eval(): this call re-reads the weights once
     t0 = time.perf_counter()
     for _ in range(50): m._hip.sync(m)
     cached_us = (time.perf_counter() - t0) / 50 * 1e6
@@ -392,11 +394,17 @@ def test_module_surface_weight_sync_is_cached_and_still_sees_every_change():
     out3 = hip()
     assert (out3 - ref()).abs().max() < 4e-3 and not torch.equal(out3, out0)
     # 4. a parameter object replaced by assignment: noticed at once after invalidate_hip_weights(), and by the periodic full check without it
-    m.embeddings.LayerNorm.weight = torch.nn.Parameter(m.embeddings.LayerNorm.weight.detach() * 1.3)
+    #    (replacements large enough that stale weights could not pass the comparison with the module's own forward)
+    w_old = m.encoder.layer[3].intermediate.dense.weight.detach()
+    m.encoder.layer[3].intermediate.dense.weight = torch.nn.Parameter(torch.flip(w_old, dims=[0]) * 3.0)
     m.invalidate_hip_weights()
     out4 = hip()
-    assert (out4 - ref()).abs().max() < 4e-3 and (out4 - out3).abs().max() > 1e-4
+    r4 = ref()
+    assert (r4 - out3).abs().max() > 2e-2, float((r4 - out3).abs().max())        # the replacement matters ...
+    assert (out4 - r4).abs().max() < 4e-3                                          # ... and the HIP path has it
     m._hip.FULL_CHECK_EVERY = 3
-    m.embeddings.LayerNorm.bias = torch.nn.Parameter(m.embeddings.LayerNorm.bias.detach() + 0.2)
-    outs = [hip() for _ in range(4)]
-    assert (outs[-1] - ref()).abs().max() < 4e-3 and (outs[-1] - out4).abs().max() > 1e-4
+    w_old = m.encoder.layer[9].output.dense.weight.detach()
+    m.encoder.layer[9].output.dense.weight = torch.nn.Parameter(torch.flip(w_old, dims=[1]) * 3.0)
+    outs = [hip() for _ in range(4)]                                # no invalidate: the periodic full walk finds the new object
+    r5 = ref()
+    assert (r5 - r4).abs().max() > 2e-2 and (outs[-1] - r5).abs().max() < 4e-3
