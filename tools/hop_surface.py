@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""One KiRAG retrieval hop at the REFERENCE'S OWN SURFACE (knowledge_graph/models.py:1645: ``self.retriever(queries, topk)`` = DenseRetriever.forward ->
+batch_retrieve, retrievers.py:250-291): strings in, lists of {"id", "score"} out — tokenizer, collator, E5Encoder module forward, D2H, Indexer.search_knn, result
+parsing — over a resident N-row index, next to the C-ABI pieces (HipBertForward.forward + FlatIPIndex.search) on the same tokens.  The difference is host work
+of the surface.  Usage: python tools/hop_surface.py [total_rows] [--profile]"""
+import os, sys, tempfile, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+import torch
+import torch.nn as nn
+from transformers import BertConfig
+from kirag_amd.bench_support import wordpiece_tokenizer
+from kirag_amd.collators import E5Collator
+from kirag_amd.retriever.encoders import E5Encoder
+from kirag_amd.retriever.index import Indexer
+from kirag_amd.retriever.retrievers import BaseRetriever, DenseRetriever
+
+total = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5_000_000
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(0)
+letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
+def rand_words(k, lo, hi):
+    out = set()
+    while len(out) < k:
+        out.add("".join(rng.choice(letters, int(rng.integers(lo, hi)))))
+    return sorted(out)
+words = rand_words(20000, 3, 9); pieces = ["##" + w for w in rand_words(10517, 2, 5)]
+td = tempfile.mkdtemp()
+with open(os.path.join(td, "vocab.txt"), "w") as f:
+    f.write("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words + pieces) + "\n")
+tok = wordpiece_tokenizer(os.path.join(td, "vocab.txt"))
+cfg = BertConfig(vocab_size=30522, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, max_position_embeddings=512)
+enc = E5Encoder(cfg, add_pooling_layer=False).to(dev).eval()
+
+class Ret(BaseRetriever):
+    def __init__(self, encoder):
+        nn.Module.__init__(self)
+        self.encoder = encoder
+        self.norm_query = self.norm_doc = False
+        self.temperature, self.local_rank, self.world_size = 1.0, -1, 1
+
+ix = Indexer(1024)
+g = torch.Generator(device=dev); g.manual_seed(3)
+ix.index.reserve(total)
+for s0 in range(0, total, 250_000):
+    m = min(250_000, total - s0)
+    ix.index.add(torch.nn.functional.normalize(torch.randn(m, 1024, generator=g, device=dev), dim=1))
+ix.index_id_to_db_id = np.arange(total, dtype=np.int64) * 3 + 1_000_000
+col = E5Collator(tokenizer=tok, query_maxlength=256, doc_maxlength=128)
+dr = DenseRetriever(retriever=Ret(enc), collator=col, indexer=ix, corpus=None, batch_size=4)
+wa = np.array(words)
+question = "which " + " ".join(rng.choice(wa, 12)) + " ?"
+chain = ". ".join("<" + " ".join(rng.choice(wa, 9)) + ">" for _ in range(16))
+query = "{}\nknowledge triples: {}.".format(question, chain)
+ntok = int(col.encode_query([query], max_length=256)["attention_mask"].sum())
+
+def hop_surface(): return dr([query], 10)
+a = col.encode_query([query], max_length=256)
+ids, mask = a["input_ids"].to(dev), a["attention_mask"].to(dev)
+def hop_abi():
+    qv = enc._hip.forward(ids, mask, 0)
+    return ix.index.search(qv, 10)
+
+def timed(fn, reps=30):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+hop_surface()
+t_surface, t_abi = timed(hop_surface), timed(hop_abi)
+t_tok = timed(lambda: col.encode_query([query], max_length=256))
+t_emb = timed(lambda: dr.calculate_query_embeddings(queries=[query], max_length=256))
+qe = dr.calculate_query_embeddings(queries=[query], max_length=256).numpy()
+t_knn = timed(lambda: ix.search_knn(qe, 10, verbose=False))
+print(f"one hop, nq = 1, query of {ntok} tokens, top-10 over {total} rows:")
+print(f"  reference surface  DenseRetriever([query], 10)                       {t_surface:.2f} ms")
+print(f"  C ABI              HipBertForward.forward + FlatIPIndex.search         {t_abi:.2f} ms")
+print(f"  pieces of the surface: tokenizer + collator {t_tok:.2f} ms | calculate_query_embeddings (tokenize, H2D, module forward, D2H) {t_emb:.2f} ms | Indexer.search_knn {t_knn:.2f} ms")
+if "--profile" in sys.argv:
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(50): hop_surface()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
