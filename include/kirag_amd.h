@@ -33,12 +33,16 @@ extern "C" {
 #define KR_ESTATE (-1)    /* handle not ready (e.g. encoder weights missing) */
 #define KR_ERANGE (-34)   /* the encoder met non-finite activations (a value outside the f16 operand range, or NaN / Inf weights): results unusable */
 
-#define KR_ABI_VERSION 7
+#define KR_ABI_VERSION 8
 int kr_abi_version(void);
 const char* kr_last_error(void);
 int kr_device_count(void);
 /* process-wide test / diagnostic switches.  "force_exact_scores" (0/1): every canonical score goes through the integer
  * super-accumulator instead of the certified fp64 fast path (same results by definition; exercises the rare path).
+ * "byte_prescan" (0/1, default 1): blocks of at most 8 queries on an index of >= 2^19 rows (384 < d <= 1024) stream an int8 copy of the rows
+ * (1 KiB per row at d = 1024, built by the first such search) in the final round of the coarse scan and 16-bit-score only the rows it marks;
+ * results are the same exact top-k either way.  KIRAG_AMD_NO_BYTE_SCAN in the environment at kr_index_create: never for that index.
+ * "debug_byte_min_rows" (rows; < 0 = default 2^19): test hook, the index size from which small blocks take that path.
  * "debug_va_retired_tib" (TiB) / "debug_vmm_min_reserve_mib" (MiB; 0 = default): test hooks of the large-index address-space
  * budget and of the smallest address range reserved per large index.  Unknown names: KR_EINVAL. */
 int kr_set_option(const char* name, int value);
@@ -139,6 +143,8 @@ typedef struct {
     int64_t marked_rows;      /* rows marked by those pre-scans, summed over the groups */
     int64_t va_retired_bytes; /* process-wide: virtual addresses retired by released / moved indexes (never reused) */
     int64_t grow_mode;        /* this index: -1 undecided (< 256 MiB), 0 hipMalloc + copy-on-grow, 1 chunks mapped into a reserved address range */
+    int64_t byte_scans;       /* query blocks whose final coarse round went through the int8 copy (kr_set_option "byte_prescan") */
+    int64_t byte_marked_rows; /* rows those pre-scans marked (then scored from the 16-bit copy), summed */
 } kr_search_stats;
 int kr_index_stats(kr_index* ix, kr_search_stats* out, int reset);
 

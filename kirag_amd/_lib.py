@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KIRAG_AMD_LIB") or os.path.join(_HERE, "libkirag_amd.so")   # KIRAG_AMD_LIB: diagnostic builds (tools/stamp_build.sh)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class KiragAmdError(RuntimeError):
@@ -26,7 +26,7 @@ class SearchStats(C.Structure):
                 ("reranked_rows", C.c_int64), ("coarse_rounds", C.c_int64), ("last_coarse_ms", C.c_double),
                 ("last_total_ms", C.c_double), ("fine", C.c_int64), ("exact", C.c_int64), ("fine_rounds", C.c_int64),
                 ("last_fine_ms", C.c_double), ("marked_passes", C.c_int64), ("marked_rows", C.c_int64),
-                ("va_retired_bytes", C.c_int64), ("grow_mode", C.c_int64)]
+                ("va_retired_bytes", C.c_int64), ("grow_mode", C.c_int64), ("byte_scans", C.c_int64), ("byte_marked_rows", C.c_int64)]
 
 
 class BertCfg(C.Structure):

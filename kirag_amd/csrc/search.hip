@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
+#include <functional>
 #include <vector>
 
 namespace kr {
@@ -122,6 +123,17 @@ struct Index {
     float* thr_mark = nullptr; // [32] the same, compacted for the group being pre-scanned
     uint32_t* bitmap = nullptr; size_t bitmap_words = 0;   // one bit per row (+ one word: the list length) — pass 2 pre-scan
     uint32_t* rowlist = nullptr;                           // the marked rows, compacted
+    // byte pre-scan of small query blocks (see byte_final_round): an int8 copy of the rows with one scale per row.  A DERIVED structure: built lazily from
+    // xf by the first small-block search (ensure_byte_copy), extended behind later adds, never part of the growth machinery above
+    int8_t* x8 = nullptr;      // [cap8, dpad8]
+    float* sx8 = nullptr;      // [cap8] row scale: x ~ sx8[row] * x8[row]   (NaN for the padding rows behind n8)
+    float* bounds8 = nullptr;  // [4] device: max ||r - sx8 x8||_2 over the rows (r = (x - mu) w) ; word 1: != 0 once a row with a non-finite element has been seen ; max ||r||_2
+    int8_t* q8 = nullptr;      // [2][32][dpad8] the block's queries as two byte planes: q ~ sq (q8[0] + q8[1] / 254)
+    float* thr8 = nullptr;     // [32] per-query mark threshold in units of the integer score (k_scan8_prep)
+    float* mu8 = nullptr;      // [3][dpad8] centre mu, axis weights w, 1 / w (k_mu_final; fixed for the life of the copy), then the partial sums
+    int64_t n8 = 0, cap8 = 0; int dpad8 = 0;
+    bool byte_off = false;     // environment switch / allocation failure / non-finite rows: the 16-bit scan serves every block
+    int byte_bad = 0, byte_pause = 0;   // feedback from finished calls: pre-scans that marked too many rows in a row; calls left without a pre-scan
     int force_exact = 0;       // test hook: every canonical score through the integer super-accumulator
     uint16_t* q_c = nullptr;   // [QBLK, dpad]
     float* thr = nullptr;      // [QBLK]
@@ -158,6 +170,7 @@ struct Index {
         uint64_t seq = 0;               // the call's number (the workspace-resident theta1 / timing events belong to the newest call only)
         bool half = false;              // kr_index_search_coarse_async was enqueued, kr_index_search_rerank_async not yet
         int final_preset = 0, rmax = 0; // ... what the second half needs from the first
+        bool byte_used = false;
     };
     static constexpr int PEND_MAX = 16;
     Pending pend[PEND_MAX];
@@ -255,6 +268,7 @@ struct CoarseArgs {
     const float* xf; const float* qf; int d;   // high-precision pass (k_fine): fp32 master rows, compacted fp32 queries
     uint32_t* bitmap;                          // one bit per ROW, set by the marking scan (k_coarse_q32 MODE 2)
     const uint32_t* rowlist; int64_t nlist;    // k_fine: scan rows rowlist[0 .. nlist) instead of 0 .. n (nullptr: every row)
+    const uint16_t* qc2; const float* sx8;     // byte pre-scan (k_coarse_q32 MODE 3): second byte plane of the queries, row scales
 };
 
 // persistent streaming coarse scan (gemm_nt_pingpong): grid = one block per CU, so nothing else on the CU hides an epilogue
@@ -268,6 +282,8 @@ constexpr int WLISTCAP = 8192;                      // entries per wave list (ex
 constexpr int COARSE_LDS = COARSE_STAGES * ShapeC::STAGE_BYTES + QBLK * 4;
 constexpr int COARSE_LDS_SMALLQ = SPLIT_RING * ShapeSplit::STAGE_BYTES + QBLK * 4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
 
 // fused scatter: this block's 8 wave lists -> the per-query candidate buffers.  One global atomic per (block, query) reserves a range (instead of one
 // per survivor), the position inside the range comes from an LDS counter.  Called by every thread of the block after the main loop (the LDS ring is free).
@@ -412,6 +428,10 @@ template <int KT> constexpr int q32_lds() { return 4 * Q32Ring<KT>::value * 4096
 // s_waitcnt vmcnt(0) before every LDS read that follows an LDS-DMA, i.e. no K-tile would ever be in flight)
 // MODE 0: threshold filter -> wave lists;  1: direct store of every score (round 0);  2: MARK — set bit `tile` of a.bitmap when any of the slot's
 // 32 x 32 scores reaches its query's threshold (a.thr; the pre-scan of pass 2, see search_block)
+// MODE 3: the BYTE pre-scan (byte_final_round).  The same ring over the int8 copy: a.xc / a.qc point at bytes, a.dpad counts 2-byte units, so a K-tile is
+// 128 int8 per row and every address below is unchanged; the queries come as two byte planes (a.qc hi, a.qc2 lo: q ~ sq (hi + lo / 254)), two
+// v_mfma_i32_32x32x32_i8 chains give the exact integer dot products Ia, Ib, and the row is marked when sx8[row] (254 Ia + Ib) >= a.thr[query].
+// (Integer sums are order-free, so all that matters of the MFMA's k layout is that A and B use the same one: both read 16-byte chunk 2 ks + (lane >> 5).)
 template <class T, int MODE, int KT>
 __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint16_t* __restrict__ xc, const uint16_t* __restrict__ qc, char* smem) {
     constexpr int RING = Q32Ring<KT>::value;
@@ -428,6 +448,12 @@ __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint1
         const uint16_t* qrow = qc + (int64_t)(lane & 31) * a.dpad + 8 * (lane >> 5);
 #pragma unroll
         for (int ks = 0; ks < KT * 4; ++ks) bq[ks] = *reinterpret_cast<const uint4*>(qrow + ks * 16);
+    }
+    uint4 bq2[MODE == 3 ? KT * 4 : 1];
+    if constexpr (MODE == 3) {
+        const uint16_t* qrow = a.qc2 + (int64_t)(lane & 31) * a.dpad + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KT * 4; ++ks) bq2[ks] = *reinterpret_cast<const uint4*>(qrow + ks * 16);
     }
     constexpr bool DIRECT = MODE == 1;
     const float thr = DIRECT ? 0.f : a.thr[lane & 31];
@@ -466,8 +492,14 @@ __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint1
         for (int64_t i = 0; i < my; ++i) {
             const int64_t m0 = tile_row0(i);
             f32x16 acc;
+            i32x16 ia, ib;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; ia[r] = 0; ib[r] = 0; }
+            float4 sc4[4];                                    // MODE 3: scales of this lane's 16 rows (4 fh + 8 j .. + 3), requested ahead of the K loop
+            if constexpr (MODE == 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc4[j] = *reinterpret_cast<const float4*>(a.sx8 + m0 + 8 * j + 4 * (lane >> 5));
+            }
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 // the slot of the PREVIOUS K-tile is free (its fragments were consumed by MFMAs that are already issued): refill it first, then wait
@@ -478,8 +510,16 @@ __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint1
                 uint4 af[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) af[ks] = *reinterpret_cast<const uint4*>(st + (((2 * ks + fh) ^ fswz) << 4));
+                if constexpr (MODE == 3) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc = T::mfma(af[ks], bq[kt * 4 + ks], acc);
+                    for (int ks = 0; ks < 4; ++ks) {
+                        ia = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, af[ks]), __builtin_bit_cast(i32x4, bq[kt * 4 + ks]), ia, 0, 0, 0);
+                        ib = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, af[ks]), __builtin_bit_cast(i32x4, bq2[kt * 4 + ks]), ib, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) acc = T::mfma(af[ks], bq[kt * 4 + ks], acc);
+                }
                 asm volatile("" ::: "memory");                // keep the next refill behind these LDS reads in program order
             }
             const uint32_t row_base = (uint32_t)m0 + (uint32_t)lane_row0;
@@ -499,6 +539,19 @@ __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint1
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned long long mask = __ballot(acc[r] >= thr);
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if ((unsigned)mask) bits |= 1u << ro;
+                    if ((unsigned)(mask >> 32)) bits |= 1u << (ro + 4);
+                }
+                if (bits && lane == 0) atomicOr(a.bitmap + (m0 >> 5), bits);
+            } else if constexpr (MODE == 3) {
+                // |Ia| <= 127 * 127 * 1024 < 2^24: exact in fp32; the fma rounds once (covered by the slack in k_scan8_prep).  Padding rows carry a NaN scale.
+                unsigned int bits = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sr = (r & 3) == 0 ? sc4[r >> 2].x : (r & 3) == 1 ? sc4[r >> 2].y : (r & 3) == 2 ? sc4[r >> 2].z : sc4[r >> 2].w;
+                    const float sc = sr * fmaf(254.f, (float)ia[r], (float)ib[r]);
+                    const unsigned long long mask = __ballot(sc >= thr);
                     const int ro = (r & 3) + 8 * (r >> 2);
                     if ((unsigned)mask) bits |= 1u << ro;
                     if ((unsigned)(mask >> 32)) bits |= 1u << (ro + 4);
@@ -965,6 +1018,262 @@ __global__ __launch_bounds__(256) void k_global_theta(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// byte pre-scan of small query blocks (<= BYTE_NQ_MAX queries: the KiRAG loop's 1-2 queries per hop, one question at a time)
+// ---------------------------------------------------------------------------------------------------------
+// A block of up to 32 queries is an HBM-bound stream over the 16-bit copy (2 dpad bytes per row).  The final round of that scan — 94 % of the rows — only has
+// to find the rows that can still be in a query's top-k, and half the bytes suffice for that: an int8 copy with one scale per row ((x - mu) w ~ sx8 x8: k_mu_final) is streamed
+// instead, every row whose byte score reaches
+//     theta8[q] = (k-th best 16-bit score of the rows seen in the earlier rounds) - eps16[q] - eps8[q]
+// for some query is marked, and only the marked rows (a few hundred to a few thousand per query) get their 16-bit scores (k_score_list) and enter the
+// candidate buffers exactly as the final 16-bit round would have entered them.  Exactness: the k rows with the best 16-bit scores seen so far have exact
+// scores >= kth16 - eps16, so a row of the final top-k has exact >= kth16 - eps16 and byte score >= kth16 - eps16 - eps8; an unmarked row is strictly below
+// the k-th exact score of rows already seen and can never be returned.  k_rerank's certificate is untouched: rows missing from the buffer are either below
+// the round threshold (as before) or unmarked (ruled out here).
+//   q.x = q.mu + u.r with u = q / w, r = (x - mu) w;  |u.r - u^.r^| <= |u| |r - r^| + |u - u^| |r^|,  r^ = sx8 x8 (bounds8[0] = max |r - r^|),
+//   u^ = sq (qa + qb / 254)  (two planes: |u - u^| ~ 1e-5 |u|);  eps8 = that + the fp32 roundings involved (k_scan8_prep)
+// The int8 copy is derived data (built lazily, ensure_byte_copy); an index with a non-finite element anywhere never takes this path (bounds8 word 1).
+
+// centre and axis weights of the int8 copy, from rows [0, m): mu = their mean, w_i = the power of two nearest to sigma_rms / sigma_i (clamped to
+// [1/16, 16]); a row is stored as x8 ~ (x - mu) * w / sx8 and a query enters as q / w, so that q.(x - mu) = (q / w).((x - mu) w) exactly (powers of
+// two: no rounding).  ANY centre and ANY positive weights are valid — they only decide how tight the bound is: the mean removes what all embeddings of
+// one encoder share (e5 / bge rows have a common direction), the weights keep a few large-variance axes ("rogue dimensions") from setting every row's
+// scale.  Two deterministic stages: MU_PARTS partial sums, then one block.
+constexpr int MU_PARTS = 256;
+constexpr int64_t MU_ROWS = 65536;
+__global__ __launch_bounds__(256) void k_mu_partial(const float* __restrict__ xf, int64_t m, int d, int dpad8, float* __restrict__ part) {
+    const int64_t per = (m + MU_PARTS - 1) / MU_PARTS, r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < m ? r0 + per : m;
+    for (int i = threadIdx.x; i < dpad8; i += 256) {
+        float acc = 0.f, acc2 = 0.f;
+        if (i < d) for (int64_t r = r0; r < r1; ++r) { const float v = xf[r * d + i]; acc += v; acc2 += v * v; }
+        part[((int64_t)blockIdx.x * 2) * dpad8 + i] = acc;
+        part[((int64_t)blockIdx.x * 2 + 1) * dpad8 + i] = acc2;
+    }
+}
+// one block of 1024 threads (dpad8 <= 1024): mu8 = [mu | w | 1 / w]
+__global__ __launch_bounds__(1024) void k_mu_final(const float* __restrict__ part, int64_t m, int d, int dpad8, float* __restrict__ mu8) {
+    __shared__ float red[16];
+    const int i = threadIdx.x;
+    float mean = 0.f, var = 0.f;
+    if (i < d) {
+        float a = 0.f, a2 = 0.f;
+        for (int p = 0; p < MU_PARTS; ++p) { a += part[((int64_t)p * 2) * dpad8 + i]; a2 += part[((int64_t)p * 2 + 1) * dpad8 + i]; }
+        mean = a / (float)m;
+        var = fmaxf(a2 / (float)m - mean * mean, 0.f);
+        if (!(fabsf(mean) <= 3.4028235e38f) || !(var <= 3.4028235e38f)) { mean = 0.f; var = 0.f; }
+    }
+    float t = var;
+#pragma unroll
+    for (int mm = 32; mm >= 1; mm >>= 1) t += __shfl_xor(t, mm, 64);
+    if ((i & 63) == 0) red[i >> 6] = t;
+    __syncthreads();
+    float tot = 0.f;
+    for (int j = 0; j < 16; ++j) tot += red[j];
+    const float rms = sqrtf(tot / (float)d);
+    float w = 1.f;
+    if (i < d && var > 0.f && rms > 0.f) {
+        const float want = fminf(fmaxf(rms / sqrtf(var), 0.0625f), 16.f);
+        w = exp2f(rintf(log2f(want)));
+        if (!(w >= 0.0625f && w <= 16.f)) w = 1.f;
+    }
+    if (i < dpad8) { mu8[i] = mean; mu8[dpad8 + i] = w; mu8[2 * dpad8 + i] = 1.f / w; }
+}
+
+// rows [r0, r1) of the fp32 master -> int8 rows + scales, one wave per row: x - mu ~ sx8 x8; rows [r1, r_pad) become padding (scale NaN: never marked)
+__global__ __launch_bounds__(256) void k_quant8_rows(const float* __restrict__ xf, const float* __restrict__ mu8, int8_t* __restrict__ x8, float* __restrict__ sx8,
+                                                     int64_t r0, int64_t r1, int64_t r_pad, int d, int dpad8, float* __restrict__ bounds8) {
+    const int lane = threadIdx.x & 63;
+    const float* mu = mu8;
+    const float* wt = mu8 + dpad8;
+    float emax = 0.f, nmax = 0.f;
+    bool bad = false;
+    for (int64_t row = r0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < r_pad; row += (int64_t)gridDim.x * 4) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(x8 + row * dpad8);
+        if (row >= r1) {
+            for (int i = lane; i < dpad8 / 4; i += 64) dst[i] = 0u;
+            if (lane == 0) sx8[row] = __uint_as_float(0x7fc00000u);
+            continue;
+        }
+        const float* src = xf + row * d;
+        auto centred = [&](int i) -> float4 {          // r = (x - mu) * w: one rounding (the subtraction); the product with a power of two is exact
+            float4 v = *reinterpret_cast<const float4*>(src + i);
+            const float4 c = *reinterpret_cast<const float4*>(mu + i), w = *reinterpret_cast<const float4*>(wt + i);
+            v.x = (v.x - c.x) * w.x; v.y = (v.y - c.y) * w.y; v.z = (v.z - c.z) * w.z; v.w = (v.w - c.w) * w.w;
+            return v;
+        };
+        float amax = 0.f, r2 = 0.f;
+        bool fin = true;
+        for (int i = lane * 4; i < d; i += 256) {
+            const float4 v = centred(i);
+            const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+            fin = fin && (fabsf(v.x) <= 3.4028235e38f) && (fabsf(v.y) <= 3.4028235e38f) && (fabsf(v.z) <= 3.4028235e38f) && (fabsf(v.w) <= 3.4028235e38f);
+            amax = fmaxf(amax, m);
+            r2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, m, 64)); r2 += __shfl_xor(r2, m, 64); }
+        fin = __all(fin);
+        const float sx = fin ? amax / 127.f : 0.f;
+        const float inv = (fin && amax > 0.f) ? 127.f / amax : 0.f;
+        float e2 = 0.f;
+        for (int i = lane * 4; i < dpad8; i += 256) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < d && fin) v = centred(i);
+            const float a0 = fminf(fmaxf(rintf(v.x * inv), -127.f), 127.f), a1 = fminf(fmaxf(rintf(v.y * inv), -127.f), 127.f);
+            const float a2 = fminf(fmaxf(rintf(v.z * inv), -127.f), 127.f), a3 = fminf(fmaxf(rintf(v.w * inv), -127.f), 127.f);
+            const float d0 = v.x - sx * a0, d1 = v.y - sx * a1, d2 = v.z - sx * a2, d3 = v.w - sx * a3;
+            e2 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            dst[i >> 2] = ((uint32_t)(int)a0 & 255u) | (((uint32_t)(int)a1 & 255u) << 8) | (((uint32_t)(int)a2 & 255u) << 16) | (((uint32_t)(int)a3 & 255u) << 24);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) e2 += __shfl_xor(e2, m, 64);
+        // slack: the fp32 roundings of x - mu, of sx * a and of the residual (each <= 2^-24 relative per component: together <= 3.6e-7 |r| in the norm,
+        // |r| <= amax sqrt(d)) and of the sums themselves
+        const float e = sqrtf(e2) * 1.0001f + 3.6e-7f * amax * sqrtf((float)d);
+        const float rn = sqrtf(r2) * 1.0001f + 1.2e-7f * amax * sqrtf((float)d);
+        if (fin && e == e && rn == rn) { emax = fmaxf(emax, e); nmax = fmaxf(nmax, rn); } else bad = true;
+        if (lane == 0) sx8[row] = sx;
+    }
+    if (lane == 0) {
+        atomicMax(reinterpret_cast<unsigned int*>(bounds8), __float_as_uint(emax));
+        atomicMax(reinterpret_cast<unsigned int*>(bounds8) + 2, __float_as_uint(nmax));
+        if (bad) atomicOr(reinterpret_cast<unsigned int*>(bounds8) + 1, 1u);
+    }
+}
+
+// one block per query slot of the 32-query stream kernel: k-th best 16-bit score of the rows seen so far (the candidate buffer as k_select left it), the
+// query's two byte planes, eps8, and the mark threshold in units of sx8 * (254 Ia + Ib).  Slots >= nq: zero planes, threshold +inf.
+__global__ __launch_bounds__(256) void k_scan8_prep(const uint64_t* __restrict__ cand, int cand_cap, const uint32_t* __restrict__ cnt, const float* __restrict__ eps16,
+                                                    const float* __restrict__ qf, int nq, int d, int dpad8, int k, const float* __restrict__ bounds8,
+                                                    const float* __restrict__ mu8, int8_t* __restrict__ q8, float* __restrict__ thr8) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red[5][4];
+    uint64_t* s = reinterpret_cast<uint64_t*>(smem);
+    unsigned int* hist = reinterpret_cast<unsigned int*>(s + cand_cap);                 // 256 + 4
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int8_t* pa = q8 + (int64_t)q * dpad8;
+    int8_t* pb = q8 + (int64_t)(32 + q) * dpad8;
+    if (q >= nq) {
+        for (int i = tid; i < dpad8; i += 256) { pa[i] = 0; pb[i] = 0; }
+        if (tid == 0) thr8[q] = INFINITY;
+        return;
+    }
+    int m = (int)cnt[q];
+    if (m > cand_cap) m = cand_cap;
+    float kth = -INFINITY;
+    if (m >= k) {
+        const uint64_t* c = cand + (int64_t)q * cand_cap;
+        for (int i = tid; i < m; i += 256) s[i] = c[i];
+        __syncthreads();
+        kth = ord_f32(radix_select_desc<256>(s, m, k, hist, tid));
+    }
+    const float* qv = qf + (int64_t)q * d;
+    const float* mu = mu8;
+    const float* winv = mu8 + 2 * dpad8;
+    float amax = 0.f;
+    for (int i = tid; i < d; i += 256) amax = fmaxf(amax, fabsf(qv[i] * winv[i]));      // u = q / w (exact: w is a power of two)
+#pragma unroll
+    for (int mm = 32; mm >= 1; mm >>= 1) amax = fmaxf(amax, __shfl_xor(amax, mm, 64));
+    if (lane == 0) red[0][wave] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    const float sq = amax / 127.f;
+    const float inv = amax > 0.f ? 127.f / amax : 0.f;
+    float e2 = 0.f, u2 = 0.f, qm = 0.f, qma = 0.f;
+    for (int i = tid; i < dpad8; i += 256) {
+        const float v = i < d ? qv[i] : 0.f;
+        const float u = v * winv[i];
+        const float t = u * inv;
+        const float a = fminf(fmaxf(rintf(t), -127.f), 127.f);
+        const float b = fminf(fmaxf(rintf(254.f * (t - a)), -127.f), 127.f);
+        const float uh = sq * (a + b * (1.f / 254.f));
+        e2 += (u - uh) * (u - uh);
+        u2 += u * u;
+        const float c = mu[i];
+        qm += v * c; qma += fabsf(v * c);
+        pa[i] = (a == a) ? (int8_t)(int)a : (int8_t)0;
+        pb[i] = (b == b) ? (int8_t)(int)b : (int8_t)0;
+    }
+#pragma unroll
+    for (int mm = 32; mm >= 1; mm >>= 1) {
+        e2 += __shfl_xor(e2, mm, 64); u2 += __shfl_xor(u2, mm, 64); qm += __shfl_xor(qm, mm, 64); qma += __shfl_xor(qma, mm, 64);
+    }
+    if (lane == 0) { red[1][wave] = e2; red[2][wave] = u2; red[3][wave] = qm; red[4][wave] = qma; }
+    __syncthreads();
+    if (tid == 0) {
+        e2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        u2 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        qm = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+        qma = red[4][0] + red[4][1] + red[4][2] + red[4][3];
+        const float un = sqrtf(u2) * 1.0001f;
+        const float du = sqrtf(e2) * 1.0001f + 4.8e-7f * un;               // |u - u^|, + the fp32 rounding of u^ itself in the residual above
+        const float dx = bounds8[0];                                       // max |r - r^|,  r = (x - mu) w,  r^ = sx8 x8
+        const float rn = bounds8[2] + dx;                                  // max |r^| <= max |r| + dx
+        // q.x = q.mu + u.r;  |u.r - u^.r^| <= |u| dx + |u - u^| |r^|;  q.mu in fp32: any order of <= d additions, <= (d + 2) 2^-24 sum |q_i mu_i|;
+        // the device's arithmetic on the byte score (one fma rounding, the scale product, the threshold's own scaling): <= 4 x 2^-23 relative
+        float e8 = un * dx + du * rn + 4.8e-7f * un * rn + (float)(d + 2) * 6.0e-8f * qma * 1.01f;
+        e8 = e8 * 1.001f + 1e-30f;
+        const float theta = kth - eps16[q] - e8 - qm;                      // bound on the byte score u^.r^ of a row that can still matter
+        const bool usable = (fabsf(theta) <= 3.4028235e38f) && sq > 0.f && (sq <= 3.4028235e38f) && reinterpret_cast<const unsigned int*>(bounds8)[1] == 0u;
+        float t = -INFINITY;                                               // unusable: every row is marked (slow, exact)
+        if (usable) { t = theta * (254.f / sq); t -= fabsf(t) * 1e-6f; }
+        thr8[q] = t;
+    }
+}
+
+// 16-bit scores of the marked rows for the block's queries -> candidate buffers (what the final round of the 16-bit scan does for the rows it streams).
+// One wave per listed row and step; the queries' 16-bit copies sit in LDS as fp32.  The sum order differs from the MFMA chain's; eps16 covers any order of
+// at most dpad fp32 additions (k_prep_queries: 1.1 dpad 2^-24 |qc| |xc|; here 16 sequential + 6 tree steps).
+template <class T>
+__global__ __launch_bounds__(256) void k_score_list(const uint16_t* __restrict__ xc, int dpad, const uint16_t* __restrict__ qc, int nq,
+                                                    const uint32_t* __restrict__ rowlist, const unsigned int* __restrict__ count,
+                                                    const float* __restrict__ thr, uint32_t* __restrict__ cnt, uint64_t* __restrict__ cand, int cand_cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = reinterpret_cast<float*>(smem);                           // [nq][dpad]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned n = *count;
+    const unsigned W = gridDim.x * 4u;
+    unsigned i = blockIdx.x * 4u + (unsigned)(tid >> 6);
+    if (blockIdx.x * 4u >= n) return;                                     // (block-uniform) nothing for this block: skip the query load too
+    for (int j = tid; j < nq * dpad; j += 256) qs[j] = T::to_f32(qc[j]);
+    __syncthreads();
+    // dpad <= 1024: a lane holds 8 consecutive elements of each 512-element half; the NEXT row is requested before this one is scored
+    uint4 cur[2], nxt[2];
+    uint32_t row = 0u, nrow = 0u;
+    auto load = [&](uint4 (&r)[2], uint32_t rw) {
+        const uint16_t* xr = xc + (int64_t)rw * dpad + lane * 8;
+        r[0] = (lane * 8 < dpad) ? *reinterpret_cast<const uint4*>(xr) : make_uint4(0u, 0u, 0u, 0u);
+        r[1] = (lane * 8 + 512 < dpad) ? *reinterpret_cast<const uint4*>(xr + 512) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    if (i < n) { row = rowlist[i]; load(cur, row); }
+    for (; i < n; i += W) {
+        const bool more = i + W < n;
+        if (more) { nrow = rowlist[i + W]; load(nxt, nrow); }
+        for (int q = 0; q < nq; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h * 512 + lane * 8 < dpad) {
+                    const uint4 v = cur[h];
+                    const float* qq = qs + q * dpad + h * 512 + lane * 8;
+                    const float4 q0 = *reinterpret_cast<const float4*>(qq), q1 = *reinterpret_cast<const float4*>(qq + 4);
+                    acc = fmaf(T::to_f32((uint16_t)(v.x & 0xffffu)), q0.x, acc); acc = fmaf(T::to_f32((uint16_t)(v.x >> 16)), q0.y, acc);
+                    acc = fmaf(T::to_f32((uint16_t)(v.y & 0xffffu)), q0.z, acc); acc = fmaf(T::to_f32((uint16_t)(v.y >> 16)), q0.w, acc);
+                    acc = fmaf(T::to_f32((uint16_t)(v.z & 0xffffu)), q1.x, acc); acc = fmaf(T::to_f32((uint16_t)(v.z >> 16)), q1.y, acc);
+                    acc = fmaf(T::to_f32((uint16_t)(v.w & 0xffffu)), q1.z, acc); acc = fmaf(T::to_f32((uint16_t)(v.w >> 16)), q1.w, acc);
+                }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+            if (lane == 0 && acc >= thr[q]) {
+                const unsigned pos = atomicAdd(&cnt[q], 1u);
+                if (pos < (unsigned)cand_cap) cand[(int64_t)q * cand_cap + pos] = make_key(acc, row);
+            }
+        }
+        cur[0] = nxt[0]; cur[1] = nxt[1]; row = nrow;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // exact full scan (fallback for flagged queries, and mode = 1)
 // ---------------------------------------------------------------------------------------------------------
 // grid (nchunks, nqf): canonical score of every row of the chunk for one query, chunk-local top-kk keys
@@ -1246,6 +1555,103 @@ static int launch_q32(const CoarseArgs& a, int kt64, int num_cu, int device, hip
     return fail(KR_EINVAL, "no k_coarse_q32 instance for dpad/64 = %d", kt64);
 }
 
+// ---- byte pre-scan: host side ---------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t BYTE_UNUSED = 0xffffffffu;
+constexpr int BYTE_NQ_MAX = 8;                    // queries per block up to which the final round goes through the int8 copy (k_score_list keeps them in 32 KiB of LDS)
+
+template <int KT>
+static int launch_scan8_kt(const CoarseArgs& a, int num_cu, int device, hipStream_t st) {
+    constexpr int lds = q32_lds<KT>();
+    static DevOnce once;
+    KR_TRY(once_per_device(once, device, [&]() -> int {
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coarse_q32<BF16, 3, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        return 0;
+    }));
+    hipLaunchKernelGGL((k_coarse_q32<BF16, 3, KT>), dim3(num_cu), dim3(Q32_THREADS), lds, st, a);
+    return 0;
+}
+static bool byte_dim_ok(int d) { const int dp = (int)round_up(d, 128); return dp == 1024 || dp == 768 || dp == 512; }
+
+// the bitmap / row list shared by pass 2's marking scan and the byte pre-scan (one bit per row + one word: the list length; the marked rows, compacted)
+static int ensure_bitmap(Index* ix) {
+    const size_t words = (size_t)((ix->n + 31) / 32);
+    if (words <= ix->bitmap_words) return 0;
+    if (ix->bitmap) (void)hipFree(ix->bitmap);
+    if (ix->rowlist) (void)hipFree(ix->rowlist);
+    ix->bitmap = nullptr; ix->rowlist = nullptr; ix->bitmap_words = 0;
+    KR_HIP(hipMalloc(&ix->bitmap, (words + 1) * sizeof(uint32_t)));
+    KR_HIP(hipMalloc(&ix->rowlist, words * 32 * sizeof(uint32_t)));
+    ix->bitmap_words = words;
+    return 0;
+}
+
+// Bring the int8 copy up to row n (kernels on `st`, behind the adds the caller has already ordered).  true: usable for this call.  An allocation failure is
+// not an error: the copy is an accelerator, the index then serves every block from the 16-bit copy (byte_off).
+static bool ensure_byte_copy(Index* ix, hipStream_t st) {
+    if (ix->byte_off) return false;
+    const int dpad8 = (int)round_up(ix->d, 128);
+    auto give_up = [&]() { (void)hipGetLastError(); ix->byte_off = true; return false; };
+    if (!ix->thr8) {
+        ix->dpad8 = dpad8;
+        if (!ix->bounds8 && hipMalloc(&ix->bounds8, 4 * sizeof(float)) != hipSuccess) return give_up();
+        if (!ix->q8 && hipMalloc(&ix->q8, (size_t)2 * 32 * dpad8) != hipSuccess) return give_up();
+        if (hipMemsetAsync(ix->bounds8, 0, 4 * sizeof(float), st) != hipSuccess) return give_up();
+        if (!ix->mu8 && hipMalloc(&ix->mu8, (size_t)(3 + 2 * MU_PARTS) * dpad8 * sizeof(float)) != hipSuccess) return give_up();
+        if (hipMalloc(&ix->thr8, 32 * sizeof(float)) != hipSuccess) return give_up();
+    }
+    if (ix->n8 == ix->n) return true;
+    const int64_t need = round_up(ix->n, 256);
+    if (need > ix->cap8) {
+        if (ix->x8) (void)hipFree(ix->x8);            // (hipFree waits for the device: earlier searches that read the old copy are done)
+        if (ix->sx8) (void)hipFree(ix->sx8);
+        ix->x8 = nullptr; ix->sx8 = nullptr; ix->n8 = 0;
+        const int64_t ncap = std::max(need, round_up(ix->cap8 + ix->cap8 / 2, 256));
+        ix->cap8 = 0;
+        if (hipMalloc(&ix->x8, (size_t)ncap * dpad8) != hipSuccess) return give_up();
+        if (hipMalloc(&ix->sx8, (size_t)ncap * sizeof(float)) != hipSuccess) return give_up();
+        ix->cap8 = ncap;
+        if (hipMemsetAsync(ix->bounds8, 0, 4 * sizeof(float), st) != hipSuccess) return give_up();
+    }
+    if (ix->n8 == 0) {   // a fresh copy: its centre = the mean of the first rows (fixed from here on: later rows are quantised around the same centre)
+        const int64_t m = std::min<int64_t>(ix->n, MU_ROWS);
+        hipLaunchKernelGGL(k_mu_partial, dim3(MU_PARTS), dim3(256), 0, st, ix->xf, m, ix->d, dpad8, ix->mu8 + 3 * dpad8);
+        hipLaunchKernelGGL(k_mu_final, dim3(1), dim3(1024), 0, st, ix->mu8 + 3 * dpad8, m, ix->d, dpad8, ix->mu8);
+    }
+    const int64_t rows = need - ix->n8;
+    const unsigned grid = (unsigned)std::min<int64_t>((rows + 3) / 4, (int64_t)ix->num_cu * 16);
+    hipLaunchKernelGGL(k_quant8_rows, dim3(grid), dim3(256), 0, st, ix->xf, ix->mu8, ix->x8, ix->sx8, ix->n8, ix->n, need, ix->d, dpad8, ix->bounds8);
+    if (hipGetLastError() != hipSuccess) return give_up();
+    ix->n8 = ix->n;
+    return true;
+}
+
+// The final round of a small block through the int8 copy: thresholds + query planes, the marking stream over the round's tile slots, the row list, the
+// 16-bit scores of the listed rows into the candidate buffers.  Enqueue only; the list length stays on the device.
+template <class T>
+static int byte_final_round(Index* ix, const CoarseArgs& a, int nq, int k, hipStream_t st) {
+    const size_t words = (size_t)((ix->n + 31) / 32);
+    unsigned int* cnt_word = ix->bitmap + words;
+    KR_HIP(hipMemsetAsync(ix->bitmap, 0, (words + 1) * sizeof(uint32_t), st));
+    const size_t prep_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int);
+    hipLaunchKernelGGL(k_scan8_prep, dim3(32), dim3(256), prep_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->eps, ix->q_f, nq, ix->d, ix->dpad8, k, ix->bounds8, ix->mu8,
+                       ix->q8, ix->thr8);
+    CoarseArgs m = a;
+    m.xc = reinterpret_cast<const uint16_t*>(ix->x8); m.dpad = ix->dpad8 / 2;
+    m.qc = reinterpret_cast<const uint16_t*>(ix->q8); m.qc2 = reinterpret_cast<const uint16_t*>(ix->q8 + (size_t)32 * ix->dpad8);
+    m.sx8 = ix->sx8; m.thr = ix->thr8; m.bitmap = ix->bitmap; m.nq_pad = 32; m.nq = nq; m.direct = 3;
+    switch (ix->dpad8 / 128) {
+        case 8: KR_TRY(launch_scan8_kt<8>(m, ix->num_cu, ix->device, st)); break;
+        case 6: KR_TRY(launch_scan8_kt<6>(m, ix->num_cu, ix->device, st)); break;
+        case 4: KR_TRY(launch_scan8_kt<4>(m, ix->num_cu, ix->device, st)); break;
+        default: return fail(KR_EINVAL, "no byte pre-scan instance for d = %d", ix->d);
+    }
+    hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ix->bitmap, (int64_t)words, ix->rowlist, cnt_word);
+    hipLaunchKernelGGL(k_score_list<T>, dim3(ix->num_cu * 8), dim3(256), (size_t)nq * ix->dpad * sizeof(float), st, ix->xc, ix->dpad, ix->q_c, nq, ix->rowlist, cnt_word,
+                       ix->thr, ix->cnt, ix->cand, ix->cand_cap);
+    KR_HIP(hipGetLastError());
+    return 0;
+}
+
 // over-fetch K1 and buffer capacity for top-k: K1 = pow2 >= 2.5 k while that is <= 512 (k <= 204), then pow2 >= 1.25 k (k <= 1638 > the k limit);
 // cap = min(16 K1, 8192) candidates per query (k_select / k_rerank keep the buffer in LDS).  The round growth factor follows from cap / K1.
 static void plan_buffers(int k, int& K1, int& cap, int& rmax) {
@@ -1261,8 +1667,11 @@ static void plan_buffers(int k, int& K1, int& cap, int& rmax) {
 //   round 0: cap rows, every score stored (direct slots);  growth rounds: g x the rows seen (g = cap / (2 K1) - 1: expected survivors cap / 2),
 //   thr = K1-th best; as soon as rows_seen * (cap / 64) >= rows_left the rest is ONE final round whose threshold is the r-th best seen with
 //   r = (cap/2) * seen / left  (expected cap/2 survivors), 32 <= r <= K1.
+// `final_round` (may be null): called INSTEAD of launch() for the last round when that round is not the direct one and covers at least half of the rows
+// (the byte pre-scan of small blocks, byte_final_round); *final_used tells the caller whether it was.
 template <class Launch>
-static int run_rounds(Index* ix, CoarseArgs& a, int64_t n_rows, int nq, int bm, int K1, int cap, hipStream_t st, hipEvent_t* timed, Launch&& launch, int& final_preset, int& rounds) {
+static int run_rounds(Index* ix, CoarseArgs& a, int64_t n_rows, int nq, int bm, int K1, int cap, hipStream_t st, hipEvent_t* timed, Launch&& launch, int& final_preset, int& rounds,
+                      const std::function<int(const CoarseArgs&)>* final_round = nullptr, bool* final_used = nullptr) {
     a.ntiles = (n_rows + bm - 1) / bm;
     // interleaving permutation: multiplier near ntiles / golden ratio, coprime to ntiles
     int64_t mul = std::max<int64_t>(1, (int64_t)((double)a.ntiles * 0.6180339887498949));
@@ -1279,7 +1688,10 @@ static int run_rounds(Index* ix, CoarseArgs& a, int64_t n_rows, int nq, int bm, 
         const int64_t cnt_t = std::min<int64_t>(step, a.ntiles - done);
         a.tile_begin = done; a.tile_count = cnt_t;
         if (timed && round < 16) KR_HIP(hipEventRecord(timed[2 * round], st));
-        KR_TRY(launch(a));
+        if (final_round && !a.direct && done + cnt_t >= a.ntiles && cnt_t * bm * 2 >= n_rows) {
+            KR_TRY((*final_round)(a));
+            if (final_used) *final_used = true;
+        } else KR_TRY(launch(a));
         if (timed && round < 16) KR_HIP(hipEventRecord(timed[2 * round + 1], st));
         const int preset = a.direct ? (int)(cnt_t * bm) : 0;
         ++round;
@@ -1348,6 +1760,7 @@ static int search_attrs(Index* ix) {
     return once_per_device(sel_once, ix->device, [&]() -> int {   // cap = 8192 needs 64 KiB + of dynamic LDS
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_local_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan8_prep), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_global_theta), hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_MAX * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 8192 * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rerank<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 8192 * 8 + 264 * 4));
@@ -1372,23 +1785,30 @@ static void fill_args(const Index* ix, CoarseArgs& a) {
 // the list-overflow word go to the block's status record in pinned memory, the (optimistic) results straight into the caller's buffers; nothing here waits
 // for the device.  kr_index_search_finish reads the status records and re-answers the flagged queries (slow_passes).
 static int pass1_rerank(Index* ix, int nq, int k, int rmax, int final_preset, float* scores, int64_t* rows, int blk, hipStream_t st, uint32_t* status,
-                        const float* theta_ext);
+                        const float* theta_ext, bool byte_used);
 template <class T>
-static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipStream_t st, int& rounds, int& final_preset, int& rmax);
+static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipStream_t st, int& rounds, int& final_preset, int& rmax, bool& byte_used);
 template <class T>
 static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int blk, hipStream_t st, int& rounds, uint32_t* status) {
     int final_preset = 0, rmax = 0;
-    KR_TRY(pass1_coarse<T>(ix, q, nq, k, blk, st, rounds, final_preset, rmax));
-    return pass1_rerank(ix, nq, k, rmax, final_preset, scores, rows, blk, st, status, nullptr);
+    bool byte_used = false;
+    KR_TRY(pass1_coarse<T>(ix, q, nq, k, blk, st, rounds, final_preset, rmax, byte_used));
+    return pass1_rerank(ix, nq, k, rmax, final_preset, scores, rows, blk, st, status, nullptr, byte_used);
 }
 
 // first half: queries -> 16-bit copy + bounds, the coarse rounds; leaves the candidate buffers of the block in the workspace
 template <class T>
-static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipStream_t st, int& rounds, int& final_preset, int& rmax) {
+static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipStream_t st, int& rounds, int& final_preset, int& rmax, bool& byte_used) {
     const BlockPlan p = plan_block(ix, nq, k);
     rmax = p.rmax;
+    byte_used = false;
     KR_TRY(ensure_ws(ix, k, p.cap));
     KR_TRY(search_attrs(ix));
+    // small block on a large index: the final round goes through the int8 copy (byte_final_round)
+    bool byte_ok = p.q32 && nq <= BYTE_NQ_MAX && !ix->byte_off && g_byte_prescan.load() != 0 && ix->n >= (int64_t)g_byte_min_rows.load() && byte_dim_ok(ix->d);
+    if (byte_ok && ix->byte_pause > 0) { --ix->byte_pause; byte_ok = false; }
+    if (byte_ok) byte_ok = ensure_byte_copy(ix, st);
+    if (byte_ok) KR_TRY(ensure_bitmap(ix));
     KR_HIP(hipMemcpyAsync(ix->q_f, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyDefault, st));
     CoarseArgs a; fill_args(ix, a);
     const size_t blk_cnt_bytes = ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int);
@@ -1408,6 +1828,7 @@ static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipSt
     }));
     final_preset = 0;
     rounds = 0;
+    const std::function<int(const CoarseArgs&)> byte_round = [&](const CoarseArgs& ca) -> int { return byte_final_round<T>(ix, ca, nq, k, st); };
     KR_TRY(run_rounds(ix, a, ix->n, nq, bm, p.K1, p.cap, st, blk < TIMED_BLOCKS ? ix->evc + blk * 32 : nullptr, [&](const CoarseArgs& ca) -> int {
         if (p.q32) return launch_q32<T>(ca, p.kt64, ix->num_cu, ix->device, st);
         if (p.smallq) {
@@ -1416,16 +1837,23 @@ static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipSt
         } else if (ca.direct) hipLaunchKernelGGL((k_coarse<T, true>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
         else hipLaunchKernelGGL((k_coarse<T, false>), dim3(ix->num_cu), dim3(ShapeC::NTHREADS), lds, st, ca);
         return 0;
-    }, final_preset, rounds));
+    }, final_preset, rounds, byte_ok ? &byte_round : nullptr, &byte_used));
     ix->st.coarse_rounds += rounds;
     return 0;
 }
 
 // second half: exactness certificate + exact re-rank of the candidates, status records and results on their way to the caller
 static int pass1_rerank(Index* ix, int nq, int k, int rmax, int final_preset, float* scores, int64_t* rows, int blk, hipStream_t st, uint32_t* status,
-                        const float* theta_ext) {
+                        const float* theta_ext, bool byte_used) {
     KR_TRY(launch_rerank(ix, nq, k, rmax, final_preset, ix->q_f, nullptr, blk < THETA_BLOCKS ? ix->theta1 + (size_t)blk * QBLK : nullptr, st, theta_ext));
     uint32_t* rec = status + (size_t)blk * STATUS_STRIDE;
+    // words 1, 2 behind the list-overflow word: rows the byte pre-scan marked (BYTE_UNUSED: the block did not take it) and the index's non-finite-row flag
+    if (byte_used) {
+        KR_HIP(hipMemcpyAsync(rec + 2 * QBLK + 1, ix->bitmap + (size_t)((ix->n + 31) / 32), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        KR_HIP(hipMemcpyAsync(rec + 2 * QBLK + 2, reinterpret_cast<const uint32_t*>(ix->bounds8) + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    } else {
+        rec[2 * QBLK + 1] = BYTE_UNUSED;
+    }
     KR_HIP(hipMemcpyAsync(rec, ix->flags, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     KR_HIP(hipMemcpyAsync(rec + QBLK, ix->nrer, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     KR_HIP(hipMemcpyAsync(rec + 2 * QBLK, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
@@ -1485,14 +1913,7 @@ static int slow_passes(Index* ix, const float* q, int nq, int k, float* scores, 
             const bool can_mark = coarse_pass && blk < THETA_BLOCKS && mark_useful && (kt64 == 16 || kt64 == 12 || kt64 == 8 || kt64 == 6) && !ix->no_mark;
             if (can_mark) {
                 const size_t words = (size_t)((ix->n + 31) / 32);
-                if (words > ix->bitmap_words) {
-                    if (ix->bitmap) (void)hipFree(ix->bitmap);
-                    if (ix->rowlist) (void)hipFree(ix->rowlist);
-                    ix->bitmap = nullptr; ix->rowlist = nullptr; ix->bitmap_words = 0;
-                    KR_HIP(hipMalloc(&ix->bitmap, (words + 1) * sizeof(uint32_t)));      // + 1: the list length lives behind the bits
-                    KR_HIP(hipMalloc(&ix->rowlist, words * 32 * sizeof(uint32_t)));
-                    ix->bitmap_words = words;
-                }
+                KR_TRY(ensure_bitmap(ix));                                              // (+ 1 word: the list length lives behind the bits)
                 KR_HIP(hipMemsetAsync(ix->bitmap, 0, (words + 1) * sizeof(uint32_t), st));
                 hipLaunchKernelGGL(k_prep_queries<T>, dim3(32), dim3(64), 0, st, ix->q_f2, ix->q_c, g, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr, ix->cnt, ix->flags);
                 hipLaunchKernelGGL(k_gather_theta, dim3(1), dim3(64), 0, st, ix->theta1 + (size_t)blk * QBLK, qmap, g, ix->thr_mark);
@@ -1615,6 +2036,15 @@ static int finish_one(Index* ix, int64_t* flagged_out) {
         const int nb = std::min(QBLK, pd.nq - b * QBLK);
         const uint32_t* rec = pd.status + (size_t)b * STATUS_STRIDE;
         const bool list_ovf = rec[2 * QBLK] != 0u;   // a block list overflowed: every query of the block goes on to the next pass
+        if (rec[2 * QBLK + 1] != BYTE_UNUSED) {
+            // feedback of the byte pre-scan: an index with non-finite rows never takes it again; four blocks in a row that marked more than 1/16 of the
+            // rows (data on which the byte bound does not separate) pause it for the next 1024 small blocks
+            const int64_t marked = (int64_t)rec[2 * QBLK + 1];
+            ix->st.byte_scans++; ix->st.byte_marked_rows += marked;
+            if (rec[2 * QBLK + 2] != 0u) ix->byte_off = true;
+            else if (marked > ix->n / 16) { if (++ix->byte_bad >= 4) { ix->byte_bad = 0; ix->byte_pause = 1024; } }
+            else ix->byte_bad = 0;
+        }
         std::vector<uint32_t> hflags(nb);
         int64_t nfl = 0;
         for (int i = 0; i < nb; ++i) { hflags[i] = rec[i] | (list_ovf ? 1u : 0u); ix->st.reranked_rows += rec[QBLK + i]; nfl += hflags[i] != 0u; }
@@ -1671,8 +2101,8 @@ static int begin_search_coarse(Index* ix, const float* q, int nq, int k, float* 
     { int K1, cap, rmax; plan_buffers(k, K1, cap, rmax); KR_TRY(ensure_ws(ix, k, cap)); }
     KR_HIP(hipEventRecord(ix->ev[0], st));
     int rc;
-    if (ix->coarse == KR_COARSE_BF16) rc = pass1_coarse<BF16>(ix, q, nq, k, 0, st, pd.rounds[0], pd.final_preset, pd.rmax);
-    else rc = pass1_coarse<F16>(ix, q, nq, k, 0, st, pd.rounds[0], pd.final_preset, pd.rmax);
+    if (ix->coarse == KR_COARSE_BF16) rc = pass1_coarse<BF16>(ix, q, nq, k, 0, st, pd.rounds[0], pd.final_preset, pd.rmax, pd.byte_used);
+    else rc = pass1_coarse<F16>(ix, q, nq, k, 0, st, pd.rounds[0], pd.final_preset, pd.rmax, pd.byte_used);
     if (rc) { (void)hipStreamSynchronize(st); return rc; }
     hipLaunchKernelGGL(k_local_topk, dim3(nq), dim3(256), (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int), st, ix->cand, ix->cand_cap, ix->cnt, ix->eps, k,
                        pd.final_preset, topk_out);
@@ -1702,7 +2132,7 @@ static int continue_search_rerank(Index* ix, const float* theta_ext, float* scor
     Index::Pending* pd = half_slot(ix, st);
     if (!pd) return fail(KR_ESTATE, "no split search is waiting on this stream (kr_index_search_coarse_async first, same stream, nothing else on the handle in between)");
     pd->scores = scores; pd->rows = rows;
-    const int rc = pass1_rerank(ix, pd->nq, pd->k, pd->rmax, pd->final_preset, scores, rows, 0, st, pd->status, theta_ext);
+    const int rc = pass1_rerank(ix, pd->nq, pd->k, pd->rmax, pd->final_preset, scores, rows, 0, st, pd->status, theta_ext, pd->byte_used);
     if (rc) { (void)hipStreamSynchronize(st); pd->active = false; pd->half = false; --ix->pend_n; return rc; }
     pd->half = false;
     KR_HIP(hipEventRecord(ix->ev[3], st));
@@ -1781,6 +2211,7 @@ int kr_index_create(int d, int metric, int coarse_dtype, int device, kr_index** 
     (void)hipMemset(ix->bounds, 0, 2 * sizeof(float));
     ix->no_q32 = getenv("KIRAG_AMD_NO_Q32") != nullptr; ix->no_fine = getenv("KIRAG_AMD_NO_FINE") != nullptr;
     ix->no_mark = getenv("KIRAG_AMD_NO_MARK") != nullptr; ix->no_vmm = getenv("KIRAG_AMD_NO_VMM") != nullptr;
+    ix->byte_off = getenv("KIRAG_AMD_NO_BYTE_SCAN") != nullptr;
     *out = reinterpret_cast<kr_index*>(ix);
     return 0;
 }
@@ -1796,7 +2227,7 @@ void kr_index_destroy(kr_index* h) {
     }
     if (ix->vmm == 1) { (void)hipDeviceSynchronize(); ix->vf.release(); ix->vc.release(); ix->xf = nullptr; ix->xc = nullptr; }
     void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_f2, ix->theta1, ix->thr_mark, ix->bitmap, ix->rowlist, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
-                    ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt};
+                    ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt, ix->x8, ix->sx8, ix->bounds8, ix->q8, ix->thr8, ix->mu8};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ix->h_status) (void)hipHostFree(ix->h_status);
     for (auto& e : ix->ev) if (e) (void)hipEventDestroy(e);

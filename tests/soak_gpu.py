@@ -6,6 +6,9 @@
     a sample of scores against torch's fp32 matmul (independent arithmetic);
   * index, every fourth case (round 5): the corpus cut into 2-3 uneven row shards searched in SPLIT form (coarse scan -> gathered coarse scores -> global bound
     -> re-rank above it), the merged lists must equal the unsharded search bit for bit;
+  * index (round 5): the byte pre-scan of small query blocks (kr_set_option "byte_prescan") is enabled for EVERY index size here (debug_byte_min_rows = 0), so
+    blocks of <= 8 queries at d in {512, 768, 1024} take it whenever their last round is not the direct one; every seventh case plants a NaN row (the int8
+    copy then marks every row: slow, still exact); every fifth case adds rows AFTER the first search (the int8 copy is extended) and searches again;
   * encoder (tiny config): the projection main loops / skinny tile shapes (KIRAG_AMD_PROJ_TILE = 256 / 130 / 128 / 64 / 32) must agree bit for bit, and a
     sequence's embedding must not depend on the rest of the batch.
 Exits non-zero on the first mismatch; prints one line per 25 cases."""
@@ -24,6 +27,8 @@ from kirag_amd.retriever.encoders import HipBertForward
 
 t_end = time.time() + budget
 cases = 0
+byte_scans = 0
+_lib.check(_lib.load().kr_set_option(b"debug_byte_min_rows", 0))
 
 
 def unit(n, d):
@@ -50,8 +55,11 @@ while time.time() < t_end - budget * 0.35:
         ix.add(x)
     if n > 20:   # duplicates: ties by row
         x2 = x.clone(); x2[n - 3] = x2[1]
+        if cases % 7 == 5 and k < n:               # (k == n would have to return the NaN row itself)
+            x2[n // 2] = float("nan")               # a NaN row is never returned; the byte pre-scan gives up on such an index after marking every row once
         ix = FlatIPIndex(d, device=0); ix.add(x2); x = x2
     pick = torch.from_numpy(rng.integers(0, n, nq)).cuda()
+    pick[pick == n // 2] = 0                            # (never the planted NaN row)
     q = torch.nn.functional.normalize(x[pick] + 0.3 * torch.randn(nq, d, device="cuda") / d ** 0.5, dim=1)
     force = cases % 4 == 3
     if force:
@@ -111,7 +119,16 @@ while time.time() < t_end - budget * 0.35:
                 why.append(("split sharded search != unsharded", cuts, bad[:5].tolist()))
             ok = ok and oks
             del shards
-    ref = (q[:4] @ x.T).cpu().numpy()                   # independent arithmetic: fp32 matmul scores of the returned rows
+    if cases % 5 == 4 and nq <= 8 and n > 1000:        # rows added AFTER the first search: the int8 copy is extended (or rebuilt), the new best rows must be found
+        extra = torch.nn.functional.normalize(q[:1] + 0.05 * torch.randn(300, d, device="cuda") / d ** 0.5, dim=1) * float(x[1].norm())
+        ix.add(extra)
+        se, ie = ix.search(q, k); se1, ie1 = ix.search(q, k, mode=1)
+        oke = np.array_equal(ie, ie1) and np.array_equal(se.view(np.uint32), se1.view(np.uint32)) and (ie[0, : min(k, 5)] >= n).sum() >= min(k, 5) - 1   # (the picked row itself may still lead)
+        if not oke:
+            why.append(("after a later add: mode0 != mode1", ie[0, :5].tolist(), ie1[0, :5].tolist()))
+        ok = ok and oke
+    nan_rows = torch.isnan(x).any(1)
+    ref = (q[:4] @ torch.where(nan_rows[:, None], torch.zeros_like(x), x).T).cpu().numpy()   # independent arithmetic: fp32 matmul scores of the returned rows
     got = np.take_along_axis(ref, i0[:4], axis=1)
     scale = float(np.abs(ref).max()) + 1e-30
     ok3 = np.abs(got - s0[:4]).max() <= 4e-6 * scale and (np.diff(s0, axis=1) <= 0).all()
@@ -123,8 +140,9 @@ while time.time() < t_end - budget * 0.35:
         print("INDEX MISMATCH", dict(n=n, d=d, nq=nq, k=k, seed=seed, case=cases, force=force), why, flush=True)
         sys.exit(1)
     cases += 1
+    byte_scans += ix.stats()["byte_scans"]
     if cases % 25 == 0:
-        print(f"[stress] {cases} cases ok (last index case n={n} d={d} nq={nq} k={k}, stats {ix.stats()['certified']} certified / {ix.stats()['fine']} fine / {ix.stats()['exact']} exact of {ix.stats()['queries']})", flush=True)
+        print(f"[stress] {cases} cases ok, {byte_scans} blocks through the byte pre-scan (last index case n={n} d={d} nq={nq} k={k}, stats {ix.stats()['certified']} certified / {ix.stats()['fine']} fine / {ix.stats()['exact']} exact of {ix.stats()['queries']})", flush=True)
     del ix, x
 
 # ---- encoder -----------------------------------------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.kr_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.kr_abi_version() == _lib.ABI_VERSION == 8
 
 
 @pytest.mark.skipif(not NO_GPU, reason="checks the no-GPU failure mode")

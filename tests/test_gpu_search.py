@@ -677,6 +677,128 @@ def test_pass2_prescan_marks_only_the_slots_that_matter():
     assert st2["marked_passes"] == 0 and st2["fine"] == st["fine"], st2
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# byte pre-scan of small query blocks (ABI 8): the final coarse round through the int8 copy
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _opt(name, v):
+    from kirag_amd import _lib
+    _lib.check(_lib.load().kr_set_option(name, v))
+
+
+@pytest.fixture()
+def byte_everywhere():
+    """small blocks take the byte pre-scan at every index size (the product default is 2^19 rows)"""
+    _opt(b"debug_byte_min_rows", 0); _opt(b"byte_prescan", 1)
+    yield
+    _opt(b"debug_byte_min_rows", -1); _opt(b"byte_prescan", 1)
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(40000, 1024, 2, 10), (30011, 768, 8, 50), (25000, 512, 1, 100), (33333, 1024, 7, 1), (50000, 1000, 3, 20), (9000, 768, 5, 64)])
+def test_byte_prescan_small_corpora_vs_canonical(byte_everywhere, n, d, nq, k):
+    """Blocks of <= 8 queries with the int8 final round forced on at small sizes: bit-exact vs the C oracle (rows and score bits), identical to the same
+    search with the option off, ties by row index across the byte-scanned region, and the statistics show that the path ran and what it marked."""
+    rng = np.random.default_rng(n + d + nq)
+    x = _unit(rng, n, d)
+    q, pick = _queries_near(rng, x, nq)
+    x[n - 5] = x[pick[0]]; x[n // 2 + 7] = x[pick[0]]            # duplicates of the best row far away: the tie is broken by row index, every copy must be marked
+    ix = _mk(d, x)
+    s, i = ix.index.search(q, k)
+    st = ix.index.stats(reset=True)
+    so, io = S.search_canonical(q, x, k)
+    assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    assert st["byte_scans"] == 1 and 0 < st["byte_marked_rows"] < n, st
+    assert st["certified"] + st["fallback"] == nq
+    _opt(b"byte_prescan", 0)
+    s0, i0 = ix.index.search(q, k)
+    st0 = ix.index.stats(reset=True)
+    assert st0["byte_scans"] == 0 and np.array_equal(i0, i) and np.array_equal(s0.view(np.uint32), s.view(np.uint32))
+
+
+def test_byte_prescan_rows_added_later_and_anisotropic_rows(byte_everywhere):
+    """The int8 copy is derived data: rows added after the first search extend it (same centre and axis weights), a growth beyond its capacity rebuilds
+    it; rows with a common direction and a few large-variance axes (what the centre / weights exist for) stay exact and mark few rows."""
+    import torch
+    from kirag_amd.bench_support import CorpusDist
+    from kirag_amd.retriever.index import FlatIPIndex
+    d, k = 1024, 10
+    dev = torch.device("cuda:0")
+    cd = CorpusDist("e5like", d, dev)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    x0 = cd.rows(60_000, g)
+    ix = FlatIPIndex(d, device=0); ix.add(x0)
+    q = cd.queries_near(x0[:3], g)
+    s, i = ix.search(q, k)
+    st = ix.stats(reset=True)
+    so, io = S.search_canonical(q.cpu().numpy(), x0.cpu().numpy(), k)
+    assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    assert st["byte_scans"] == 1 and st["byte_marked_rows"] < 60_000 // 8, st
+    # a small add (fits the copy's padding) and a large one (rebuild), each with new best rows for query 0
+    xs = [x0]
+    for it, m in enumerate((100, 90_000)):
+        extra = cd.rows(m, g)
+        extra[:5] = torch.nn.functional.normalize(q[0] + 0.01 * torch.randn(5, d, device=dev, generator=g) / d ** 0.5, dim=1)
+        n_before = sum(len(t) for t in xs)
+        ix.add(extra); xs.append(extra)
+        s, i = ix.search(q, k)
+        st = ix.stats(reset=True)
+        xa = torch.cat(xs).cpu().numpy()
+        so, io = S.search_canonical(q.cpu().numpy(), xa, k)
+        assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+        assert st["byte_scans"] == 1 and (i[0, : 5 * (it + 1)] >= 60_000).all() and (i[0] >= n_before).sum() == 5, (st, i[0])
+
+
+def test_byte_prescan_nan_row_marks_everything_once_then_steps_aside(byte_everywhere):
+    """A non-finite element anywhere makes the byte bound meaningless: the pre-scan of that call marks every row (exact, slow), the index never takes
+    the path again; NaN rows are never returned either way."""
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 30000, 1024, 2, 10
+    x = _unit(rng, n, d)
+    x[12345] = np.nan
+    q, _ = _queries_near(rng, x[:1000], nq)
+    ix = _mk(d, x)
+    xo = x.copy(); xo[12345] = 0.0
+    so, io = S.search_canonical(q, xo, k)
+    for call in range(2):
+        s, i = ix.index.search(q, k)
+        st = ix.index.stats(reset=True)
+        assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32)) and not (i == 12345).any()
+        assert st["byte_scans"] == (1 if call == 0 else 0), (call, st)
+    
+
+def test_byte_prescan_at_the_product_threshold_600k_rows():
+    """The product's own switch-over (>= 2^19 rows): 600k x 1024 rows, 1 / 2 / 8 queries, top-10 and top-100, option on == option off bit for bit, a query
+    bit-exact vs the C oracle, and the path is not taken by a 9-query block or below the threshold."""
+    import torch
+    from kirag_amd.retriever.index import FlatIPIndex
+    n, d = 600_000, 1024
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    x = torch.nn.functional.normalize(torch.randn(n, d, device=dev, generator=g), dim=1)
+    ix = FlatIPIndex(d, device=0); ix.add(x)
+    q = torch.nn.functional.normalize(x[:9] + 0.05 * torch.randn(9, d, device=dev, generator=g), dim=1)
+    _opt(b"byte_prescan", 1); _opt(b"debug_byte_min_rows", -1)
+    try:
+        for nq in (1, 2, 8):
+            for k in (10, 100):
+                s1, i1 = ix.search(q[:nq], k); st1 = ix.stats(reset=True)
+                _opt(b"byte_prescan", 0)
+                s0, i0 = ix.search(q[:nq], k); st0 = ix.stats(reset=True)
+                _opt(b"byte_prescan", 1)
+                assert st1["byte_scans"] == 1 and st0["byte_scans"] == 0 and st1["byte_marked_rows"] < n // 4, (st1, st0)
+                assert np.array_equal(i1, i0) and np.array_equal(s1.view(np.uint32), s0.view(np.uint32)) and (i1[:, 0] == np.arange(nq)).all()
+        s9, _ = ix.search(q, 10)
+        assert ix.stats(reset=True)["byte_scans"] == 0
+        so, io = S.search_canonical(q[:1].cpu().numpy(), x.cpu().numpy(), 10)
+        s1, i1 = ix.search(q[:1], 10)
+        assert np.array_equal(i1, io) and np.array_equal(s1.view(np.uint32), so.view(np.uint32))
+        small = FlatIPIndex(d, device=0); small.add(x[:400_000])
+        small.search(q[:1], 10)
+        assert small.stats()["byte_scans"] == 0
+    finally:
+        _opt(b"byte_prescan", 1)
+
+
 def test_faiss_padding_flag_for_k_above_ntotal():
     """`top_docs > ntotal`: default = ValueError (documented deviation); with faiss_padding=True the reference's behaviour on faiss's padded output:
     k entries per query, the missing ones with score -FLT_MAX and the id that label -1 maps to through index_id_to_db_id[-1] (index.py:49)."""
