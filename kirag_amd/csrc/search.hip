@@ -1273,6 +1273,21 @@ __global__ __launch_bounds__(256) void k_score_list(const uint16_t* __restrict__
     }
 }
 
+// the status record of one query block, written straight into the call's pinned host record (one kernel instead of three to five 4-byte .. 4-KiB copies,
+// each of which is a 9-us copy kernel of its own on the stream): [QBLK] flags | [QBLK] re-ranked rows | list overflow | rows marked by the byte pre-scan
+// (BYTE_UNUSED: not taken) | non-finite-row flag of the int8 copy
+constexpr uint32_t BYTE_UNUSED = 0xffffffffu;
+__global__ __launch_bounds__(256) void k_status_pack(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ nrer, const unsigned int* __restrict__ list_overflow,
+                                                     const unsigned int* __restrict__ marked, const float* __restrict__ bounds8, int nq, uint32_t* __restrict__ rec) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nq) { rec[i] = flags[i]; rec[QBLK + i] = nrer[i]; }
+    if (i == 0) {
+        rec[2 * QBLK] = *list_overflow;
+        rec[2 * QBLK + 1] = marked ? *marked : BYTE_UNUSED;
+        rec[2 * QBLK + 2] = marked ? reinterpret_cast<const uint32_t*>(bounds8)[1] : 0u;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // exact full scan (fallback for flagged queries, and mode = 1)
 // ---------------------------------------------------------------------------------------------------------
@@ -1556,7 +1571,6 @@ static int launch_q32(const CoarseArgs& a, int kt64, int num_cu, int device, hip
 }
 
 // ---- byte pre-scan: host side ---------------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t BYTE_UNUSED = 0xffffffffu;
 constexpr int BYTE_NQ_MAX = 8;                    // queries per block up to which the final round goes through the int8 copy (k_score_list keeps them in 32 KiB of LDS)
 
 template <int KT>
@@ -1745,13 +1759,17 @@ static int ensure_slot_status(Index::Pending& pd, int nblocks) {
 }
 
 struct BlockPlan { bool smallq, q32; int kt64, nq_pad, K1, cap, rmax; };
-static BlockPlan plan_block(const Index* ix, int nq, int k) {
+static BlockPlan plan_block(const Index* ix, int nq, int k, bool byte_block = false) {
     BlockPlan p;
     p.smallq = nq <= ShapeSplit::BN;             // one 128-query tile: HBM-bound scan on the producer / consumer loop
     p.kt64 = ix->dpad / 64;
     p.q32 = nq <= 32 && (p.kt64 == 16 || p.kt64 == 12 || p.kt64 == 8 || p.kt64 == 6) && !ix->no_q32;   // register-resident queries, pure stream
     p.nq_pad = p.q32 ? 32 : (int)round_up(nq, p.smallq ? ShapeSplit::BN : ShapeC::BN);   // <= QBLK = 1024 = 4 x 256
     plan_buffers(k, p.K1, p.cap, p.rmax);
+    // a block whose final round streams the int8 copy wants that round to start early (every 16-bit round before it costs a launch plus 2 bytes per
+    // element): with 4096 candidates per query the schedule is the direct round (4096 rows), one 16-bit round of 31 x that, then the byte round over
+    // the remaining ~97 % (with 1024 candidates the final round cannot start before 6 % of the rows have been seen: run_rounds' survivor budget)
+    if (byte_block && p.cap < 4096) p.cap = 4096;
     return p;
 }
 
@@ -1799,16 +1817,16 @@ static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores
 // first half: queries -> 16-bit copy + bounds, the coarse rounds; leaves the candidate buffers of the block in the workspace
 template <class T>
 static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipStream_t st, int& rounds, int& final_preset, int& rmax, bool& byte_used) {
-    const BlockPlan p = plan_block(ix, nq, k);
+    // small block on a large index: the final round goes through the int8 copy (byte_final_round)
+    bool byte_ok = plan_block(ix, nq, k).q32 && nq <= BYTE_NQ_MAX && !ix->byte_off && g_byte_prescan.load() != 0 && ix->n >= (int64_t)g_byte_min_rows.load() && byte_dim_ok(ix->d);
+    if (byte_ok && ix->byte_pause > 0) { --ix->byte_pause; byte_ok = false; }
+    if (byte_ok) byte_ok = ensure_byte_copy(ix, st);
+    if (byte_ok) KR_TRY(ensure_bitmap(ix));
+    const BlockPlan p = plan_block(ix, nq, k, byte_ok);
     rmax = p.rmax;
     byte_used = false;
     KR_TRY(ensure_ws(ix, k, p.cap));
     KR_TRY(search_attrs(ix));
-    // small block on a large index: the final round goes through the int8 copy (byte_final_round)
-    bool byte_ok = p.q32 && nq <= BYTE_NQ_MAX && !ix->byte_off && g_byte_prescan.load() != 0 && ix->n >= (int64_t)g_byte_min_rows.load() && byte_dim_ok(ix->d);
-    if (byte_ok && ix->byte_pause > 0) { --ix->byte_pause; byte_ok = false; }
-    if (byte_ok) byte_ok = ensure_byte_copy(ix, st);
-    if (byte_ok) KR_TRY(ensure_bitmap(ix));
     KR_HIP(hipMemcpyAsync(ix->q_f, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyDefault, st));
     CoarseArgs a; fill_args(ix, a);
     const size_t blk_cnt_bytes = ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int);
@@ -1847,16 +1865,9 @@ static int pass1_rerank(Index* ix, int nq, int k, int rmax, int final_preset, fl
                         const float* theta_ext, bool byte_used) {
     KR_TRY(launch_rerank(ix, nq, k, rmax, final_preset, ix->q_f, nullptr, blk < THETA_BLOCKS ? ix->theta1 + (size_t)blk * QBLK : nullptr, st, theta_ext));
     uint32_t* rec = status + (size_t)blk * STATUS_STRIDE;
-    // words 1, 2 behind the list-overflow word: rows the byte pre-scan marked (BYTE_UNUSED: the block did not take it) and the index's non-finite-row flag
-    if (byte_used) {
-        KR_HIP(hipMemcpyAsync(rec + 2 * QBLK + 1, ix->bitmap + (size_t)((ix->n + 31) / 32), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        KR_HIP(hipMemcpyAsync(rec + 2 * QBLK + 2, reinterpret_cast<const uint32_t*>(ix->bounds8) + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    } else {
-        rec[2 * QBLK + 1] = BYTE_UNUSED;
-    }
-    KR_HIP(hipMemcpyAsync(rec, ix->flags, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    KR_HIP(hipMemcpyAsync(rec + QBLK, ix->nrer, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    KR_HIP(hipMemcpyAsync(rec + 2 * QBLK, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_status_pack, dim3((nq + 255) / 256), dim3(256), 0, st, ix->flags, ix->nrer, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE,
+                       byte_used ? ix->bitmap + (size_t)((ix->n + 31) / 32) : nullptr, ix->bounds8, nq, rec);
+    KR_HIP(hipGetLastError());
     KR_HIP(hipMemcpyAsync(scores, ix->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
     KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
     return 0;
