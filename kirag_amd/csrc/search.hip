@@ -171,6 +171,7 @@ struct Index {
         bool half = false;              // kr_index_search_coarse_async was enqueued, kr_index_search_rerank_async not yet
         int final_preset = 0, rmax = 0; // ... what the second half needs from the first
         bool byte_used = false;
+        bool direct_io = false;         // pass 1 read the queries / wrote the results in the caller's own buffers: the workspace holds neither
     };
     static constexpr int PEND_MAX = 16;
     Pending pend[PEND_MAX];
@@ -221,8 +222,9 @@ __global__ __launch_bounds__(256) void k_add_rows(const float* __restrict__ xf, 
 template <class T>
 __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ qf, uint16_t* __restrict__ qc, int nq, int d, int dpad,
                                                      const float* __restrict__ bounds, float* __restrict__ eps, float* __restrict__ thr,
-                                                     uint32_t* __restrict__ cnt, uint32_t* __restrict__ flags) {
+                                                     uint32_t* __restrict__ cnt, uint32_t* __restrict__ flags, unsigned int* __restrict__ zero = nullptr, int nzero = 0) {
     const int q = blockIdx.x, lane = threadIdx.x;
+    for (int i = q * 64 + lane; i < nzero; i += (int)gridDim.x * 64) zero[i] = 0u;     // the wave-list counters of the scans behind this kernel
     uint16_t* dst = qc + (int64_t)q * dpad;
     float q2 = 0.f, e2 = 0.f, c2 = 0.f;
     for (int i = lane * 4; i < dpad; i += 256) {
@@ -430,7 +432,8 @@ template <int KT> constexpr int q32_lds() { return 4 * Q32Ring<KT>::value * 4096
 // 32 x 32 scores reaches its query's threshold (a.thr; the pre-scan of pass 2, see search_block)
 // MODE 3: the BYTE pre-scan (byte_final_round).  The same ring over the int8 copy: a.xc / a.qc point at bytes, a.dpad counts 2-byte units, so a K-tile is
 // 128 int8 per row and every address below is unchanged; the queries come as two byte planes (a.qc hi, a.qc2 lo: q ~ sq (hi + lo / 254)), two
-// v_mfma_i32_32x32x32_i8 chains give the exact integer dot products Ia, Ib, and the row is marked when sx8[row] (254 Ia + Ib) >= a.thr[query].
+// v_mfma_i32_32x32x32_i8 chains give the exact integer dot products Ia, Ib, and the row's bit in a.bitmap is set when sx8[row] (254 Ia + Ib) >= a.thr[query]
+// for some query.
 // (Integer sums are order-free, so all that matters of the MFMA's k layout is that A and B use the same one: both read 16-byte chunk 2 ks + (lane >> 5).)
 template <class T, int MODE, int KT>
 __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint16_t* __restrict__ xc, const uint16_t* __restrict__ qc, char* smem) {
@@ -556,6 +559,8 @@ __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint1
                     if ((unsigned)mask) bits |= 1u << ro;
                     if ((unsigned)(mask >> 32)) bits |= 1u << (ro + 4);
                 }
+                // fire-and-forget (no returned value: an atomic that returns one would be waited for with vmcnt, i.e. behind the whole ring of K-tiles in
+                // flight — measured: appending the rows to a list from here cost 0.1 ms per 5M-row scan)
                 if (bits && lane == 0) atomicOr(a.bitmap + (m0 >> 5), bits);
             } else {
 #pragma unroll
@@ -746,20 +751,30 @@ __global__ void k_gather_rows(const float* __restrict__ src, const int* __restri
     for (int i = threadIdx.x * 4; i < d; i += blockDim.x * 4) *reinterpret_cast<float4*>(dst + (int64_t)g * d + i) = *reinterpret_cast<const float4*>(s + i);
 }
 
-// bitmap (one bit per row) -> unordered list of the marked rows; *count = its length (the order is irrelevant: the re-rank sorts by (score, row))
-__global__ __launch_bounds__(256) void k_compact_rows(const uint32_t* __restrict__ bitmap, int64_t nwords, uint32_t* __restrict__ rowlist, unsigned int* __restrict__ count) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// bitmap (one bit per row) -> unordered list of the marked rows; *count += its length (the order is irrelevant: the re-rank sorts by (score, row)).
+// One reservation per block of 1024 words (round 5: one per wave serialised ~1500 atomics on one address, 15 us of the 22 this kernel took at 5M rows).
+// CLEAN: every word read is written back as zero, so the bitmap is all-zero again for the next scan without a memset in between.
+template <bool CLEAN>
+__global__ __launch_bounds__(1024) void k_compact_rows(uint32_t* __restrict__ bitmap, int64_t nwords, uint32_t* __restrict__ rowlist, unsigned int* __restrict__ count) {
+    __shared__ unsigned int wsum[16];
+    __shared__ unsigned int bbase;
+    const int64_t w = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     uint32_t bits = w < nwords ? bitmap[w] : 0u;
+    if (CLEAN && bits) bitmap[w] = 0u;
     const unsigned c = __popc(bits);
-    // wave-aggregated reservation: one atomic per wave
     unsigned incl = c;
 #pragma unroll
     for (int dlt = 1; dlt < 64; dlt <<= 1) { const unsigned t = __shfl_up(incl, dlt, 64); if ((int)(threadIdx.x & 63) >= dlt) incl += t; }
-    const unsigned total = __shfl(incl, 63, 64);
-    unsigned base = 0;
-    if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(count, total);
-    base = __shfl(base, 63, 64);
-    unsigned pos = base + incl - c;
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0u;
+        for (int i = 0; i < 16; ++i) { const unsigned t = wsum[i]; wsum[i] = tot; tot += t; }
+        bbase = tot ? atomicAdd(count, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned pos = bbase + wsum[wave] + incl - c;
     while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; rowlist[pos++] = (uint32_t)(w * 32 + b); }
 }
 
@@ -844,7 +859,8 @@ __device__ __forceinline__ uint32_t radix_select_desc(const uint64_t* __restrict
 
 // between rounds: keep the entries with score >= (keep-th best score), publish thr[q] = thr_rank-th best score (thr_rank <= keep).
 // `preset` > 0: the buffer was filled by the direct round with `preset` slots (cnt unused).
-__global__ __launch_bounds__(256) void k_select(uint64_t* __restrict__ cand, int cand_cap, uint32_t* __restrict__ cnt,
+template <int NT>   // threads per block: 256 for blocks of many queries, 1024 for the <= 32-query stream (one block per query: the few blocks are a latency chain)
+__global__ __launch_bounds__(NT) void k_select(uint64_t* __restrict__ cand, int cand_cap, uint32_t* __restrict__ cnt,
                                                 uint32_t* __restrict__ flags, float* __restrict__ thr, int keep, int thr_rank, int preset) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* s = reinterpret_cast<uint64_t*>(smem);
@@ -858,19 +874,19 @@ __global__ __launch_bounds__(256) void k_select(uint64_t* __restrict__ cand, int
     }
     if (m == 0) { if (tid == 0) cnt[q] = 0; return; }
     uint64_t* c = cand + (int64_t)q * cand_cap;
-    for (int i = tid; i < (int)m; i += 256) s[i] = c[i];
+    for (int i = tid; i < (int)m; i += NT) s[i] = c[i];
     if (tid == 0) outc = 0u;
     __syncthreads();
     uint32_t vkeep = 0u;
     if ((int)m >= thr_rank) {
-        const uint32_t vthr = radix_select_desc<256>(s, (int)m, thr_rank, hist, tid);
+        const uint32_t vthr = radix_select_desc<NT>(s, (int)m, thr_rank, hist, tid);
         if (tid == 0) thr[q] = ord_f32(vthr);      // NaN (vthr == 0) compares false everywhere: nothing more is appended, the query ends up flagged
         vkeep = vthr;
     }
-    if ((int)m > keep) vkeep = (keep == thr_rank && (int)m >= thr_rank) ? vkeep : radix_select_desc<256>(s, (int)m, keep, hist, tid);
+    if ((int)m > keep) vkeep = (keep == thr_rank && (int)m >= thr_rank) ? vkeep : radix_select_desc<NT>(s, (int)m, keep, hist, tid);
     else vkeep = 0u;
     // compact: everything with score >= the keep-th best (ties kept; zero keys = padding dropped)
-    for (int i = tid; i < (int)m; i += 256) {
+    for (int i = tid; i < (int)m; i += NT) {
         const uint64_t key = s[i];
         if (key != 0ull && (uint32_t)(key >> 32) >= vkeep) c[atomicAdd(&outc, 1u)] = key;
     }
@@ -1144,9 +1160,11 @@ __global__ __launch_bounds__(256) void k_quant8_rows(const float* __restrict__ x
 // query's two byte planes, eps8, and the mark threshold in units of sx8 * (254 Ia + Ib).  Slots >= nq: zero planes, threshold +inf.
 __global__ __launch_bounds__(256) void k_scan8_prep(const uint64_t* __restrict__ cand, int cand_cap, const uint32_t* __restrict__ cnt, const float* __restrict__ eps16,
                                                     const float* __restrict__ qf, int nq, int d, int dpad8, int k, const float* __restrict__ bounds8,
-                                                    const float* __restrict__ mu8, int8_t* __restrict__ q8, float* __restrict__ thr8) {
+                                                    const float* __restrict__ mu8, int8_t* __restrict__ q8, float* __restrict__ thr8,
+                                                    unsigned int* __restrict__ mark_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[5][4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *mark_count = 0u;          // the list the scan behind this kernel appends to
     uint64_t* s = reinterpret_cast<uint64_t*>(smem);
     unsigned int* hist = reinterpret_cast<unsigned int*>(s + cand_cap);                 // 256 + 4
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1595,6 +1613,7 @@ static int ensure_bitmap(Index* ix) {
     ix->bitmap = nullptr; ix->rowlist = nullptr; ix->bitmap_words = 0;
     KR_HIP(hipMalloc(&ix->bitmap, (words + 1) * sizeof(uint32_t)));
     KR_HIP(hipMalloc(&ix->rowlist, words * 32 * sizeof(uint32_t)));
+    KR_HIP(hipMemset(ix->bitmap, 0, (words + 1) * sizeof(uint32_t)));        // from here on k_compact_rows leaves it all-zero behind every scan
     ix->bitmap_words = words;
     return 0;
 }
@@ -1639,16 +1658,15 @@ static bool ensure_byte_copy(Index* ix, hipStream_t st) {
     return true;
 }
 
-// The final round of a small block through the int8 copy: thresholds + query planes, the marking stream over the round's tile slots, the row list, the
-// 16-bit scores of the listed rows into the candidate buffers.  Enqueue only; the list length stays on the device.
+// The final round of a small block through the int8 copy: thresholds + query planes, the marking stream over the round's tile slots, the row list (the
+// compaction also clears the bits it reads), the 16-bit scores of the listed rows into the candidate buffers.  Enqueue only; the list length stays on the device.
 template <class T>
-static int byte_final_round(Index* ix, const CoarseArgs& a, int nq, int k, hipStream_t st) {
+static int byte_final_round(Index* ix, const CoarseArgs& a, const float* qf, int nq, int k, hipStream_t st) {
     const size_t words = (size_t)((ix->n + 31) / 32);
-    unsigned int* cnt_word = ix->bitmap + words;
-    KR_HIP(hipMemsetAsync(ix->bitmap, 0, (words + 1) * sizeof(uint32_t), st));
+    unsigned int* cnt_word = ix->bitmap + words;                         // (the list-length word behind the bitmap pass 2's marking scan uses)
     const size_t prep_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int);
-    hipLaunchKernelGGL(k_scan8_prep, dim3(32), dim3(256), prep_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->eps, ix->q_f, nq, ix->d, ix->dpad8, k, ix->bounds8, ix->mu8,
-                       ix->q8, ix->thr8);
+    hipLaunchKernelGGL(k_scan8_prep, dim3(32), dim3(256), prep_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->eps, qf, nq, ix->d, ix->dpad8, k, ix->bounds8, ix->mu8,
+                       ix->q8, ix->thr8, cnt_word);
     CoarseArgs m = a;
     m.xc = reinterpret_cast<const uint16_t*>(ix->x8); m.dpad = ix->dpad8 / 2;
     m.qc = reinterpret_cast<const uint16_t*>(ix->q8); m.qc2 = reinterpret_cast<const uint16_t*>(ix->q8 + (size_t)32 * ix->dpad8);
@@ -1659,7 +1677,7 @@ static int byte_final_round(Index* ix, const CoarseArgs& a, int nq, int k, hipSt
         case 4: KR_TRY(launch_scan8_kt<4>(m, ix->num_cu, ix->device, st)); break;
         default: return fail(KR_EINVAL, "no byte pre-scan instance for d = %d", ix->d);
     }
-    hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ix->bitmap, (int64_t)words, ix->rowlist, cnt_word);
+    hipLaunchKernelGGL(k_compact_rows<true>, dim3((unsigned)((words + 1023) / 1024)), dim3(1024), 0, st, ix->bitmap, (int64_t)words, ix->rowlist, cnt_word);
     hipLaunchKernelGGL(k_score_list<T>, dim3(ix->num_cu * 8), dim3(256), (size_t)nq * ix->dpad * sizeof(float), st, ix->xc, ix->dpad, ix->q_c, nq, ix->rowlist, cnt_word,
                        ix->thr, ix->cnt, ix->cand, ix->cand_cap);
     KR_HIP(hipGetLastError());
@@ -1723,18 +1741,30 @@ static int run_rounds(Index* ix, CoarseArgs& a, int64_t n_rows, int nq, int bm, 
         } else {
             step = done * growth;
         }
-        hipLaunchKernelGGL(k_select, dim3(nq), dim3(256), sel_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, K1, rank, preset);
+        if (nq <= 32) hipLaunchKernelGGL(k_select<1024>, dim3(nq), dim3(1024), sel_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, K1, rank, preset);
+        else hipLaunchKernelGGL(k_select<256>, dim3(nq), dim3(256), sel_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, K1, rank, preset);
     }
     rounds = round;
     return 0;
 }
 
+// device-usable aliases of a small call's own query / result buffers (device memory of this GPU or pinned host memory): the kernels then read the queries
+// and write the results in place — no staging copy through the workspace (three ~10-us copy kernels per one-query search).  All null: the staged path.
+struct DirectIO { const float* q = nullptr; float* scores = nullptr; int64_t* rows = nullptr; };
+static const void* device_alias(const void* p, int device) {
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (a.type == hipMemoryTypeDevice) return a.device == device ? p : nullptr;
+    if (a.type == hipMemoryTypeHost) return a.devicePointer;          // pinned: mapped into the device's address space
+    return nullptr;
+}
+
 static int launch_rerank(Index* ix, int nq, int k, int rmax, int final_preset, const float* qf, const int* qmap, float* theta_out, hipStream_t st,
-                         const float* theta_ext = nullptr) {
+                         const float* theta_ext = nullptr, float* out_s = nullptr, int64_t* out_r = nullptr) {
     const size_t rer_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + (size_t)rmax * sizeof(uint64_t) + 264 * sizeof(unsigned int);
     auto rerank = ix->d <= 1024 ? &k_rerank<4> : ix->d <= 2048 ? &k_rerank<8> : &k_rerank<16>;   // row steps held in registers
     hipLaunchKernelGGL(rerank, dim3(nq), dim3(256), rer_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->flags, ix->thr, ix->eps, qf, ix->xf, ix->d, k,
-                       final_preset, rmax, ix->out_s, ix->out_r, ix->nrer, qmap, ix->force_exact, theta_out, theta_ext);
+                       final_preset, rmax, out_s ? out_s : ix->out_s, out_r ? out_r : ix->out_r, ix->nrer, qmap, ix->force_exact, theta_out, theta_ext);
     KR_HIP(hipGetLastError());
     return 0;
 }
@@ -1776,7 +1806,8 @@ static BlockPlan plan_block(const Index* ix, int nq, int k, bool byte_block = fa
 static int search_attrs(Index* ix) {
     static DevOnce sel_once;
     return once_per_device(sel_once, ix->device, [&]() -> int {   // cap = 8192 needs 64 KiB + of dynamic LDS
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_local_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan8_prep), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 264 * 4));
         KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_global_theta), hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_MAX * 8 + 264 * 4));
@@ -1803,20 +1834,23 @@ static void fill_args(const Index* ix, CoarseArgs& a) {
 // the list-overflow word go to the block's status record in pinned memory, the (optimistic) results straight into the caller's buffers; nothing here waits
 // for the device.  kr_index_search_finish reads the status records and re-answers the flagged queries (slow_passes).
 static int pass1_rerank(Index* ix, int nq, int k, int rmax, int final_preset, float* scores, int64_t* rows, int blk, hipStream_t st, uint32_t* status,
-                        const float* theta_ext, bool byte_used);
+                        const float* theta_ext, bool byte_used, const DirectIO& dio = DirectIO{});
 template <class T>
-static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipStream_t st, int& rounds, int& final_preset, int& rmax, bool& byte_used);
+static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipStream_t st, int& rounds, int& final_preset, int& rmax, bool& byte_used,
+                        const float* q_direct = nullptr);
 template <class T>
-static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int blk, hipStream_t st, int& rounds, uint32_t* status) {
+static int pass1_enqueue(Index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int blk, hipStream_t st, int& rounds, uint32_t* status,
+                         const DirectIO& dio = DirectIO{}) {
     int final_preset = 0, rmax = 0;
     bool byte_used = false;
-    KR_TRY(pass1_coarse<T>(ix, q, nq, k, blk, st, rounds, final_preset, rmax, byte_used));
-    return pass1_rerank(ix, nq, k, rmax, final_preset, scores, rows, blk, st, status, nullptr, byte_used);
+    KR_TRY(pass1_coarse<T>(ix, q, nq, k, blk, st, rounds, final_preset, rmax, byte_used, dio.q));
+    return pass1_rerank(ix, nq, k, rmax, final_preset, scores, rows, blk, st, status, nullptr, byte_used, dio);
 }
 
 // first half: queries -> 16-bit copy + bounds, the coarse rounds; leaves the candidate buffers of the block in the workspace
 template <class T>
-static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipStream_t st, int& rounds, int& final_preset, int& rmax, bool& byte_used) {
+static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipStream_t st, int& rounds, int& final_preset, int& rmax, bool& byte_used,
+                        const float* q_direct) {
     // small block on a large index: the final round goes through the int8 copy (byte_final_round)
     bool byte_ok = plan_block(ix, nq, k).q32 && nq <= BYTE_NQ_MAX && !ix->byte_off && g_byte_prescan.load() != 0 && ix->n >= (int64_t)g_byte_min_rows.load() && byte_dim_ok(ix->d);
     if (byte_ok && ix->byte_pause > 0) { --ix->byte_pause; byte_ok = false; }
@@ -1827,13 +1861,13 @@ static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipSt
     byte_used = false;
     KR_TRY(ensure_ws(ix, k, p.cap));
     KR_TRY(search_attrs(ix));
-    KR_HIP(hipMemcpyAsync(ix->q_f, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyDefault, st));
+    if (!q_direct) KR_HIP(hipMemcpyAsync(ix->q_f, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyDefault, st));
+    const float* const qsrc = q_direct ? q_direct : ix->q_f;
     CoarseArgs a; fill_args(ix, a);
     const size_t blk_cnt_bytes = ((size_t)ix->num_cu * ShapeC::NWAVE + 4) * sizeof(unsigned int);
-    hipLaunchKernelGGL(k_prep_queries<T>, dim3(p.nq_pad), dim3(64), 0, st, ix->q_f, ix->q_c, nq, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr,
-                       ix->cnt, ix->flags);
+    hipLaunchKernelGGL(k_prep_queries<T>, dim3(p.nq_pad), dim3(64), 0, st, qsrc, ix->q_c, nq, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr,
+                       ix->cnt, ix->flags, ix->blk_cnt, (int)(blk_cnt_bytes / sizeof(unsigned int)));
     a.nq_pad = p.nq_pad; a.nq = nq;
-    KR_HIP(hipMemsetAsync(ix->blk_cnt, 0, blk_cnt_bytes, st));
     const int bm = p.q32 ? 32 : p.smallq ? ShapeSplit::BM : ShapeC::BM;
     const int lds = p.smallq ? COARSE_LDS_SMALLQ : COARSE_LDS;
     static DevOnce coarse_once;
@@ -1846,7 +1880,7 @@ static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipSt
     }));
     final_preset = 0;
     rounds = 0;
-    const std::function<int(const CoarseArgs&)> byte_round = [&](const CoarseArgs& ca) -> int { return byte_final_round<T>(ix, ca, nq, k, st); };
+    const std::function<int(const CoarseArgs&)> byte_round = [&](const CoarseArgs& ca) -> int { return byte_final_round<T>(ix, ca, qsrc, nq, k, st); };
     KR_TRY(run_rounds(ix, a, ix->n, nq, bm, p.K1, p.cap, st, blk < TIMED_BLOCKS ? ix->evc + blk * 32 : nullptr, [&](const CoarseArgs& ca) -> int {
         if (p.q32) return launch_q32<T>(ca, p.kt64, ix->num_cu, ix->device, st);
         if (p.smallq) {
@@ -1862,14 +1896,17 @@ static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipSt
 
 // second half: exactness certificate + exact re-rank of the candidates, status records and results on their way to the caller
 static int pass1_rerank(Index* ix, int nq, int k, int rmax, int final_preset, float* scores, int64_t* rows, int blk, hipStream_t st, uint32_t* status,
-                        const float* theta_ext, bool byte_used) {
-    KR_TRY(launch_rerank(ix, nq, k, rmax, final_preset, ix->q_f, nullptr, blk < THETA_BLOCKS ? ix->theta1 + (size_t)blk * QBLK : nullptr, st, theta_ext));
+                        const float* theta_ext, bool byte_used, const DirectIO& dio) {
+    KR_TRY(launch_rerank(ix, nq, k, rmax, final_preset, dio.q ? dio.q : ix->q_f, nullptr, blk < THETA_BLOCKS ? ix->theta1 + (size_t)blk * QBLK : nullptr, st, theta_ext,
+                         dio.scores, dio.rows));
     uint32_t* rec = status + (size_t)blk * STATUS_STRIDE;
     hipLaunchKernelGGL(k_status_pack, dim3((nq + 255) / 256), dim3(256), 0, st, ix->flags, ix->nrer, ix->blk_cnt + ix->num_cu * ShapeC::NWAVE,
                        byte_used ? ix->bitmap + (size_t)((ix->n + 31) / 32) : nullptr, ix->bounds8, nq, rec);
     KR_HIP(hipGetLastError());
-    KR_HIP(hipMemcpyAsync(scores, ix->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
-    KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
+    if (!dio.scores) {
+        KR_HIP(hipMemcpyAsync(scores, ix->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDefault, st));
+        KR_HIP(hipMemcpyAsync(rows, ix->out_r, (size_t)nq * k * sizeof(int64_t), hipMemcpyDefault, st));
+    }
     return 0;
 }
 
@@ -1933,7 +1970,7 @@ static int slow_passes(Index* ix, const float* q, int nq, int k, float* scores, 
                 m.ntiles = (ix->n + 31) / 32; m.perm_mul = 1; m.tile_begin = 0; m.tile_count = m.ntiles;
                 KR_TRY((launch_q32<T>(m, kt64, ix->num_cu, ix->device, st)));
                 unsigned int* cnt_word = ix->bitmap + words;
-                hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ix->bitmap, (int64_t)words, ix->rowlist, cnt_word);
+                hipLaunchKernelGGL(k_compact_rows<true>, dim3((unsigned)((words + 1023) / 1024)), dim3(1024), 0, st, ix->bitmap, (int64_t)words, ix->rowlist, cnt_word);
                 KR_HIP(hipMemcpyAsync(hs + 3 * QBLK + 8, cnt_word, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
                 KR_HIP(hipStreamSynchronize(st));                 // the row count sizes the rounds of this group (pass 2 is the rare path)
                 const int64_t marked = (int64_t)hs[3 * QBLK + 8];
@@ -2011,13 +2048,23 @@ static int begin_search(Index* ix, const float* q, int nq, int k, float* scores,
     KR_HIP(hipEventRecord(ix->ev[0], st));
     pd.active = true;      // from here on finish_one() has something to wait for, also when a later block fails to enqueue
     ++ix->pend_n;
+    // a small call (the latency-bound case) whose buffers the device can address works in place
+    DirectIO dio;
+    pd.direct_io = false;
+    if (nq <= 32) {
+        dio.q = static_cast<const float*>(device_alias(q, ix->device));
+        dio.scores = static_cast<float*>(const_cast<void*>(device_alias(scores, ix->device)));
+        dio.rows = static_cast<int64_t*>(const_cast<void*>(device_alias(rows, ix->device)));
+        if (!dio.q || !dio.scores || !dio.rows) dio = DirectIO{};
+        pd.direct_io = dio.q != nullptr;
+    }
     for (int b = 0; b < nblocks; ++b) {
         const int nb = std::min(QBLK, nq - b * QBLK);
         const float* qb = q + (size_t)b * QBLK * ix->d;
         float* sb = scores + (size_t)b * QBLK * k; int64_t* rb = rows + (size_t)b * QBLK * k;
         int rc;
-        if (ix->coarse == KR_COARSE_BF16) rc = pass1_enqueue<BF16>(ix, qb, nb, k, sb, rb, b, st, pd.rounds[b], pd.status);
-        else rc = pass1_enqueue<F16>(ix, qb, nb, k, sb, rb, b, st, pd.rounds[b], pd.status);
+        if (ix->coarse == KR_COARSE_BF16) rc = pass1_enqueue<BF16>(ix, qb, nb, k, sb, rb, b, st, pd.rounds[b], pd.status, dio);
+        else rc = pass1_enqueue<F16>(ix, qb, nb, k, sb, rb, b, st, pd.rounds[b], pd.status, dio);
         if (rc) { (void)hipStreamSynchronize(st); pd.active = false; --ix->pend_n; return rc; }
     }
     KR_HIP(hipEventRecord(ix->ev[3], st));
@@ -2070,7 +2117,7 @@ static int finish_one(Index* ix, int64_t* flagged_out) {
             const int tb = newest ? b : THETA_BLOCKS;     // an older call's theta1 has been overwritten: pass 2 without the pre-scan
             // ... and so have its queries and pass-1 results in the workspace (by a later call's pass 1, or by the slow passes of an older call that was
             // finished just before this one): copied in again
-            const bool restore = nblocks > 1 || ix->ws_owner != pd.seq;
+            const bool restore = nblocks > 1 || ix->ws_owner != pd.seq || pd.direct_io;
             ix->ws_owner = pd.seq;
             int rc;
             if (ix->coarse == KR_COARSE_BF16) rc = slow_passes<BF16>(ix, qb, nb, pd.k, sb, rb, tb, pd.st, hflags, true, true, restore);
@@ -2107,6 +2154,7 @@ static int begin_search_coarse(Index* ix, const float* q, int nq, int k, float* 
     Index::Pending& pd = ix->pend[(ix->pend_head + ix->pend_n) % Index::PEND_MAX];
     KR_TRY(ensure_slot_status(pd, 1));
     pd.q = q; pd.nq = nq; pd.k = k; pd.scores = nullptr; pd.rows = nullptr; pd.st = st; pd.rounds.assign(1, 0);
+    pd.direct_io = false;
     pd.seq = ++ix->call_seq;
     ix->ws_owner = pd.seq;
     { int K1, cap, rmax; plan_buffers(k, K1, cap, rmax); KR_TRY(ensure_ws(ix, k, cap)); }

@@ -105,11 +105,38 @@ class FlatIPIndex:
         if not 0 < k <= self.ntotal:
             raise ValueError(f"top_docs={k} must satisfy 0 < k <= ntotal={self.ntotal}")
         nq = int(q.shape[0])
+        p, keep = self._ptr(q)
+        pin = self._small_out(nq, k) if mode == 0 else None
+        if pin is not None:
+            # a small call (the KiRAG loop's 1-2 queries per hop): results land in a pinned scratch the device writes directly (ABI 8: the library works
+            # in place when it can address the caller's buffers) instead of going through a staged copy into pageable memory
+            ps, pr, pq = pin
+            if isinstance(q, np.ndarray):                       # host queries: through the pinned query scratch (4 KiB per query) for the same reason
+                pq[: nq * self.d].numpy()[:] = q.reshape(-1)
+                p = int(pq.data_ptr())
+            _lib.check(self._lib.kr_index_search(self._h, p, nq, k, int(ps.data_ptr()), int(pr.data_ptr()), 0, self._stream(q)))
+            return ps[: nq * k].numpy().reshape(nq, k).copy(), pr[: nq * k].numpy().reshape(nq, k).copy()
         scores = np.empty((nq, k), np.float32)
         rows = np.empty((nq, k), np.int64)
-        p, keep = self._ptr(q)
         _lib.check(self._lib.kr_index_search(self._h, p, nq, k, scores.ctypes.data, rows.ctypes.data, int(mode), self._stream(q)))
         return scores, rows
+
+    def _small_out(self, nq: int, k: int):
+        """pinned result scratch for calls of at most 32 queries x 1024 hits (None: larger call, or no torch / no GPU to pin for)"""
+        if nq > 32 or nq * k > 32 * 1024:
+            return None
+        pin = getattr(self, "_pin_out", None)
+        if pin is None:
+            try:
+                import torch
+                if not torch.cuda.is_available():
+                    raise RuntimeError
+                pin = (torch.empty(32 * 1024, dtype=torch.float32, pin_memory=True), torch.empty(32 * 1024, dtype=torch.int64, pin_memory=True),
+                       torch.empty(32 * self.d, dtype=torch.float32, pin_memory=True))
+            except Exception:
+                pin = False
+            self._pin_out = pin
+        return pin or None
 
     def search_into(self, q, k: int, scores_out, rows_out, mode: int = 0) -> None:
         """Same as ``search`` but writes into caller-provided torch tensors (host or device):
