@@ -300,6 +300,8 @@ class Indexer(object):
         self.index.add(embeddings)
         logger.info(f'Total data indexed {len(self.index_id_to_db_id)}')
 
+    accepts_device_queries = True      # search_knn takes a torch tensor on the index's GPU as it takes a numpy array (DenseRetriever.batch_retrieve)
+
     def search_knn(self, query_vectors, top_docs: int, index_batch_size=1024, verbose: bool = True) -> List[Tuple[List[object], List[float]]]:
         """index.py:36-53, pipelined: the reference's loop searches a block, THEN builds its id strings, THEN starts the next block — the string pass
         costs as much host time as the GPU's whole search of the block.  Here block i + 1 is enqueued (``kr_index_search_async``, results into pinned

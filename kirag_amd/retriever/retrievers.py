@@ -155,7 +155,7 @@ class DenseRetriever(nn.Module):
             return documents
         raise ValueError(f"{type(docid_list)} is not a supported type for \"docid_list\"!")
 
-    def _embed(self, texts: List[str], which: str, max_length, verbose: bool, **kwargs) -> Tensor:
+    def _embed(self, texts: List[str], which: str, max_length, verbose: bool, on_device: bool = False, **kwargs) -> Tensor:
         assert isinstance(texts, list) and len(texts) > 0   # must provide queries / documents
         encode = self.collator.encode_query if which == "query" else self.collator.encode_doc
         embed = self.retriever.query if which == "query" else self.retriever.doc
@@ -163,11 +163,17 @@ class DenseRetriever(nn.Module):
         for s in range(0, len(texts), self.encode_batch_size):
             inputs = to_device(encode(texts[s:s + self.encode_batch_size], max_length=max_length, **kwargs), self.device)
             chunks.append(embed(inputs).detach())
-        out = torch.cat(chunks, dim=0).cpu()
+        out = chunks[0] if len(chunks) == 1 else torch.cat(chunks, dim=0)
+        if on_device and out.is_cuda:
+            return out                                      # batch_retrieve: the search reads the embeddings where they are; _check_inputs() follows it
+        out = out.cpu()
+        self._check_inputs()
+        return out
+
+    def _check_inputs(self) -> None:
         hip = getattr(getattr(self.retriever, "encoder", None), "_hip", None)
         if hip is not None:
             hip.check()                                     # deferred input errors (token ids outside the vocabulary, token_type_ids != 0) surface here
-        return out
 
     def calculate_query_embeddings(self, queries: List[str], max_length: int = None, verbose: bool = False, **kwargs) -> Tensor:
         return self._embed(queries, "query", max_length, verbose, **kwargs)
@@ -190,6 +196,16 @@ class DenseRetriever(nn.Module):
         return results
 
     def batch_retrieve(self, queries: List[str], topk: int, verbose: bool = False, **kwargs) -> List[dict]:
+        # (retrievers.py:198-199 goes embeddings -> .cpu().numpy() -> faiss.)  With the index resident on the encoder's own GPU the embeddings stay where the
+        # encoder wrote them: one device round trip per hop less; same fp32 values, same results.
+        if getattr(self.indexer, "accepts_device_queries", False):
+            max_length = kwargs.pop("max_length", None)
+            q = self._embed(queries, "query", max_length, verbose, on_device=True, **kwargs)
+            if not q.is_cuda:
+                q = q.numpy()
+            knn = self.indexer.search_knn(query_vectors=q, top_docs=topk, index_batch_size=1024, verbose=verbose)
+            self._check_inputs()
+            return self.parse_indexer_output(knn)
         q = self.calculate_query_embeddings(queries=queries, verbose=verbose, **kwargs).numpy()
         knn = self.indexer.search_knn(query_vectors=q, top_docs=topk, index_batch_size=1024, verbose=verbose)
         return self.parse_indexer_output(knn)
