@@ -172,6 +172,24 @@ def latency_block(args, encoder, index, dev):
         if i >= 3:
             hops.append((time.perf_counter() - t0) * 1e3)
     out["kirag_hop_nq1"] = {"ms": float(np.median(hops)), "what": f"encode 1 x 256 tokens + exact top-{k} over {index.ntotal} resident rows, results in pinned host memory"}
+    # the search half of the hop alone, with and without the int8 final round of small blocks (kr_set_option "byte_prescan"): same rows, same scores
+    from kirag_amd import _lib as L
+    qv = encoder.forward(ids, mask, 0)
+    alone = {}
+    for name, on in (("search_16bit_final_round_ms", 0), ("search_ms", 1)):
+        L.check(L.load().kr_set_option(b"byte_prescan", on))
+        ts = []
+        for i in range(23):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            index.search_async(qv, k, sc, rw); index.finish()
+            if i >= 3:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        alone[name] = float(np.median(ts))
+        alone["rows_" + name[:-3]] = rw.clone().numpy().tolist()[0]
+    st = index.stats()
+    out["kirag_hop_nq1"].update({"search_ms": alone["search_ms"], "search_16bit_final_round_ms": alone["search_16bit_final_round_ms"],
+                                 "same_rows_either_way": alone["rows_search"] == alone["rows_search_16bit_final_round"],
+                                 "byte_scans": int(st.get("byte_scans", 0)), "byte_marked_rows_per_scan": (st.get("byte_marked_rows", 0) / max(1, st.get("byte_scans", 0)))})
     # the same 1 x 32 forward through the reference's own surface: E5Encoder.forward (retriever/encoders.py:67-77) of an nn.Module with the e5-large shape —
     # what BaseRetriever.query / the e5.py helpers call; one forward at a time (forward + wait), which is how a hop uses it
     from transformers import BertConfig

@@ -30,6 +30,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.kr_abi_version() == _lib.ABI_VERSION == 8
 
 
+def test_search_stats_struct_and_options_mirror_the_header():
+    """ABI 8: the ctypes mirror of kr_search_stats has the header's fields in the header's order (two new ones at the end: the byte pre-scan of small
+    query blocks), every option name the header documents is accepted, an unknown one is KR_EINVAL."""
+    hdr = open(os.path.join(REPO, "include", "kirag_amd.h")).read()
+    end = hdr.index("} kr_search_stats;")
+    body = hdr[hdr.rindex("typedef struct {", 0, end):end]
+    fields = re.findall(r"^\s*(?:int64_t|double)\s+([a-z0-9_]+)\s*;", body, flags=re.M)
+    assert fields == [f for f, _ in _lib.SearchStats._fields_] and fields[-2:] == ["byte_scans", "byte_marked_rows"]
+    assert C.sizeof(_lib.SearchStats) == 8 * len(fields)
+    lib = _lib.load()
+    for name, back in ((b"byte_prescan", 1), (b"debug_byte_min_rows", -1), (b"force_exact_scores", 0)):
+        assert name.decode() in hdr
+        assert lib.kr_set_option(name, 0) == 0 and lib.kr_set_option(name, back) == 0
+    assert lib.kr_set_option(b"no_such_option", 1) == -22
+
+
 @pytest.mark.skipif(not NO_GPU, reason="checks the no-GPU failure mode")
 def test_compute_calls_fail_loudly_without_gpu():
     lib = _lib.load()
