@@ -36,6 +36,9 @@ for nq in (1, 2):
     ms_t, tv = timed(lambda: enc.forward(t_ids, t_mask, 0))
     ms_r, _ = timed(lambda: rank_by_similarity(qv, tv, 20))
     ms_s, _ = timed(lambda: ix.search(qv, 10))
-    st = ix.stats()
+    st = ix.stats(reset=True)
+    byte = st.get("byte_scans", 0) > 0          # the final coarse round streamed the int8 copy (1 KiB per row) instead of the 16-bit one (2 KiB)
+    streamed = total * (1024 if byte else 2048)
     print(f"nq={nq}: encode queries {ms_q:.2f} ms | encode 512 triples {ms_t:.2f} ms (first turn only with the cache) | rank top-20 {ms_r:.2f} ms | "
-          f"search top-10 over {total} rows {ms_s:.2f} ms (coarse {st['last_coarse_ms']:.2f} ms = {total * 2048 / st['last_coarse_ms'] / 1e9:.2f} TB/s of corpus bytes)")
+          f"search top-10 over {total} rows {ms_s:.2f} ms (coarse {st['last_coarse_ms']:.2f} ms = {streamed / st['last_coarse_ms'] / 1e9:.2f} TB/s of the "
+          f"{'int8' if byte else '16-bit'} copy's bytes{', %d rows marked per search' % (st['byte_marked_rows'] // max(1, st['byte_scans'])) if byte else ''})")
