@@ -1229,6 +1229,9 @@ __global__ __launch_bounds__(256) void k_scan8_prep(const uint64_t* __restrict__
         // q.x = q.mu + u.r;  |u.r - u^.r^| <= |u| dx + |u - u^| |r^|;  q.mu in fp32: any order of <= d additions, <= (d + 2) 2^-24 sum |q_i mu_i|;
         // the device's arithmetic on the byte score (one fma rounding, the scale product, the threshold's own scaling): <= 4 x 2^-23 relative
         float e8 = un * dx + du * rn + 4.8e-7f * un * rn + (float)(d + 2) * 6.0e-8f * qma * 1.01f;
+        // + the three fp32 subtractions that form theta below, and a few ulps of distance from the canonical (fp32-rounded) scores of the k rows the bound
+        // rests on: an unmarked row must not even TIE with them (a tie would be decided by the row index)
+        e8 += 1e-6f * (fabsf(kth) + fabsf(qm) + eps16[q]);
         e8 = e8 * 1.001f + 1e-30f;
         const float theta = kth - eps16[q] - e8 - qm;                      // bound on the byte score u^.r^ of a row that can still matter
         const bool usable = (fabsf(theta) <= 3.4028235e38f) && sq > 0.f && (sq <= 3.4028235e38f) && reinterpret_cast<const unsigned int*>(bounds8)[1] == 0u;

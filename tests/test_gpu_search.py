@@ -715,6 +715,43 @@ def test_byte_prescan_small_corpora_vs_canonical(byte_everywhere, n, d, nq, k):
     assert st0["byte_scans"] == 0 and np.array_equal(i0, i) and np.array_equal(s0.view(np.uint32), s.view(np.uint32))
 
 
+def test_byte_prescan_f16_coarse_copy_and_row_shards_in_split_form(byte_everywhere):
+    """The f16 flavour of the 16-bit copy behind the byte round (k_score_list<F16>), and the split row-sharded search (coarse half -> gathered coarse scores ->
+    global bound -> re-rank half) with the byte round inside each shard's coarse half: merged lists = the canonical answer."""
+    import torch
+    from kirag_amd import _lib
+    from kirag_amd.retriever.index import FlatIPIndex
+    rng = np.random.default_rng(4242)
+    n, d, nq, k = 36000, 1024, 3, 10
+    x = _unit(rng, n, d)
+    q, pick = _queries_near(rng, x, nq)
+    so, io = S.search_canonical(q, x, k)
+    ix = _mk(d, x, coarse_dtype="f16")
+    s, i = ix.index.search(q, k)
+    st = ix.index.stats(reset=True)
+    assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32)) and st["byte_scans"] == 1, st
+    cuts = [0, 15000, n]
+    shards = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        sh = FlatIPIndex(d, device=0); sh.add(x[a:b]); shards.append((sh, a))
+    qd = torch.from_numpy(q).cuda()
+    tks = [torch.empty((nq, k + 1), dtype=torch.float32, device="cuda") for _ in shards]
+    for (sh, a), tk in zip(shards, tks):
+        sh.search_coarse_async(qd, k, tk)
+    gathered = torch.cat(tks, dim=0).contiguous()
+    sc_all, id_all = [], []
+    for (sh, a) in shards:
+        th = torch.empty((nq,), dtype=torch.float32, device="cuda")
+        sc = torch.empty((nq, k), dtype=torch.float32, device="cuda"); rw = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        sh.search_global_theta(gathered, len(shards), th); sh.search_rerank_async(th, sc, rw); sh.finish()
+        assert sh.stats()["byte_scans"] == 1
+        r_ = rw.cpu().numpy(); sc_all.append(sc.cpu().numpy()); id_all.append(np.where(r_ >= 0, r_ + a, -1))
+    ms = np.empty((nq, k), np.float32); mi = np.empty((nq, k), np.int64)
+    sc_st, id_st = np.ascontiguousarray(np.stack(sc_all)), np.ascontiguousarray(np.stack(id_all))      # named: they must outlive the call
+    _lib.check(_lib.load().kr_topk_merge(sc_st.ctypes.data, id_st.ctypes.data, len(shards), nq, k, ms.ctypes.data, mi.ctypes.data))
+    assert np.array_equal(mi, io) and np.array_equal(ms.view(np.uint32), so.view(np.uint32))
+
+
 def test_byte_prescan_rows_added_later_and_anisotropic_rows(byte_everywhere):
     """The int8 copy is derived data: rows added after the first search extend it (same centre and axis weights), a growth beyond its capacity rebuilds
     it; rows with a common direction and a few large-variance axes (what the centre / weights exist for) stay exact and mark few rows."""
