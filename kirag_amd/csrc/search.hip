@@ -123,6 +123,7 @@ struct Index {
     float* thr_mark = nullptr; // [32] the same, compacted for the group being pre-scanned
     uint32_t* bitmap = nullptr; size_t bitmap_words = 0;   // one bit per row (+ one word: the list length) — pass 2 pre-scan
     uint32_t* rowlist = nullptr;                           // the marked rows, compacted
+    uint32_t* qmask = nullptr;                             // byte pre-scan: per row, the queries of the block that marked it (all-zero between searches)
     // byte pre-scan of small query blocks (see byte_final_round): an int8 copy of the rows with one scale per row.  A DERIVED structure: built lazily from
     // xf by the first small-block search (ensure_byte_copy), extended behind later adds, never part of the growth machinery above
     int8_t* x8 = nullptr;      // [cap8, dpad8]
@@ -271,6 +272,7 @@ struct CoarseArgs {
     uint32_t* bitmap;                          // one bit per ROW, set by the marking scan (k_coarse_q32 MODE 2)
     const uint32_t* rowlist; int64_t nlist;    // k_fine: scan rows rowlist[0 .. nlist) instead of 0 .. n (nullptr: every row)
     const uint16_t* qc2; const float* sx8;     // byte pre-scan (k_coarse_q32 MODE 3): second byte plane of the queries, row scales
+    uint32_t* qmask;                           // ... and per row the set of queries that marked it
 };
 
 // persistent streaming coarse scan (gemm_nt_pingpong): grid = one block per CU, so nothing else on the CU hides an epilogue
@@ -556,8 +558,9 @@ __device__ __forceinline__ void coarse_q32_body(const CoarseArgs& a, const uint1
                     const float sc = sr * fmaf(254.f, (float)ia[r], (float)ib[r]);
                     const unsigned long long mask = __ballot(sc >= thr);
                     const int ro = (r & 3) + 8 * (r >> 2);
-                    if ((unsigned)mask) bits |= 1u << ro;
-                    if ((unsigned)(mask >> 32)) bits |= 1u << (ro + 4);
+                    const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);      // the queries (lanes 0..31) that want row ro / row ro + 4
+                    if (lo) { bits |= 1u << ro; if (lane == 0) atomicOr(a.qmask + m0 + ro, lo); }
+                    if (hi) { bits |= 1u << (ro + 4); if (lane == 0) atomicOr(a.qmask + m0 + ro + 4, hi); }
                 }
                 // fire-and-forget (no returned value: an atomic that returns one would be waited for with vmcnt, i.e. behind the whole ring of K-tiles in
                 // flight — measured: appending the rows to a list from here cost 0.1 ms per 5M-row scan)
@@ -1241,56 +1244,60 @@ __global__ __launch_bounds__(256) void k_scan8_prep(const uint64_t* __restrict__
     }
 }
 
-// 16-bit scores of the marked rows for the block's queries -> candidate buffers (what the final round of the 16-bit scan does for the rows it streams).
-// One wave per listed row and step; the queries' 16-bit copies sit in LDS as fp32.  The sum order differs from the MFMA chain's; eps16 covers any order of
-// at most dpad fp32 additions (k_prep_queries: 1.1 dpad 2^-24 |qc| |xc|; here 16 sequential + 6 tree steps).
+// 16-bit scores of the marked rows, each for the queries that marked it (qmask[row], cleared on the way) -> candidate buffers: what the final round of the
+// 16-bit scan does for the rows it streams.  One wave per listed row and step, the next row and its mask requested before the current one is scored; the
+// queries' 16-bit copies sit in LDS.  The sum order differs from the MFMA chain's; eps16 covers any order of at most dpad fp32 additions (k_prep_queries:
+// 1.1 dpad 2^-24 |qc| |xc|; here 16 sequential + 6 tree steps).  dpad <= 1024.
 template <class T>
-__global__ __launch_bounds__(256) void k_score_list(const uint16_t* __restrict__ xc, int dpad, const uint16_t* __restrict__ qc, int nq,
-                                                    const uint32_t* __restrict__ rowlist, const unsigned int* __restrict__ count,
-                                                    const float* __restrict__ thr, uint32_t* __restrict__ cnt, uint64_t* __restrict__ cand, int cand_cap) {
+__global__ __launch_bounds__(1024) void k_score_list(const uint16_t* __restrict__ xc, int dpad, const uint16_t* __restrict__ qc, int nq,
+                                                     const uint32_t* __restrict__ rowlist, const unsigned int* __restrict__ count, uint32_t* __restrict__ qmask,
+                                                     const float* __restrict__ thr, uint32_t* __restrict__ cnt, uint64_t* __restrict__ cand, int cand_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* qs = reinterpret_cast<float*>(smem);                           // [nq][dpad]
+    uint16_t* qs = reinterpret_cast<uint16_t*>(smem);                     // [nq][dpad]
     const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned wpb = blockDim.x >> 6;                                 // waves per block
     const unsigned n = *count;
-    const unsigned W = gridDim.x * 4u;
-    unsigned i = blockIdx.x * 4u + (unsigned)(tid >> 6);
-    if (blockIdx.x * 4u >= n) return;                                     // (block-uniform) nothing for this block: skip the query load too
-    for (int j = tid; j < nq * dpad; j += 256) qs[j] = T::to_f32(qc[j]);
+    const unsigned W = gridDim.x * wpb;
+    unsigned i = blockIdx.x * wpb + (unsigned)(tid >> 6);
+    if (blockIdx.x * wpb >= n) return;                                    // (block-uniform) nothing for this block: skip the query load too
+    for (int j = tid * 8; j < nq * dpad; j += (int)blockDim.x * 8) *reinterpret_cast<uint4*>(qs + j) = *reinterpret_cast<const uint4*>(qc + j);
     __syncthreads();
-    // dpad <= 1024: a lane holds 8 consecutive elements of each 512-element half; the NEXT row is requested before this one is scored
+    // a lane holds 8 consecutive elements of each 512-element half of the row
     uint4 cur[2], nxt[2];
-    uint32_t row = 0u, nrow = 0u;
+    uint32_t row = 0u, nrow = 0u, m = 0u, nm = 0u;
     auto load = [&](uint4 (&r)[2], uint32_t rw) {
         const uint16_t* xr = xc + (int64_t)rw * dpad + lane * 8;
         r[0] = (lane * 8 < dpad) ? *reinterpret_cast<const uint4*>(xr) : make_uint4(0u, 0u, 0u, 0u);
         r[1] = (lane * 8 + 512 < dpad) ? *reinterpret_cast<const uint4*>(xr + 512) : make_uint4(0u, 0u, 0u, 0u);
     };
-    if (i < n) { row = rowlist[i]; load(cur, row); }
+    auto dot8 = [&](const uint4& v, const uint16_t* qq, float acc) -> float {
+        const uint4 u = *reinterpret_cast<const uint4*>(qq);
+        acc = fmaf(T::to_f32((uint16_t)(v.x & 0xffffu)), T::to_f32((uint16_t)(u.x & 0xffffu)), acc); acc = fmaf(T::to_f32((uint16_t)(v.x >> 16)), T::to_f32((uint16_t)(u.x >> 16)), acc);
+        acc = fmaf(T::to_f32((uint16_t)(v.y & 0xffffu)), T::to_f32((uint16_t)(u.y & 0xffffu)), acc); acc = fmaf(T::to_f32((uint16_t)(v.y >> 16)), T::to_f32((uint16_t)(u.y >> 16)), acc);
+        acc = fmaf(T::to_f32((uint16_t)(v.z & 0xffffu)), T::to_f32((uint16_t)(u.z & 0xffffu)), acc); acc = fmaf(T::to_f32((uint16_t)(v.z >> 16)), T::to_f32((uint16_t)(u.z >> 16)), acc);
+        acc = fmaf(T::to_f32((uint16_t)(v.w & 0xffffu)), T::to_f32((uint16_t)(u.w & 0xffffu)), acc); acc = fmaf(T::to_f32((uint16_t)(v.w >> 16)), T::to_f32((uint16_t)(u.w >> 16)), acc);
+        return acc;
+    };
+    if (i < n) { row = rowlist[i]; m = qmask[row]; load(cur, row); }
     for (; i < n; i += W) {
         const bool more = i + W < n;
-        if (more) { nrow = rowlist[i + W]; load(nxt, nrow); }
-        for (int q = 0; q < nq; ++q) {
+        if (more) { nrow = rowlist[i + W]; nm = qmask[nrow]; load(nxt, nrow); }
+        if (lane == 0) qmask[row] = 0u;                                  // this row's mask has been read (by this wave only: a row is listed once)
+        uint32_t mm = __builtin_amdgcn_readfirstlane(m);
+        while (mm) {
+            const int q = __ffs(mm) - 1;
+            mm &= mm - 1u;
             float acc = 0.f;
+            if (lane * 8 < dpad) acc = dot8(cur[0], qs + q * dpad + lane * 8, acc);
+            if (lane * 8 + 512 < dpad) acc = dot8(cur[1], qs + q * dpad + 512 + lane * 8, acc);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h * 512 + lane * 8 < dpad) {
-                    const uint4 v = cur[h];
-                    const float* qq = qs + q * dpad + h * 512 + lane * 8;
-                    const float4 q0 = *reinterpret_cast<const float4*>(qq), q1 = *reinterpret_cast<const float4*>(qq + 4);
-                    acc = fmaf(T::to_f32((uint16_t)(v.x & 0xffffu)), q0.x, acc); acc = fmaf(T::to_f32((uint16_t)(v.x >> 16)), q0.y, acc);
-                    acc = fmaf(T::to_f32((uint16_t)(v.y & 0xffffu)), q0.z, acc); acc = fmaf(T::to_f32((uint16_t)(v.y >> 16)), q0.w, acc);
-                    acc = fmaf(T::to_f32((uint16_t)(v.z & 0xffffu)), q1.x, acc); acc = fmaf(T::to_f32((uint16_t)(v.z >> 16)), q1.y, acc);
-                    acc = fmaf(T::to_f32((uint16_t)(v.w & 0xffffu)), q1.z, acc); acc = fmaf(T::to_f32((uint16_t)(v.w >> 16)), q1.w, acc);
-                }
-            }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+            for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
             if (lane == 0 && acc >= thr[q]) {
                 const unsigned pos = atomicAdd(&cnt[q], 1u);
                 if (pos < (unsigned)cand_cap) cand[(int64_t)q * cand_cap + pos] = make_key(acc, row);
             }
         }
-        cur[0] = nxt[0]; cur[1] = nxt[1]; row = nrow;
+        cur[0] = nxt[0]; cur[1] = nxt[1]; row = nrow; m = nm;
     }
 }
 
@@ -1592,7 +1599,7 @@ static int launch_q32(const CoarseArgs& a, int kt64, int num_cu, int device, hip
 }
 
 // ---- byte pre-scan: host side ---------------------------------------------------------------------------------------------------------------------------
-constexpr int BYTE_NQ_MAX = 8;                    // queries per block up to which the final round goes through the int8 copy (k_score_list keeps them in 32 KiB of LDS)
+constexpr int BYTE_NQ_MAX = 32;                   // the whole range of the <= 32-query stream kernel (k_score_list keeps the queries' 16-bit copies in <= 64 KiB of LDS)
 
 template <int KT>
 static int launch_scan8_kt(const CoarseArgs& a, int num_cu, int device, hipStream_t st) {
@@ -1613,10 +1620,13 @@ static int ensure_bitmap(Index* ix) {
     if (words <= ix->bitmap_words) return 0;
     if (ix->bitmap) (void)hipFree(ix->bitmap);
     if (ix->rowlist) (void)hipFree(ix->rowlist);
-    ix->bitmap = nullptr; ix->rowlist = nullptr; ix->bitmap_words = 0;
+    if (ix->qmask) (void)hipFree(ix->qmask);
+    ix->bitmap = nullptr; ix->rowlist = nullptr; ix->qmask = nullptr; ix->bitmap_words = 0;
     KR_HIP(hipMalloc(&ix->bitmap, (words + 1) * sizeof(uint32_t)));
     KR_HIP(hipMalloc(&ix->rowlist, words * 32 * sizeof(uint32_t)));
+    KR_HIP(hipMalloc(&ix->qmask, words * 32 * sizeof(uint32_t)));
     KR_HIP(hipMemset(ix->bitmap, 0, (words + 1) * sizeof(uint32_t)));        // from here on k_compact_rows leaves it all-zero behind every scan
+    KR_HIP(hipMemset(ix->qmask, 0, words * 32 * sizeof(uint32_t)));          // ... and k_score_list the per-row query masks
     ix->bitmap_words = words;
     return 0;
 }
@@ -1673,7 +1683,7 @@ static int byte_final_round(Index* ix, const CoarseArgs& a, const float* qf, int
     CoarseArgs m = a;
     m.xc = reinterpret_cast<const uint16_t*>(ix->x8); m.dpad = ix->dpad8 / 2;
     m.qc = reinterpret_cast<const uint16_t*>(ix->q8); m.qc2 = reinterpret_cast<const uint16_t*>(ix->q8 + (size_t)32 * ix->dpad8);
-    m.sx8 = ix->sx8; m.thr = ix->thr8; m.bitmap = ix->bitmap; m.nq_pad = 32; m.nq = nq; m.direct = 3;
+    m.sx8 = ix->sx8; m.thr = ix->thr8; m.bitmap = ix->bitmap; m.qmask = ix->qmask; m.nq_pad = 32; m.nq = nq; m.direct = 3;
     switch (ix->dpad8 / 128) {
         case 8: KR_TRY(launch_scan8_kt<8>(m, ix->num_cu, ix->device, st)); break;
         case 6: KR_TRY(launch_scan8_kt<6>(m, ix->num_cu, ix->device, st)); break;
@@ -1681,8 +1691,17 @@ static int byte_final_round(Index* ix, const CoarseArgs& a, const float* qf, int
         default: return fail(KR_EINVAL, "no byte pre-scan instance for d = %d", ix->d);
     }
     hipLaunchKernelGGL(k_compact_rows<true>, dim3((unsigned)((words + 1023) / 1024)), dim3(1024), 0, st, ix->bitmap, (int64_t)words, ix->rowlist, cnt_word);
-    hipLaunchKernelGGL(k_score_list<T>, dim3(ix->num_cu * 8), dim3(256), (size_t)nq * ix->dpad * sizeof(float), st, ix->xc, ix->dpad, ix->q_c, nq, ix->rowlist, cnt_word,
-                       ix->thr, ix->cnt, ix->cand, ix->cand_cap);
+    // few queries: many small blocks (each reloads <= 16 KiB of queries); up to 32: 1024-thread blocks, two per CU, around 64 KiB of queries each
+    const size_t sl_lds = (size_t)nq * ix->dpad * sizeof(uint16_t);
+    static DevOnce sl_once;
+    KR_TRY(once_per_device(sl_once, ix->device, [&]() -> int {
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_list<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024 * 2));
+        return 0;
+    }));
+    if (nq <= 8) hipLaunchKernelGGL(k_score_list<T>, dim3(ix->num_cu * 8), dim3(256), sl_lds, st, ix->xc, ix->dpad, ix->q_c, nq, ix->rowlist, cnt_word, ix->qmask,
+                                    ix->thr, ix->cnt, ix->cand, ix->cand_cap);
+    else hipLaunchKernelGGL(k_score_list<T>, dim3(ix->num_cu * 2), dim3(1024), sl_lds, st, ix->xc, ix->dpad, ix->q_c, nq, ix->rowlist, cnt_word, ix->qmask,
+                            ix->thr, ix->cnt, ix->cand, ix->cand_cap);
     KR_HIP(hipGetLastError());
     return 0;
 }
@@ -2098,12 +2117,12 @@ static int finish_one(Index* ix, int64_t* flagged_out) {
         const uint32_t* rec = pd.status + (size_t)b * STATUS_STRIDE;
         const bool list_ovf = rec[2 * QBLK] != 0u;   // a block list overflowed: every query of the block goes on to the next pass
         if (rec[2 * QBLK + 1] != BYTE_UNUSED) {
-            // feedback of the byte pre-scan: an index with non-finite rows never takes it again; four blocks in a row that marked more than 1/16 of the
+            // feedback of the byte pre-scan: an index with non-finite rows never takes it again; four blocks in a row that marked more than 1/8 of the
             // rows (data on which the byte bound does not separate) pause it for the next 1024 small blocks
             const int64_t marked = (int64_t)rec[2 * QBLK + 1];
             ix->st.byte_scans++; ix->st.byte_marked_rows += marked;
             if (rec[2 * QBLK + 2] != 0u) ix->byte_off = true;
-            else if (marked > ix->n / 16) { if (++ix->byte_bad >= 4) { ix->byte_bad = 0; ix->byte_pause = 1024; } }
+            else if (marked > ix->n / 8) { if (++ix->byte_bad >= 4) { ix->byte_bad = 0; ix->byte_pause = 1024; } }
             else ix->byte_bad = 0;
         }
         std::vector<uint32_t> hflags(nb);
@@ -2289,7 +2308,7 @@ void kr_index_destroy(kr_index* h) {
     }
     if (ix->vmm == 1) { (void)hipDeviceSynchronize(); ix->vf.release(); ix->vc.release(); ix->xf = nullptr; ix->xc = nullptr; }
     void* ptrs[] = {ix->xf, ix->xc, ix->bounds, ix->q_f, ix->q_f2, ix->theta1, ix->thr_mark, ix->bitmap, ix->rowlist, ix->q_c, ix->thr, ix->eps, ix->cnt, ix->flags, ix->cand, ix->out_s, ix->out_r,
-                    ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt, ix->x8, ix->sx8, ix->bounds8, ix->q8, ix->thr8, ix->mu8};
+                    ix->nrer, ix->ex_a, ix->ex_b, ix->ex_qidx, ix->blk_list, ix->blk_cnt, ix->x8, ix->sx8, ix->bounds8, ix->q8, ix->thr8, ix->mu8, ix->qmask};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ix->h_status) (void)hipHostFree(ix->h_status);
     for (auto& e : ix->ev) if (e) (void)hipEventDestroy(e);

@@ -7,7 +7,7 @@
   * index, every fourth case (round 5): the corpus cut into 2-3 uneven row shards searched in SPLIT form (coarse scan -> gathered coarse scores -> global bound
     -> re-rank above it), the merged lists must equal the unsharded search bit for bit;
   * index (round 5): the byte pre-scan of small query blocks (kr_set_option "byte_prescan") is enabled for EVERY index size here (debug_byte_min_rows = 0), so
-    blocks of <= 8 queries at d in {512, 768, 1024} take it whenever their last round is not the direct one; every seventh case plants a NaN row (the int8
+    blocks of <= 32 queries at d in {512, 768, 1024} take it whenever their last round is not the direct one; every seventh case plants a NaN row (the int8
     copy then marks every row: slow, still exact); every fifth case adds rows AFTER the first search (the int8 copy is extended) and searches again;
   * encoder (tiny config): the projection main loops / skinny tile shapes (KIRAG_AMD_PROJ_TILE = 256 / 130 / 128 / 64 / 32) must agree bit for bit, and a
     sequence's embedding must not depend on the rest of the batch.

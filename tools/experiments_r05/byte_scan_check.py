@@ -44,7 +44,7 @@ for kind in KINDS:
             head = x[:64].clone()
         del x
     gq = torch.Generator(device=dev); gq.manual_seed(2)
-    for nq in (1, 2, 8):
+    for nq in (1, 2, 8, 16, 32):
         qn = cd.queries_near(head[:nq], gq)
         qr = cd.rows(nq, gq)                       # queries that aim at nothing in particular
         for name, q in (("near", qn), ("free", qr)):
