@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_quant8_rows(const float* __restrict__ x
 __global__ __launch_bounds__(256) void k_scan8_prep(const uint64_t* __restrict__ cand, int cand_cap, const uint32_t* __restrict__ cnt, const float* __restrict__ eps16,
                                                     const float* __restrict__ qf, int nq, int d, int dpad8, int k, const float* __restrict__ bounds8,
                                                     const float* __restrict__ mu8, int8_t* __restrict__ q8, float* __restrict__ thr8,
-                                                    unsigned int* __restrict__ mark_count) {
+                                                    unsigned int* __restrict__ mark_count, float* __restrict__ thr16) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[5][4];
     if (blockIdx.x == 0 && threadIdx.x == 0) *mark_count = 0u;          // the list the scan behind this kernel appends to
@@ -1241,6 +1241,13 @@ __global__ __launch_bounds__(256) void k_scan8_prep(const uint64_t* __restrict__
         float t = -INFINITY;                                               // unusable: every row is marked (slow, exact)
         if (usable) { t = theta * (254.f / sq); t -= fabsf(t) * 1e-6f; }
         thr8[q] = t;
+        // the 16-bit threshold of the round as well: a row whose 16-bit score is below kth16 - 2 eps16 has an exact score below kth16 - eps16, i.e. below k rows
+        // already seen — for small k that is far above the round's own survivor-budget threshold (the rank-55 score of the sample): a few hundred listed rows
+        // per query pass instead of ~2000 (each costs a returning atomic on the query's counter, and k_rerank reads them all).  Kept strictly below what
+        // k_rerank will compute from the same kth16 (theta = b_k - 2 eps with b_k >= kth16), so its "theta > thr" test still passes when nothing better turns up.
+        float t16 = kth - 2.f * eps16[q];
+        t16 -= fabsf(t16) * 1e-6f + 1e-30f;
+        if (t16 > thr16[q]) thr16[q] = t16;                                // (NaN / -inf: no change)
     }
 }
 
@@ -1679,7 +1686,7 @@ static int byte_final_round(Index* ix, const CoarseArgs& a, const float* qf, int
     unsigned int* cnt_word = ix->bitmap + words;                         // (the list-length word behind the bitmap pass 2's marking scan uses)
     const size_t prep_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int);
     hipLaunchKernelGGL(k_scan8_prep, dim3(32), dim3(256), prep_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->eps, qf, nq, ix->d, ix->dpad8, k, ix->bounds8, ix->mu8,
-                       ix->q8, ix->thr8, cnt_word);
+                       ix->q8, ix->thr8, cnt_word, ix->thr);
     CoarseArgs m = a;
     m.xc = reinterpret_cast<const uint16_t*>(ix->x8); m.dpad = ix->dpad8 / 2;
     m.qc = reinterpret_cast<const uint16_t*>(ix->q8); m.qc2 = reinterpret_cast<const uint16_t*>(ix->q8 + (size_t)32 * ix->dpad8);

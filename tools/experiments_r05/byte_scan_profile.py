@@ -20,7 +20,9 @@ for s0 in range(0, N, 250_000):
     if head is None:
         head = x[:8].clone()
     del x
-q = cd.queries_near(head[:1], g)
+NQ = int(os.environ.get("NQ", 1))
+head = head if NQ <= 8 else torch.cat([head] * 4)
+q = cd.queries_near(head[:NQ], g)
 for _ in range(200):
     ix.search(q, 10)
 print(ix.stats())
