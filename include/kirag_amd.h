@@ -90,7 +90,10 @@ int kr_index_add_raw(kr_index* ix, const float* xf, const uint16_t* xc, int64_t 
  * `mode`: 0 = auto: pass 1 = 16-bit MFMA scan + certified exact re-rank for all queries; pass 2 = fp64 MFMA scan of the fp32 rows
  *             + certified re-rank for the queries pass 1 could not certify (they share one pass over the corpus per group of
  *             32); pass 3 = exact scan, query by query, for what is left (mass ties);
- *         1 = exact scan only, 2 = pass 2 (+3) only — slow; used by tests as on-device cross-checks. */
+ *         1 = exact scan only, 2 = pass 2 (+3) only — slow; used by tests as on-device cross-checks.
+ * Small calls (ABI 8, nq <= 32, mode 0): when q, scores and rows are all addressable by the device (device memory of the index's GPU, pinned host
+ * memory) the kernels read the queries and write the results in place — no staging copies; any other combination goes through the workspace as before.
+ * On an index of >= 2^19 rows the final coarse round of such a call streams an int8 copy of the rows (kr_set_option "byte_prescan"). */
 int kr_index_search(kr_index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, int mode, void* stream);
 /* The same search (mode 0) in two halves.  kr_index_search_async ENQUEUES pass 1 of every 1024-query block on `stream` and returns without waiting
  * for the device (given device pointers it performs no host synchronisation at all): the results of every query whose exactness certificate holds
