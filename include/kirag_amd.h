@@ -39,7 +39,7 @@ const char* kr_last_error(void);
 int kr_device_count(void);
 /* process-wide test / diagnostic switches.  "force_exact_scores" (0/1): every canonical score goes through the integer
  * super-accumulator instead of the certified fp64 fast path (same results by definition; exercises the rare path).
- * "byte_prescan" (0/1, default 1): blocks of at most 32 queries on an index of >= 2^19 rows (384 < d <= 1024) stream an int8 copy of the rows
+ * "byte_prescan" (0/1, default 1): blocks of at most 32 queries on an index of >= 2^19 rows (256 < d <= 1024 with a 16-bit row pitch of 384 / 512 / 768 / 1024) stream an int8 copy of the rows
  * (1 KiB per row at d = 1024, built by the first such search) in the final round of the coarse scan and 16-bit-score only the rows it marks;
  * results are the same exact top-k either way.  KIRAG_AMD_NO_BYTE_SCAN in the environment at kr_index_create: never for that index.
  * "debug_byte_min_rows" (rows; < 0 = default 2^19): test hook, the index size from which small blocks take that path.

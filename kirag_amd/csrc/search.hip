@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512, SMALLQ ? 1 : 2) void k_coarse(CoarseArgs a) {
 // Tile slots are 32 rows here (a.ntiles, a.tile_begin, a.tile_count, a.perm_mul are in units of 32 rows).
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 constexpr int Q32_THREADS = 256;
-template <int KT> struct Q32Ring { static constexpr int value = (KT % 8 == 0) ? 8 : (KT % 6 == 0) ? 6 : 4; };
+template <int KT> struct Q32Ring { static constexpr int value = (KT % 8 == 0) ? 8 : (KT % 6 == 0) ? 6 : (KT % 4 == 0) ? 4 : 3; };   // (3: the int8 copy of 384-d rows)
 template <int KT> constexpr int q32_lds() { return 4 * Q32Ring<KT>::value * 4096 > 2 * QBLK * 4 + 64 ? 4 * Q32Ring<KT>::value * 4096 : 2 * QBLK * 4 + 64; }
 
 // (the body is a function with a __restrict__ corpus pointer on purpose: after inlining, the LDS-DMA carries that pointer's alias scope and the ring's
@@ -1619,7 +1619,7 @@ static int launch_scan8_kt(const CoarseArgs& a, int num_cu, int device, hipStrea
     hipLaunchKernelGGL((k_coarse_q32<BF16, 3, KT>), dim3(num_cu), dim3(Q32_THREADS), lds, st, a);
     return 0;
 }
-static bool byte_dim_ok(int d) { const int dp = (int)round_up(d, 128); return dp == 1024 || dp == 768 || dp == 512; }
+static bool byte_dim_ok(int d) { const int dp = (int)round_up(d, 128); return dp == 1024 || dp == 768 || dp == 512 || dp == 384; }
 
 // the bitmap / row list shared by pass 2's marking scan and the byte pre-scan (one bit per row + one word: the list length; the marked rows, compacted)
 static int ensure_bitmap(Index* ix) {
@@ -1695,6 +1695,7 @@ static int byte_final_round(Index* ix, const CoarseArgs& a, const float* qf, int
         case 8: KR_TRY(launch_scan8_kt<8>(m, ix->num_cu, ix->device, st)); break;
         case 6: KR_TRY(launch_scan8_kt<6>(m, ix->num_cu, ix->device, st)); break;
         case 4: KR_TRY(launch_scan8_kt<4>(m, ix->num_cu, ix->device, st)); break;
+        case 3: KR_TRY(launch_scan8_kt<3>(m, ix->num_cu, ix->device, st)); break;
         default: return fail(KR_EINVAL, "no byte pre-scan instance for d = %d", ix->d);
     }
     hipLaunchKernelGGL(k_compact_rows<true>, dim3((unsigned)((words + 1023) / 1024)), dim3(1024), 0, st, ix->bitmap, (int64_t)words, ix->rowlist, cnt_word);

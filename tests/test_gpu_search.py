@@ -694,7 +694,7 @@ def byte_everywhere():
     _opt(b"debug_byte_min_rows", -1); _opt(b"byte_prescan", 1)
 
 
-@pytest.mark.parametrize("n,d,nq,k", [(40000, 1024, 2, 10), (30011, 768, 8, 50), (25000, 512, 1, 100), (33333, 1024, 7, 1), (50000, 1000, 3, 20), (9000, 768, 5, 64), (40000, 1024, 32, 10), (30000, 768, 17, 100), (26000, 512, 9, 5)])
+@pytest.mark.parametrize("n,d,nq,k", [(40000, 1024, 2, 10), (30011, 768, 8, 50), (25000, 512, 1, 100), (33333, 1024, 7, 1), (50000, 1000, 3, 20), (9000, 768, 5, 64), (40000, 1024, 32, 10), (30000, 768, 17, 100), (26000, 512, 9, 5), (45000, 384, 4, 10), (20000, 380, 1, 30)])
 def test_byte_prescan_small_corpora_vs_canonical(byte_everywhere, n, d, nq, k):
     """Blocks of <= 32 queries with the int8 final round forced on at small sizes: bit-exact vs the C oracle (rows and score bits), identical to the same
     search with the option off, ties by row index across the byte-scanned region, and the statistics show that the path ran and what it marked."""
