@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call 34: byte round for the whole <= 32-query range (per-row query masks): byte tests, A/B at 5M rows, 200-s soak
+# round 5, call 34: 16-bit list threshold raised to kth16 - 2 eps16: byte tests, A/B at 5M rows, 150-s soak
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5c34; mkdir -p $O
 cd $R

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call 37: tie-safe slack in the byte bound; byte tests (incl. f16 copy + split form) and a 240-s soak, seed 909
+# round 5, call 37: byte round for 384-d rows (three-slot ring): byte tests + a 150-s soak, seed 384
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5c37; mkdir -p $O
 cd $R
