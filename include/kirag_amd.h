@@ -109,6 +109,9 @@ int kr_index_search(kr_index* ix, const float* q, int nq, int k, float* scores, 
 int kr_index_search_async(kr_index* ix, const float* q, int nq, int k, float* scores, int64_t* rows, void* stream);
 int kr_index_search_finish(kr_index* ix);
 int kr_index_search_finish_ex(kr_index* ix, int64_t* flagged, int cap, int* ncalls);
+/* ... and only the OLDEST outstanding call (ABI 8): a host that converts block i's results while block i + 1 is already being searched keeps two calls
+ * in flight and finishes them one at a time (Indexer.search_knn).  *flagged (may be NULL) as in kr_index_search_finish_ex; no call outstanding: 0, nothing done. */
+int kr_index_search_finish_one(kr_index* ix, int64_t* flagged);
 int kr_index_search_pending(const kr_index* ix);   /* number of outstanding asynchronous calls */
 
 /* Row-sharded search with the exchange BEFORE the re-rank (replaces the gather of utils/utils.py:145-155 together with kr_topk_merge_device /

@@ -60,6 +60,7 @@ SIGNATURES = {
     "kr_index_search_rerank_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kr_index_search_finish": (C.c_int, [C.c_void_p]),
     "kr_index_search_finish_ex": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
+    "kr_index_search_finish_one": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "kr_index_search_pending": (C.c_int, [C.c_void_p]),
     "kr_index_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "kr_score_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -2551,6 +2551,16 @@ int kr_index_search_finish_ex(kr_index* h, int64_t* flagged, int cap, int* ncall
     return 0;
 }
 
+int kr_index_search_finish_one(kr_index* h, int64_t* flagged) {
+    if (!h) return fail(KR_EINVAL, "index is NULL");
+    Index* ix = reinterpret_cast<Index*>(h);
+    KR_TRY(select_device(ix->device));
+    int64_t fl = 0;
+    KR_TRY(finish_one(ix, &fl));
+    if (flagged) *flagged = fl;
+    return 0;
+}
+
 int kr_index_search_pending(const kr_index* h) { return h ? reinterpret_cast<const Index*>(h)->pend_n : 0; }
 
 // exact top-k of q x^T for a small, transient candidate set (the KiRAG loop's aligner step): canonical scores of every (query, row)

@@ -217,6 +217,16 @@ class FlatIPIndex:
             self._pending = []
         return [int(flagged[i]) for i in range(min(ncalls.value, 16))]
 
+    def finish_one(self) -> int:
+        """Finish the OLDEST outstanding ``search_async`` call only (``kr_index_search_finish_one``); returns the number of its queries pass 1 could not certify."""
+        fl = C.c_int64(0)
+        try:
+            _lib.check(self._lib.kr_index_search_finish_one(self._h, C.byref(fl)))
+        finally:
+            if self._pending:
+                self._pending.pop(0)
+        return int(fl.value)
+
     def reconstruct_n(self, start: int, n: int) -> np.ndarray:
         out = np.empty((n, self.d), np.float32)
         _lib.check(self._lib.kr_index_get_rows(self._h, int(start), int(n), out.ctypes.data, None))
@@ -304,10 +314,11 @@ class Indexer(object):
 
     def search_knn(self, query_vectors, top_docs: int, index_batch_size=1024, verbose: bool = True) -> List[Tuple[List[object], List[float]]]:
         """index.py:36-53, pipelined: the reference's loop searches a block, THEN builds its id strings, THEN starts the next block — the string pass
-        costs as much host time as the GPU's whole search of the block.  Here block i + 1 is enqueued (``kr_index_search_async``, results into pinned
-        host buffers) before block i's ids are converted, so the device works under the host's conversion; same lists, same order."""
+        costs as much host time as the GPU's whole search of the block.  Here two blocks are in flight (``kr_index_search_async``, results into pinned
+        host buffers; the oldest is finished with ``kr_index_search_finish_one``) while block i's ids are converted, so the device never waits for the
+        host's conversion; the last block is searched as 3/4 + 1/4 so that only a quarter block's strings are built behind the device; same lists, same order."""
         if isinstance(query_vectors, np.ndarray):
-            query_vectors = query_vectors.astype('float32')
+            query_vectors = np.asarray(query_vectors, dtype=np.float32)        # (index.py:40 `.astype('float32')`, without the copy when it already is)
         top_docs = int(top_docs)
         nq_all = len(query_vectors)
         blocks = [(s, min(s + index_batch_size, nq_all)) for s in range(0, nq_all, index_batch_size)]
@@ -333,27 +344,48 @@ class Indexer(object):
         import torch
         if not 0 < top_docs <= self.index.ntotal:
             raise ValueError(f"top_docs={top_docs} must satisfy 0 < k <= ntotal={self.index.ntotal}")
+        # the conversion of the LAST block's ids has no search left to hide under: that block is searched as two pieces (3/4 + 1/4, whole 128-query tiles), so
+        # only a quarter block's strings (~2 ms instead of ~8) are built after the device has finished; same lists, same order
+        s_last, e_last = blocks[-1]
+        if e_last - s_last >= 512:
+            tail = max(128, ((e_last - s_last) // 4) // 128 * 128)
+            blocks[-1:] = [(s_last, e_last - tail), (e_last - tail, e_last)]
         dev = torch.device("cuda", self.index.device)
         qd = (query_vectors if torch.is_tensor(query_vectors) else torch.from_numpy(np.ascontiguousarray(query_vectors, dtype=np.float32)))
-        qd = qd.detach().to(dev, dtype=torch.float32).contiguous()       # one upload of all queries (nq x 4 KiB)
+        qd = qd.detach().to(dev, dtype=torch.float32).contiguous()       # ONE upload of all queries (nq x 4 KiB) before the first search: an upload from pageable
+                                                                         # memory per block would queue behind the searches in flight on the same stream
         bs = blocks[0][1] - blocks[0][0]
-        slots = [(torch.empty((bs, top_docs), dtype=torch.float32, pin_memory=True), torch.empty((bs, top_docs), dtype=torch.int64, pin_memory=True)) for _ in range(2)]
+        key = (bs, top_docs)
+        if getattr(self, "_knn_slots_key", None) != key:   # the three pinned result slots are kept between calls (pinning 2.4 MiB costs more than a block's upload)
+            self._knn_slots = [(torch.empty((bs, top_docs), dtype=torch.float32, pin_memory=True), torch.empty((bs, top_docs), dtype=torch.int64, pin_memory=True))
+                               for _ in range(3)]
+            self._knn_slots_key = key
+        slots = self._knn_slots
 
         def enqueue(j):
             s0, e0 = blocks[j]
-            ps, pi = slots[j & 1]
+            ps, pi = slots[j % 3]
             self.index.search_async(qd[s0:e0], top_docs, ps[:e0 - s0], pi[:e0 - s0])
 
         with torch.cuda.device(dev):
-            enqueue(0)
-            for j, (s0, e0) in enumerate(blocks):
-                self.index.finish()                                     # block j is final in its pinned slot (the only call outstanding)
-                ps, pi = slots[j & 1]
-                scores = ps[:e0 - s0].numpy().copy(); indexes = pi[:e0 - s0].numpy().copy()
-                if j + 1 < len(blocks):
-                    enqueue(j + 1)                                      # the device searches block j + 1 while the host builds block j's strings
-                db_ids = ids_to_str_rows(self.index_id_to_db_id[indexes])
-                result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
+            try:
+                enqueue(0)
+                if len(blocks) > 1:
+                    enqueue(1)                                          # two calls in flight: the device goes from block j straight into block j + 1
+                for j, (s0, e0) in enumerate(blocks):
+                    self.index.finish_one()                             # block j (the oldest call) is final in its pinned slot
+                    ps, pi = slots[j % 3]
+                    scores = ps[:e0 - s0].numpy().copy(); indexes = pi[:e0 - s0].numpy().copy()
+                    if j + 2 < len(blocks):
+                        enqueue(j + 2)                                  # slot (j + 2) % 3 was read out one iteration ago
+                    db_ids = ids_to_str_rows(self.index_id_to_db_id[indexes])
+                    result.extend([(db_ids[i], scores[i]) for i in range(len(db_ids))])
+            except BaseException:
+                try:
+                    self.index.finish()                                 # nothing of this call stays outstanding on the handle
+                except Exception:
+                    pass
+                raise
         return result
 
     # ---- on-disk formats (index.py:55-79) --------------------------------------------------------------

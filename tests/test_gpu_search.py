@@ -148,6 +148,27 @@ def test_search_knn_pipelined_blocks_equal_the_block_by_block_form():
     assert ix.index.stats()["fine"] + ix.index.stats()["exact"] > 0     # the uncertified queries really went through passes 2 / 3
 
 
+def test_finish_one_finishes_the_oldest_call_only():
+    """ABI 8: kr_index_search_finish_one — two asynchronous searches in flight, the oldest is finished (its results are final) while the newer one stays
+    outstanding; a third call on a handle with nothing outstanding is a no-op."""
+    import torch
+    from kirag_amd.retriever.index import FlatIPIndex
+    rng = np.random.default_rng(5)
+    x = _unit(rng, 30000, 256)
+    q, _ = _queries_near(rng, x, 40)
+    ix = FlatIPIndex(256, device=0); ix.add(x)
+    so, io = S.search_canonical(q, x, 10)
+    qa, qb = torch.from_numpy(q[:20]).cuda(), torch.from_numpy(q[20:]).cuda()
+    outs = [(torch.empty((20, 10), dtype=torch.float32, pin_memory=True), torch.empty((20, 10), dtype=torch.int64, pin_memory=True)) for _ in range(2)]
+    ix.search_async(qa, 10, *outs[0]); ix.search_async(qb, 10, *outs[1])
+    assert ix._lib.kr_index_search_pending(ix._h) == 2
+    assert ix.finish_one() == 0 and ix._lib.kr_index_search_pending(ix._h) == 1
+    assert np.array_equal(outs[0][1].numpy(), io[:20]) and np.array_equal(outs[0][0].numpy().view(np.uint32), so[:20].view(np.uint32))
+    assert ix.finish_one() == 0 and ix._lib.kr_index_search_pending(ix._h) == 0
+    assert np.array_equal(outs[1][1].numpy(), io[20:]) and np.array_equal(outs[1][0].numpy().view(np.uint32), so[20:].view(np.uint32))
+    assert ix.finish_one() == 0
+
+
 def test_split_search_exchange_before_rerank_two_shards_in_one_process():
     """Round 5: kr_index_search_coarse_async -> [gather of the shards' k best coarse scores] -> kr_index_search_global_theta ->
     kr_index_search_rerank_async.  Two row shards of one corpus held by two indexes of ONE process, the gather done by hand: the merged lists must be the
