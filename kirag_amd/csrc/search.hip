@@ -16,8 +16,11 @@
 //                 theta > thr the exact answer is inside the buffer prefix {coarse >= theta}: gather those
 //                 fp32 rows, compute the canonical fp64-ordered score (oracle/search_c.c), sort by
 //                 (score desc, row asc), emit k.  Otherwise (or on buffer overflow) flag the query.
-//   4. flagged queries are re-answered by the exact full scan (k_exact_scan + k_sort_chunks tree).
-// The result is therefore ALWAYS the exact top-k under the canonical score; the 16-bit scan only decides
+//   4. flagged queries are re-answered by the fp64-MFMA scan of the fp32 rows (k_fine, pass 2) and, failing that, by the exact full
+//      scan (k_exact_scan + k_sort_chunks tree, pass 3).
+// Blocks of <= 32 queries on a large index stream a derived int8 copy (1 byte per element + one scale per row) in the LAST round of
+// step 2 and 16-bit-score only the rows it marks (byte_final_round).
+// The result is therefore ALWAYS the exact top-k under the canonical score; the low-precision scans only decide
 // which rows get the fp64 treatment.
 #include "gemm_nt.hpp"
 
