@@ -148,6 +148,27 @@ def test_search_knn_pipelined_blocks_equal_the_block_by_block_form():
     assert ix.index.stats()["fine"] + ix.index.stats()["exact"] > 0     # the uncertified queries really went through passes 2 / 3
 
 
+@pytest.mark.parametrize("nq,bs", [(2600, 1024), (1024 + 512, 1024), (1300, 600), (3000, 1000)])
+def test_search_knn_last_block_in_two_pieces_and_two_calls_in_flight(nq, bs):
+    """Indexer.search_knn with full-size blocks: the last block of >= 512 queries is searched as 3/4 + 1/4 (whole 128-query tiles), two blocks are in
+    flight at any time; every row of every query must equal the one-shot search (ids mapped through index_id_to_db_id, scores bit for bit)."""
+    rng = np.random.default_rng(nq + bs)
+    n, d, k = 20000, 128, 7
+    x = _unit(rng, n, d)
+    q, _ = _queries_near(rng, x, nq)
+    from kirag_amd.retriever.index import Indexer
+    ix = Indexer(d)
+    ids = [str(10_000_000_000 + 3 * i) for i in range(n)]
+    ix.index_data(ids, x)
+    res = ix.search_knn(q, k, index_batch_size=bs, verbose=False)
+    s, i = ix.index.search(q, k)
+    assert len(res) == nq
+    for r in range(nq):
+        assert res[r][0] == [ids[j] for j in i[r]], r
+        assert np.array_equal(np.asarray(res[r][1]).view(np.uint32), s[r].view(np.uint32)), r
+    assert ix.index._lib.kr_index_search_pending(ix.index._h) == 0
+
+
 def test_finish_one_finishes_the_oldest_call_only():
     """ABI 8: kr_index_search_finish_one — two asynchronous searches in flight, the oldest is finished (its results are final) while the newer one stays
     outstanding; a third call on a handle with nothing outstanding is a no-op."""
