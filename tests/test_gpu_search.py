@@ -794,6 +794,71 @@ def test_byte_prescan_f16_coarse_copy_and_row_shards_in_split_form(byte_everywhe
     assert np.array_equal(mi, io) and np.array_equal(ms.view(np.uint32), so.view(np.uint32))
 
 
+def test_byte_prescan_bound_holds_for_a_row_built_to_reach_it(byte_everywhere):
+    """Random data leaves the byte bound ~30 x slack, so a too-small eps8 would pass every other test.  Here a row of the exact top-k is BUILT so that its byte
+    score underestimates its exact score by ~96 % of the Cauchy-Schwarz bound: the query has equal-magnitude components (the inequality is tight), every
+    component of the row sits 1/64 of a step short of a rounding boundary on the side that loses against the query's sign, one component pins the row's scale to
+    a power of two, the first 65 536 rows come in +- pairs (centre exactly 0, unit weights).  k - 1 anchors and one further anchor with exact scores just
+    below the built row's sit in the tiles of the 16-bit rounds, the built row in a tile of the byte round: it must displace the lowest anchor."""
+    from math import gcd
+    rng = np.random.default_rng(20260)
+    n, d, k = 400_000, 1024, 10
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x[1:65536:2] = -x[0:65536:2]                                   # mean of the first 65 536 rows: exactly zero in any summation order of +- pairs
+    sign = np.where(rng.random(d) < 0.5, -1.0, 1.0).astype(np.float32)
+    q = (sign / np.float32(32.0)).astype(np.float32)[None, :]      # |q_i| = 1 / sqrt(d) exactly, |q| = 1
+    # which 32-row tiles the two 16-bit rounds visit (run_rounds: slots [0, 4096) of the multiplicative tile permutation for cap = 4096, K1 = 64)
+    ntiles = (n + 31) // 32
+    mul = max(1, int(ntiles * 0.6180339887498949))
+    while gcd(mul, ntiles) != 1:
+        mul += 1
+    sample_tiles = {(s * mul) % ntiles for s in range(4096)}
+    late_sample = sorted(t for t in sample_tiles if t * 32 >= 65536)
+    byte_tiles = [t for t in range(ntiles) if t not in sample_tiles and t * 32 >= 65536]
+    S0 = 0.5
+    anchor_rows = [late_sample[7 * j + 3] * 32 + 5 for j in range(k)]
+    for j, r in enumerate(anchor_rows):                            # exact scores S0, S0 + 1e-3, ..., S0 + 9e-3 (unit rows: score = cosine with q)
+        c = S0 + 1e-3 * j
+        z = rng.standard_normal(d).astype(np.float64); z -= (z @ q[0].astype(np.float64)) * q[0]; z /= np.linalg.norm(z)
+        x[r] = (c * q[0].astype(np.float64) + np.sqrt(1.0 - c * c) * z).astype(np.float32)
+    # the built row: r_i = sign(q_i) s (m_i + 31/64): the rounding error loses against q_i everywhere; scale pinned by one component at 127 s
+    s_ = np.float64(2.0 ** -10)
+    target = S0 + 5e-4                                             # between the lowest and the second-lowest anchor
+    m = np.floor(rng.random(d) * 40.0)                             # magnitudes (m_i + 31/64) s with the sign of q_i: the value rounds to sign m s, so the
+    frac = 31.0 / 64.0                                             # rounding error sign (31/64) s has the sign of q_i on EVERY component (and is exact in fp32)
+    mag = (m + frac) * s_
+    row = sign.astype(np.float64) * mag
+    row[0] = sign[0] * 127.0 * s_
+    # scale the integer parts so that q.row hits the target (keep the fractional parts): adjust m on a few components
+    cur = float((q[0].astype(np.float64) * row).sum())
+    need = target - cur
+    steps = int(round(need * 32.0 / s_))                           # one unit of m on one component changes the score by s / 32
+    idx = 1
+    while steps != 0:
+        stp = 1 if steps > 0 else -1
+        if 0 <= m[idx] + stp <= 120:
+            m[idx] += stp; steps -= stp
+        idx = 1 + (idx % (d - 1))
+    mag = (m + frac) * s_
+    row = sign.astype(np.float64) * mag
+    row[0] = sign[0] * 127.0 * s_
+    built = byte_tiles[len(byte_tiles) // 2] * 32 + 11
+    x[built] = row.astype(np.float32)
+    assert np.array_equal(x[built].astype(np.float64), row)        # every component is exact in fp32
+    exact_built = float((q[0].astype(np.float64) * row).sum())
+    err = row - s_ * np.rint(row / s_)                             # what the int8 copy loses of the built row
+    under = float((q[0].astype(np.float64) * err).sum())
+    assert abs(exact_built - target) < 2e-5 and under > 0.95 * float(np.linalg.norm(err)) > 0.013, (exact_built, under, float(np.linalg.norm(err)))
+    ix = _mk(d, x)
+    s, i = ix.index.search(q, k)
+    st = ix.index.stats(reset=True)
+    so, io = S.search_canonical(q, x, k)
+    assert st["byte_scans"] == 1, st
+    assert built in io[0] and anchor_rows[0] not in io[0]          # the oracle agrees with the construction
+    assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32)), (i, io)
+
+
 def test_byte_prescan_rows_added_later_and_anisotropic_rows(byte_everywhere):
     """The int8 copy is derived data: rows added after the first search extend it (same centre and axis weights), a growth beyond its capacity rebuilds
     it; rows with a common direction and a few large-variance axes (what the centre / weights exist for) stay exact and mark few rows."""
