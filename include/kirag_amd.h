@@ -33,7 +33,7 @@ extern "C" {
 #define KR_ESTATE (-1)    /* handle not ready (e.g. encoder weights missing) */
 #define KR_ERANGE (-34)   /* the encoder met non-finite activations (a value outside the f16 operand range, or NaN / Inf weights): results unusable */
 
-#define KR_ABI_VERSION 8
+#define KR_ABI_VERSION 9
 int kr_abi_version(void);
 const char* kr_last_error(void);
 int kr_device_count(void);
@@ -245,6 +245,15 @@ int kr_encoder_forward(kr_encoder* enc, const int64_t* input_ids, const int64_t*
  * [0, type_vocab) is reported as KR_EINVAL through the same deferred channel as token ids. */
 int kr_encoder_forward_tt(kr_encoder* enc, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids, int B, int S,
                           int pool, float* out, void* stream);
+/* The same forward from RAGGED input: token_ids = int32 ids of the attended positions of every sequence back to back (total_tokens of them, host or device),
+ * seq_lens [B] int32 = how many belong to each sequence, occupying positions 0 .. len-1 - what the reference's collator yields for a right-padding tokenizer
+ * (dataset/collators.py:59-81, padding=True: input_ids[b, :len], attention_mask[b] = 1^len 0^(S-len)) without the padding: 4-16x fewer bytes from the tokenizer
+ * processes of compute_corpus_embeddings.py:77-81 to the GPU.  S = the padded width the equivalent [B,S] call would have (>= every length, <= max_pos; it selects
+ * the attention kernel exactly as kr_encoder_forward does).  Rows are BIT-IDENTICAL to kr_encoder_forward on the equivalent padded batch (the same kernels run
+ * on the same packed token tables).  A length outside [0, S] or lengths that do not add up to total_tokens are reported as KR_EINVAL through the deferred
+ * channel below (the sequence is read as empty, nothing is read out of bounds); an empty sequence yields NaN (mean pool) like an all-zero mask. */
+int kr_encoder_forward_packed(kr_encoder* enc, const int32_t* token_ids, const int32_t* seq_lens, int B, int S, int64_t total_tokens, int pool, float* out,
+                              void* stream);
 /* kr_encoder_forward with a DEVICE `out` pointer only enqueues work on `stream` and returns (no host synchronisation); with a host `out`
  * it returns when the result is in the caller's buffer.  The one thing a forward can get wrong at run time - a token id outside [0, vocab)
  * - is recorded by the kernels (the offending token is read as id 0) and reported as KR_EINVAL by the host-output call itself, or, for

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KIRAG_AMD_LIB") or os.path.join(_HERE, "libkirag_amd.so")   # KIRAG_AMD_LIB: diagnostic builds (tools/stamp_build.sh)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class KiragAmdError(RuntimeError):
@@ -82,6 +82,7 @@ SIGNATURES = {
     "kr_encoder_finalize": (C.c_int, [C.c_void_p]),
     "kr_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "kr_encoder_forward_tt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "kr_encoder_forward_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "kr_encoder_last_hidden": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "kr_encoder_check": (C.c_int, [C.c_void_p]),
 }

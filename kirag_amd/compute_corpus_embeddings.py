@@ -15,10 +15,12 @@ import argparse
 import logging
 import os
 import pickle
+import threading
 from typing import Optional
 
 import torch
 
+from . import feed
 from .collators import COLLATOR_MAP
 from .retriever.retrievers import InBatchRetriever
 from .utils import prefetch_map, to_device
@@ -43,9 +45,9 @@ def setup_parser(argv=None):
     # MI355X path: passages per encoder launch (rows are batch-invariant, so this changes speed only)
     parser.add_argument("--encode_batch_size", type=int, default=512)
     parser.add_argument("--prefetch_batches", type=int, default=2, help="batches tokenised ahead of the GPU on a background thread")
-    parser.add_argument("--tokenizer_workers", type=int, default=0,
-                        help="> 0: tokenise in that many worker PROCESSES (each with its own tokenizer; batches come back in order) instead of "
-                             "one background thread - for hosts where one tokenizer cannot keep the encoder fed")
+    parser.add_argument("--tokenizer_workers", type=int, default=-1,
+                        help="> 0: tokenise in that many worker PROCESSES (each with its own tokenizer; batches come back in order); 0: one background "
+                             "thread; -1 (default): min(8, cpus / 2) processes for a GPU run over more than a few batches, else 0")
     parser.add_argument("--no_embedding_files", action="store_true",
                         help="do not write corpus_embeddings_*.pkl / passage_id_list_*.pkl (streamed encode straight into a resident index shard)")
     return parser.parse_args(argv)
@@ -56,10 +58,108 @@ def shard_range(n: int, rank: int, world: int):
     return min(rank * per, n), min((rank + 1) * per, n)
 
 
+def default_tokenizer_workers(n_batches: int, on_gpu: bool) -> int:
+    """``--tokenizer_workers -1``: one tokenizer thread alone feeds ~5.6 k passages/s, the encoder takes ~13 k (profiles/r05/feed_bench_100k.txt), so a GPU run over
+    more than a few batches gets min(8, cpus / 2) tokenizer processes; tiny corpora and host-only runs stay in-process (no process start-up cost)."""
+    if not on_gpu or n_batches <= 4:
+        return 0
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    return max(0, min(8, cpus // 2, n_batches))
+
+
+class _ShardWriter:
+    """The D2H -> file-buffer -> ``.pkl`` half of the loop on its own thread: the encode loop hands over (event, pinned rows, passage ids) and goes on launching;
+    this thread waits for the copy, appends the rows to the buffer of the current shard file (allocated at its final size: no list of chunks, no ``torch.cat``)
+    and writes ``corpus_embeddings_{s}_{e}.pkl`` / ``passage_id_list_{s}_{e}.pkl`` (compute_corpus_embeddings.py:101-120) whenever ``cap`` rows are complete."""
+
+    def __init__(self, folder: str, start: int, end: int, cap: int, bs: int, on_gpu: bool, depth: int = 4):
+        import queue
+        self.folder, self.end, self.cap, self.bs, self.on_gpu = folder, end, cap, bs, on_gpu
+        self.file_start, self.rows, self.ids, self.buf = start, 0, [], None
+        self.free: "queue.Queue" = queue.Queue()
+        self.work: "queue.Queue" = queue.Queue()
+        self.depth, self.made, self.error = depth, 0, None
+        self.thread = threading.Thread(target=self._run, daemon=True, name="kirag-amd-shard-writer")
+        self.thread.start()
+
+    def host_buffer(self, hidden: int) -> torch.Tensor:
+        """A pinned [bs, hidden] landing buffer; blocks while all ``depth`` of them are still waiting to be consumed."""
+        if self.made < self.depth and self.free.empty():
+            self.made += 1
+            return torch.empty((self.bs, hidden), dtype=torch.float32, pin_memory=self.on_gpu)
+        while True:
+            self.check()
+            try:
+                return self.free.get(timeout=0.2)
+            except Exception:   # queue.Empty
+                continue
+
+    def put(self, event, host: torch.Tensor, n_rows: int, ids) -> None:
+        self.work.put((event, host, n_rows, ids))
+
+    def check(self) -> None:
+        if self.error is not None:
+            raise self.error
+
+    def _flush(self) -> None:
+        if not self.ids:
+            return
+        upto = self.file_start + self.rows
+        emb = self.buf if self.rows == self.buf.shape[0] else self.buf[:self.rows].clone()
+        logger.info(f"Finished calculating embeddings from {self.file_start} to {upto - 1}. Saving embeddings to {self.folder} ...")
+        with open(os.path.join(self.folder, f"corpus_embeddings_{self.file_start}_{upto - 1}.pkl"), "wb") as f:
+            pickle.dump(emb, f)
+        with open(os.path.join(self.folder, f"passage_id_list_{self.file_start}_{upto - 1}.pkl"), "wb") as f:
+            pickle.dump(self.ids, f)
+        self.file_start, self.rows, self.ids, self.buf = upto, 0, [], None
+
+    def _append(self, emb: torch.Tensor, ids) -> None:
+        while len(ids):
+            if self.buf is None:
+                self.buf = torch.empty((max(1, min(self.cap, self.end - self.file_start)), emb.shape[1]), dtype=torch.float32)
+            take = min(len(ids), self.buf.shape[0] - self.rows)
+            self.buf[self.rows:self.rows + take].copy_(emb[:take])
+            self.ids.extend(ids[:take]); self.rows += take
+            emb, ids = emb[take:], ids[take:]
+            if self.rows == self.buf.shape[0]:
+                self._flush()
+
+    def _run(self) -> None:
+        while True:
+            item = self.work.get()
+            if item is None:
+                return
+            event, host, n_rows, ids = item
+            try:
+                if self.error is None:
+                    if event is not None:
+                        event.synchronize()
+                    self._append(host[:n_rows], list(ids))
+            except BaseException as e:   # noqa: BLE001 - re-raised on the encode thread
+                self.error = e
+            self.free.put(host)
+
+    def close(self, flush: bool = True) -> None:
+        self.work.put(None)
+        self.thread.join()
+        if flush and self.error is None:
+            self._flush()
+        self.check()
+
+
 def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, world: int = 1, indexer=None, device: Optional[torch.device] = None):
     """Encode this rank's contiguous shard of ``corpus_dataset`` (items ``{"index": int, "passage": str}`` plus
     ``index_to_passage_id``), write the reference's shard files, and (optionally) add the rows to a resident ``indexer``.
-    Returns ``(start, end)`` of the rows handled."""
+    Returns ``(start, end)`` of the rows handled.
+
+    The loop is a three-stage pipeline in which the one Python thread that launches the encoder does nothing else (it used to un-pickle padded
+    int64 batches, pin each of them, validate, clone and buffer — a quarter of the encoder's rate was lost here): ``feed.TokenFeed`` puts RAGGED int32 token
+    frames into a pinned ring (tokenizer processes; ids validated where they are produced), ``model.doc_packed`` enqueues upload + forward
+    (``kr_encoder_forward_packed``: rows bit-identical to the padded forward) and the append to the resident shard, and ``_ShardWriter`` takes the rows off
+    the GPU and into the ``.pkl`` files on its own thread."""
     if device is None:
         device = torch.device("cuda:0") if args.local_rank < 0 else torch.device(f"cuda:{args.local_rank}")
     model = model.to(device)
@@ -69,98 +169,82 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
     start, end = shard_range(len(corpus_dataset), rank, world)
     bs = max(int(getattr(args, "encode_batch_size", 512)), int(args.per_gpu_batch_size))
     cap = int(args.num_passage_per_index_file)
-    buf, buf_ids, file_start = [], [], start
-
-    def flush(upto):
-        nonlocal buf, buf_ids, file_start
-        if not buf_ids:
-            return
-        emb = torch.cat(buf, dim=0)
-        logger.info(f"Finished calculating embeddings from {file_start} to {upto - 1}. Saving embeddings to {folder} ...")
-        with open(os.path.join(folder, f"corpus_embeddings_{file_start}_{upto - 1}.pkl"), "wb") as f:
-            pickle.dump(emb, f)
-        with open(os.path.join(folder, f"passage_id_list_{file_start}_{upto - 1}.pkl"), "wb") as f:
-            pickle.dump(buf_ids, f)
-        buf, buf_ids, file_start = [], [], upto
-
-    def collate(s):                                          # runs on the prefetch thread (or in a worker process): dataset access + tokenisation
-        items = [corpus_dataset[i] for i in range(s, min(s + bs, end))]
-        return collator.encode_doc([it["passage"] for it in items]), [corpus_dataset.index_to_passage_id[it["index"]] for it in items]
-
     write_files = not bool(getattr(args, "no_embedding_files", False))
     depth = int(getattr(args, "prefetch_batches", 2))
-    workers = int(getattr(args, "tokenizer_workers", 0))
     batches = range(start, end, bs)
-    def make_texts(s):
-        items = [corpus_dataset[i] for i in range(s, min(s + bs, end))]
-        return [it["passage"] for it in items], [corpus_dataset.index_to_passage_id[it["index"]] for it in items]
-    source = pool_map(make_texts, collator, batches, workers, depth) if workers > 0 else prefetch_map(collate, batches, depth=depth)
-    # The GPU side never waits for the host inside the loop: inputs go up from pinned memory, the forward (device output: asynchronous,
-    # kr_encoder_forward) and the append to the resident shard are enqueued on the current stream, the embeddings come down into a small ring of
-    # pinned buffers behind an event; the host consumes batch i - 2 (file buffers) while batch i is being encoded.
-    ring, pending = [], []
-
-    def drain(keep):
-        nonlocal buf, buf_ids, file_start
-        while len(pending) > keep:
-            ev, host, n_rows, ids = pending.pop(0)
-            ev.synchronize()
-            emb = host[:n_rows].clone()
-            ring.append(host)
-            while len(buf_ids) + len(ids) > cap:             # respect the per-file row cap
-                take = cap - len(buf_ids)
-                buf.append(emb[:take]); buf_ids.extend(ids[:take])
-                flush(file_start + cap)
-                emb, ids = emb[take:], ids[take:]
-            buf.append(emb); buf_ids.extend(ids)
-            if len(buf_ids) == cap:
-                flush(file_start + cap)
-
-    class _Done:                                             # event stand-in for a host-only model (the CPU tests of the file contract)
-        def synchronize(self): pass
     on_gpu = torch.device(device).type == "cuda"
-    hidden = None
+    workers = int(getattr(args, "tokenizer_workers", -1))
+    if workers < 0:
+        workers = default_tokenizer_workers(len(batches), on_gpu)
+    use_packed = on_gpu and hasattr(model, "doc_packed") and not bool(getattr(args, "padded_feed", False))
     # Token ids are validated on the HOST, before the batch goes anywhere: the HIP forward reports an id outside the vocabulary only after the fact
     # (deferred error word, enc.check() below), by which time the batch's rows would already sit in the resident shard and in the .pkl buffers.
     vocab = getattr(getattr(getattr(model, "encoder", None), "config", None), "vocab_size", None)
     vocab = int(getattr(args, "vocab_size", 0) or 0) or (int(vocab) if vocab else None)
 
-    def validate(cpu_inputs, ids):
-        t = cpu_inputs.get("input_ids") if isinstance(cpu_inputs, dict) else None
-        if vocab is None or not torch.is_tensor(t) or t.is_cuda or t.numel() == 0:
-            return
-        # ATTENDED positions only: the HIP forward never reads a masked id (k_fill_tokens packs attended positions), and __main__ may add a
-        # '[PAD]' token whose id == len(tokenizer) >= the model's vocab_size when the tokenizer has no pad token — a padded batch is not an error
-        m = cpu_inputs.get("attention_mask")
-        if torch.is_tensor(m) and m.shape == t.shape:
-            t = t[m.bool()]
-            if t.numel() == 0:
-                return
-        lo, hi = int(t.min()), int(t.max())
-        if lo < 0 or hi >= vocab:
-            raise ValueError(f"input_ids of the batch starting at passage id {ids[0] if ids else '?'} contain a token id outside [0, {vocab}) "
-                             f"(min {lo}, max {hi}): nothing of this batch was encoded, indexed or written")
-    for cpu_inputs, ids in source:
-        validate(cpu_inputs, ids)
-        if on_gpu:
-            inputs = {k: (v.pin_memory().to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in cpu_inputs.items()}
-        else:
-            inputs = to_device(cpu_inputs, device)
-        emb = model.doc(inputs).detach()                     # HIP path (eval mode), stays on the GPU; no host synchronisation
-        if indexer is not None:
-            indexer.index_data(ids, emb)                     # device-to-device append into the resident shard (stream-ordered)
-        if write_files:
-            hidden = emb.shape[1]
-            host = ring.pop() if ring and ring[-1].shape[0] >= emb.shape[0] else torch.empty((bs, hidden), dtype=torch.float32, pin_memory=on_gpu)
-            host[:emb.shape[0]].copy_(emb, non_blocking=on_gpu)
-            if on_gpu:
-                ev = torch.cuda.Event(); ev.record()
+    def make_texts(s):                                       # dataset access: this process (a serve thread of the feed, or the prefetch thread)
+        items = [corpus_dataset[i] for i in range(s, min(s + bs, end))]
+        return [it["passage"] for it in items], [corpus_dataset.index_to_passage_id[it["index"]] for it in items]
+
+    def collate_checked(s):                                  # host-only models (the CPU tests of the file contract): the collator's own dict, validated here
+        texts, ids = make_texts(s)
+        enc = collator.encode_doc(texts)
+        if vocab is not None and torch.is_tensor(enc.get("input_ids")) and enc["input_ids"].numel():
+            r = feed.attended_range(feed.tokens_of(enc)) if torch.is_tensor(enc.get("attention_mask")) and enc["attention_mask"].shape == enc["input_ids"].shape \
+                else (int(enc["input_ids"].min()), int(enc["input_ids"].max()))
+            if r is not None and (r[0] < 0 or r[1] >= vocab):
+                raise ValueError(feed.bad_id_message(ids[0] if ids else "?", vocab, r[0], r[1]))
+        return enc, ids
+
+    tokens = None
+    if use_packed or workers > 0:
+        max_len = int(getattr(collator, "doc_maxlength", 512) or 512)
+        tokens = feed.TokenFeed(make_texts, collator, batches, workers, depth, bs, max_len, vocab=vocab, pinned=on_gpu)
+        source = tokens
+    else:
+        source = prefetch_map(collate_checked, batches, depth=depth)
+    writer = _ShardWriter(folder, start, end, cap, bs, on_gpu) if write_files else None
+    pad_id = getattr(getattr(collator, "tokenizer", None), "pad_token_id", None) or 0
+    ok = False
+    try:
+        for item in source:
+            ev_in = None
+            if tokens is not None:
+                frame, ids = item, item.doc_ids
+                if use_packed and frame.kind == feed.KIND_RAGGED:
+                    emb = model.doc_packed(frame.ids, frame.lens, frame.S, frame.T).detach()    # upload from the pinned slot + forward, enqueue-only
+                else:
+                    cpu_inputs = frame.inputs(pad_id)
+                    inputs = {k: (v.pin_memory().to(device, non_blocking=True) if on_gpu else v.to(device)) for k, v in cpu_inputs.items()}
+                    emb = model.doc(inputs).detach()
+                if on_gpu:
+                    ev_in = torch.cuda.Event(); ev_in.record()
+                tokens.release(frame, ev_in)
             else:
-                ev = _Done()
-            pending.append((ev, host, emb.shape[0], ids))
-            drain(2)
-    drain(0)
-    flush(end)
+                cpu_inputs, ids = item
+                emb = model.doc(to_device(cpu_inputs, device)).detach()
+            if indexer is not None:
+                indexer.index_data(ids, emb)                     # device-to-device append into the resident shard (stream-ordered)
+            if writer is not None:
+                writer.check()
+                host = writer.host_buffer(emb.shape[1])
+                host[:emb.shape[0]].copy_(emb, non_blocking=on_gpu)
+                ev = None
+                if on_gpu:
+                    ev = torch.cuda.Event(); ev.record()
+                writer.put(ev, host, emb.shape[0], ids)
+        ok = True
+    finally:
+        if tokens is not None:
+            tokens.close()
+        if writer is not None:
+            if ok:
+                writer.close()
+            else:
+                try:
+                    writer.close(flush=False)    # complete files written so far stay; the partial buffer is dropped, as when the reference's loop dies
+                except BaseException:   # noqa: BLE001 - the loop's own exception is the one to report
+                    pass
     enc = getattr(getattr(model, "encoder", None), "_hip", None)
     if enc is not None:
         enc.check()                                          # token ids outside the vocabulary surface here at the latest
@@ -168,82 +252,13 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
 
 
 def pool_map(make_texts, collator, items, workers: int, depth: int):
-    """Ordered map over ``workers`` tokenizer PROCESSES (``python -m kirag_amd.tokenize_worker``, started as plain child processes: no fork of a
-    process that holds a GPU context and a tokenizer thread pool, no re-import of the caller's ``__main__``).  For every item the parent builds the
-    batch's strings (``make_texts(item) -> (texts, ids)``: dataset access stays in the parent), worker ``j % workers`` tokenises batch j with its own
-    copy of the collator (one Rust thread each), and the batches are yielded in order, at most ``workers + depth`` ahead of the consumer."""
-    import struct
-    import subprocess
-    import sys
-    import threading
-    import numpy as np
+    """Ordered map over ``workers`` tokenizer PROCESSES, yielding ``({"input_ids", "attention_mask"} int64 [n,S], ids)`` per item — the round 3-5 interface, kept
+    as a thin wrapper over ``feed.TokenFeed`` (the frames travel ragged and are re-padded here; ``cal_doc_embeddings`` consumes the frames directly)."""
     items = list(items)
-    env = dict(os.environ, TOKENIZERS_PARALLELISM="false", PYTHONPATH=os.pathsep.join(
-        [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p]))
-    procs = [subprocess.Popen([sys.executable, "-m", "kirag_amd.tokenize_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
-             for _ in range(min(workers, max(1, len(items))))]
-    blob = pickle.dumps(collator)
-
-    def send(p, payload):
-        p.stdin.write(struct.pack("<Q", len(payload))); p.stdin.write(payload); p.stdin.flush()
-
-    def recv(p):
-        head = p.stdout.read(8)
-        if len(head) != 8:
-            raise RuntimeError("tokenizer worker exited unexpectedly")
-        (n,) = struct.unpack("<Q", head)
-        return pickle.loads(p.stdout.read(n))
-    results, cond, failed = {}, threading.Condition(), []
-    window = len(procs) + max(1, depth)
-    consumed = [0]
-
-    def serve(w):
-        p = procs[w]
-        try:
-            send(p, blob)
-            for j in range(w, len(items), len(procs)):
-                with cond:
-                    cond.wait_for(lambda: j < consumed[0] + window or failed)
-                    if failed:
-                        return
-                texts, ids = make_texts(items[j])
-                send(p, pickle.dumps(texts))
-                out = recv(p)
-                if isinstance(out, str):
-                    raise RuntimeError("tokenizer worker: " + out)
-                ii, mm = out
-                with cond:
-                    results[j] = ({"input_ids": torch.from_numpy(ii.astype(np.int64)), "attention_mask": torch.from_numpy(mm.astype(np.int64))}, ids)
-                    cond.notify_all()
-        except BaseException as e:   # noqa: BLE001 - forwarded to the consumer
-            with cond:
-                failed.append(e); cond.notify_all()
-    threads = [threading.Thread(target=serve, args=(w,), daemon=True) for w in range(len(procs))]
-    for t in threads:
-        t.start()
-    try:
-        for j in range(len(items)):
-            with cond:
-                cond.wait_for(lambda: j in results or failed)
-                if failed:
-                    raise failed[0]
-                out = results.pop(j)
-                consumed[0] = j + 1
-                cond.notify_all()
-            yield out
-    finally:
-        with cond:
-            failed.append(GeneratorExit()); cond.notify_all()
-        for p in procs:
-            try:
-                p.stdin.close()
-            except Exception:
-                pass
-        for p in procs:
-            try:
-                p.wait(timeout=10)
-            except Exception:
-                p.kill()
+    pad_id = getattr(getattr(collator, "tokenizer", None), "pad_token_id", None) or 0
+    tf = feed.TokenFeed(make_texts, collator, items, max(1, workers), depth, 1, 1)
+    for frame in tf:
+        yield frame.inputs(pad_id), frame.doc_ids
 
 
 def main(argv=None):

@@ -283,6 +283,97 @@ __global__ __launch_bounds__(1024) void k_pack_small(const int64_t* __restrict__
     }
 }
 
+// ---- ragged input (kr_encoder_forward_packed): ids32 = the attended tokens of every sequence back to back, lens[b] = how many belong to sequence b, at
+// positions 0 .. lens[b]-1 (what a right-padding tokenizer produces: collators.py:59-81 with padding=True).  These kernels fill exactly the tables the
+// padded-input kernels above fill for the equivalent [B,S] batch (mask[b,p] = p < lens[b]), so everything behind them is the same code on the same data.
+// A length outside [0, S], or lengths that do not add up to `total`, set error bit 8 and the sequence is read as empty (nothing is read out of bounds).
+__device__ __forceinline__ void rag_fill_one(const int* __restrict__ src, int n_in, int n, int o, int vocab, int align, int lane, int* __restrict__ tok_id,
+                                             int* __restrict__ tok_pos, int* __restrict__ tok_type, int* __restrict__ err) {
+    for (int p = lane; p < n_in; p += 64) {
+        int id = src[p];
+        if (id < 0 || id >= vocab) { atomicOr(err, 1); id = 0; }
+        tok_id[o + p] = id; tok_pos[o + p] = p; tok_type[o + p] = 0;
+    }
+    // CLS pooling of an empty sequence: the query-only row for position 0 reads token id 0 (the padded call with input_ids padded by [PAD] = 0)
+    if (lane == 0 && n > n_in) { tok_id[o + n_in] = 0; tok_pos[o + n_in] = 0; tok_type[o + n_in] = 0; }
+    const int padded = (n + align - 1) & ~(align - 1);
+    if (lane < padded - n) { tok_id[o + n + lane] = 0; tok_pos[o + n + lane] = 0; tok_type[o + n + lane] = 0; }
+}
+
+// one wave: k_seq_len + k_seq_scan of the ragged form, plus the exclusive scan of the raw lengths (where each sequence starts in ids32)
+__global__ __launch_bounds__(64) void k_rag_scan(const int* __restrict__ lens, int B, int S, int total, int pool, int align, int* __restrict__ nk, int* __restrict__ has0,
+                                                 int* __restrict__ nq, int* __restrict__ off, int* __restrict__ cls, int* __restrict__ in_off, int* __restrict__ T,
+                                                 int* __restrict__ err) {
+    const int lane = threadIdx.x;
+    int carry = 0, carry_in = 0;
+    bool bad = false;
+    for (int base = 0; base < B; base += 64) {
+        const int b = base + lane;
+        int len = (b < B) ? lens[b] : 0;
+        if (len < 0 || len > S) { bad = true; len = 0; }
+        int incl_in = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl_in, d, 64); if (lane >= d) incl_in += t; }
+        const int start = carry_in + incl_in - len;
+        if (start + len > total) { bad = true; len = 0; }          // never read past the caller's buffer (the following starts keep the caller's lengths)
+        int n = 0;
+        if (b < B) {
+            n = len + ((pool == KR_POOL_CLS && len == 0) ? 1 : 0);
+            nk[b] = len; has0[b] = len > 0 ? 1 : 0; nq[b] = n; cls[b] = 0; in_off[b] = start;
+        }
+        const int padded = (n + align - 1) & ~(align - 1);
+        int incl = padded;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (b < B) off[b] = carry + incl - padded;
+        carry += __shfl(incl, 63, 64);
+        carry_in += __shfl(incl_in, 63, 64);
+    }
+    if (__ballot(bad) != 0ull || carry_in != total) { if (lane == 0) atomicOr(err, 8); }
+    if (lane == 0) *T = carry;
+}
+
+__global__ __launch_bounds__(64) void k_rag_fill(const int* __restrict__ ids32, int vocab, int align, const int* __restrict__ in_off, const int* __restrict__ off,
+                                                 const int* __restrict__ nk, const int* __restrict__ nq, int* __restrict__ tok_id, int* __restrict__ tok_pos,
+                                                 int* __restrict__ tok_type, int* __restrict__ err) {
+    const int b = blockIdx.x;
+    rag_fill_one(ids32 + in_off[b], nk[b], nq[b], off[b], vocab, align, threadIdx.x, tok_id, tok_pos, tok_type, err);
+}
+
+// both as ONE single-block launch for B <= PACK_SMALL_B (the ragged twin of k_pack_small)
+__global__ __launch_bounds__(1024) void k_rag_small(const int* __restrict__ ids32, const int* __restrict__ lens, int B, int S, int total, int vocab, int pool, int align,
+                                                    int* __restrict__ nk, int* __restrict__ has0, int* __restrict__ nq, int* __restrict__ off, int* __restrict__ cls,
+                                                    int* __restrict__ T, int* __restrict__ tok_id, int* __restrict__ tok_pos, int* __restrict__ tok_type, int* __restrict__ err) {
+    __shared__ int s_nk[PACK_SMALL_B], s_nq[PACK_SMALL_B], s_off[PACK_SMALL_B], s_in[PACK_SMALL_B];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        const int b = lane;
+        int len = (b < B) ? lens[b] : 0;
+        bool bad = false;
+        if (len < 0 || len > S) { bad = true; len = 0; }
+        int incl_in = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl_in, d, 64); if (lane >= d) incl_in += t; }
+        const int start = incl_in - len;
+        if (start + len > total) { bad = true; len = 0; }
+        int n = 0;
+        if (b < B) {
+            n = len + ((pool == KR_POOL_CLS && len == 0) ? 1 : 0);
+            nk[b] = len; has0[b] = len > 0 ? 1 : 0; nq[b] = n; cls[b] = 0; s_nk[b] = len; s_nq[b] = n; s_in[b] = start;
+        }
+        const int padded = (n + align - 1) & ~(align - 1);
+        int incl = padded;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (b < B) { off[b] = incl - padded; s_off[b] = incl - padded; }
+        const int sum_in = __shfl(incl_in, 63, 64);
+        if (__ballot(bad) != 0ull || sum_in != total) { if (lane == 0) atomicOr(err, 8); }
+        if (lane == 63) *T = incl;
+    }
+    __syncthreads();
+    for (int b = wave; b < B; b += 16) rag_fill_one(ids32 + s_in[b], s_nk[b], s_nq[b], s_off[b], vocab, align, lane, tok_id, tok_pos, tok_type, err);
+}
+
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -1797,7 +1888,7 @@ __global__ __launch_bounds__(256) void k_gather_cls(const uint16_t* __restrict__
 }
 
 // every kernel of one forward, enqueued on `st` (inputs already in e->d_ids / e->d_mask, result left in e->out)
-static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, bool has_tt = false) {
+static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, bool has_tt = false, int ragged_total = -1) {
     const int H = e->cfg.hidden, FF = e->cfg.intermediate;
     const float eps = e->cfg.ln_eps;
     e->kn.read();
@@ -1805,7 +1896,21 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, b
     const bool long_seq = (nqt_max > 4 && !e->kn.attn_lds) || e->kn.attn_dma;   // KIRAG_AMD_ATTN_DMA=1: the ring kernel for short sequences too (A/B)
             // > 128 tokens: the LDS-DMA attention kernel (KIRAG_AMD_ATTN_LDS=1: A/B against the register-staged one)
     const int align = long_seq ? 8 : 4;                                            // sequence offsets: multiple of 8 tokens so that V^T chunks start 16-B aligned
-    if (B <= PACK_SMALL_B) {
+    if (ragged_total >= 0) {
+        // kr_encoder_forward_packed: e->d_ids holds the int32 token list, e->d_mask the int32 lengths, e->d_tt is scratch for the input offsets
+        const int* ids32 = reinterpret_cast<const int*>(e->d_ids);
+        const int* lens = reinterpret_cast<const int*>(e->d_mask);
+        int* in_off = reinterpret_cast<int*>(e->d_tt);
+        if (B <= PACK_SMALL_B) {
+            hipLaunchKernelGGL(k_rag_small, dim3(1), dim3(1024), 0, st, ids32, lens, B, S, ragged_total, e->cfg.vocab, pool, align, e->seq_nk, e->seq_has0, e->seq_nq,
+                               e->seq_off, e->seq_cls, e->d_T, e->tok_id, e->tok_pos, e->tok_type, e->d_err);
+        } else {
+            hipLaunchKernelGGL(k_rag_scan, dim3(1), dim3(64), 0, st, lens, B, S, ragged_total, pool, align, e->seq_nk, e->seq_has0, e->seq_nq, e->seq_off, e->seq_cls,
+                               in_off, e->d_T, e->d_err);
+            hipLaunchKernelGGL(k_rag_fill, dim3(B), dim3(64), 0, st, ids32, e->cfg.vocab, align, in_off, e->seq_off, e->seq_nk, e->seq_nq, e->tok_id, e->tok_pos,
+                               e->tok_type, e->d_err);
+        }
+    } else if (B <= PACK_SMALL_B) {
         hipLaunchKernelGGL(k_pack_small, dim3(1), dim3(1024), 0, st, e->d_ids, e->d_mask, has_tt ? e->d_tt : nullptr, B, S, e->cfg.vocab, e->cfg.type_vocab, pool, align,
                            e->seq_nk, e->seq_has0, e->seq_nq, e->seq_off, e->seq_cls, e->d_T, e->tok_id, e->tok_pos, e->tok_type, e->d_err);
     } else {
@@ -1936,6 +2041,7 @@ static int report_token_error(Encoder* e, hipStream_t st) {
     KR_HIP(hipMemsetAsync(e->d_err, 0, sizeof(int), st));
     if (w & 1) return fail(KR_EINVAL, "input_ids contain a token id outside [0, %d)", e->cfg.vocab);
     if (w & 4) return fail(KR_EINVAL, "token_type_ids contain a value outside [0, %d)", e->cfg.type_vocab);
+    if (w & 8) return fail(KR_EINVAL, "seq_lens hold a length outside [0, S] or do not add up to total_tokens (kr_encoder_forward_packed)");
 #ifdef KR_ENC_BUILD_F16
     return fail(KR_ERANGE, "non-finite activations in the forward: a value left the f16 operand range (|x| > 65504) or the weights hold NaN / Inf; "
                            "the embeddings of this batch are not usable (KIRAG_AMD_ENCODER_DTYPE=bf16 has the fp32 exponent range)");
@@ -1979,6 +2085,44 @@ int enc_forward(void* h, const int64_t* input_ids, const int64_t* attention_mask
         return 0;
     }
     KR_HIP(hipStreamSynchronize(st));   // a host pointer is returned: the caller reads it as soon as we return
+    e->pending = false;
+    return report_token_error(e, st);
+}
+
+// kr_encoder_forward_packed: the same forward from the ragged token list (int32 ids of the attended positions + int32 length per sequence)
+int enc_forward_packed(void* h, const int32_t* token_ids, const int32_t* seq_lens, int B, int S, int64_t total_tokens, int pool, float* out, void* stream) {
+    if (!h) return fail(KR_EINVAL, "encoder is NULL");
+    Encoder* e = reinterpret_cast<Encoder*>(h);
+    if (!e->ready) return fail(KR_ESTATE, "encoder weights incomplete: call kr_encoder_finalize after loading every tensor");
+    if (B < 0 || S <= 0 || total_tokens < 0 || (B > 0 && (!seq_lens || !out)) || (total_tokens > 0 && !token_ids)) return fail(KR_EINVAL, "bad input pointers / shape");
+    if (S > e->cfg.max_pos) return fail(KR_EINVAL, "sequence length %d exceeds max_position_embeddings %d", S, e->cfg.max_pos);
+    if (total_tokens > (int64_t)B * S) return fail(KR_EINVAL, "total_tokens %lld exceeds B * S = %lld", (long long)total_tokens, (long long)B * S);
+    if (pool != KR_POOL_MEAN && pool != KR_POOL_CLS) return fail(KR_EINVAL, "pool must be 0 (mean) or 1 (cls)");
+    if (B == 0) return 0;
+    if (B > 65535) return fail(KR_EINVAL, "at most 65535 sequences per call");
+    KR_TRY(select_device(e->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (e->pending) {
+        if (st != e->last_stream) KR_HIP(hipEventSynchronize(e->ev_done));
+        if (hipEventQuery(e->ev_done) == hipSuccess) {
+            e->pending = false;
+            KR_TRY(report_token_error(e, st));
+        }
+    }
+    KR_TRY(ensure_ws(e, B, S));
+    const int H = e->cfg.hidden;
+    if (total_tokens > 0) KR_HIP(hipMemcpyAsync(e->d_ids, token_ids, (size_t)total_tokens * 4, hipMemcpyDefault, st));
+    KR_HIP(hipMemcpyAsync(e->d_mask, seq_lens, (size_t)B * 4, hipMemcpyDefault, st));
+    KR_TRY(enqueue_forward(e, B, S, pool, st, false, (int)total_tokens));
+    KR_HIP(hipMemcpyAsync(out, e->out, (size_t)B * H * 4, hipMemcpyDefault, st));
+    e->lastB = B; e->lastS = S; e->last_stream = st;
+    KR_HIP(hipMemcpyAsync(e->h_err, e->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (is_device_pointer(out)) {
+        KR_HIP(hipEventRecord(e->ev_done, st));
+        e->pending = true;
+        return 0;
+    }
+    KR_HIP(hipStreamSynchronize(st));
     e->pending = false;
     return report_token_error(e, st);
 }

@@ -13,6 +13,7 @@ namespace kr {
     int enc_load_weight(void* h, const char* hf_name, const float* data, int64_t numel);                                                     \
     int enc_finalize(void* h);                                                                                                               \
     int enc_forward(void* h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids, int B, int S, int pool, float* out, void* stream); \
+    int enc_forward_packed(void* h, const int32_t* token_ids, const int32_t* seq_lens, int B, int S, int64_t total_tokens, int pool, float* out, void* stream); \
     int enc_check(void* h);                                                                                                                  \
     int enc_last_hidden(void* h, float* out, int B, int S);                                                                                  \
     }
@@ -81,6 +82,11 @@ int kr_encoder_forward_tt(kr_encoder* e, const int64_t* input_ids, const int64_t
                           void* stream) {
     if (!e) return fail(KR_EINVAL, "encoder is NULL");
     return KR_ENC_CALL(reinterpret_cast<EncHandle*>(e), enc_forward, input_ids, attention_mask, token_type_ids, B, S, pool, out, stream);
+}
+int kr_encoder_forward_packed(kr_encoder* e, const int32_t* token_ids, const int32_t* seq_lens, int B, int S, int64_t total_tokens, int pool, float* out,
+                              void* stream) {
+    if (!e) return fail(KR_EINVAL, "encoder is NULL");
+    return KR_ENC_CALL(reinterpret_cast<EncHandle*>(e), enc_forward_packed, token_ids, seq_lens, B, S, total_tokens, pool, out, stream);
 }
 int kr_encoder_check(kr_encoder* e) {
     if (!e) return fail(KR_EINVAL, "encoder is NULL");

@@ -147,6 +147,25 @@ class HipBertForward:
             _lib.check(self._lib.kr_encoder_forward_tt(self._h, ids.data_ptr(), mask.data_ptr(), tt.data_ptr(), B, S, pool, out.data_ptr(), stream))
         return out
 
+    def forward_packed(self, token_ids, seq_lens, S: int, pool: int, total_tokens: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
+        """The forward from RAGGED input (``kr_encoder_forward_packed``): ``token_ids`` int32 = the attended ids of every sequence back to back, ``seq_lens`` int32
+        [B] = how many belong to each (positions 0..len-1, a right-padded batch without its padding), ``S`` = the padded width of the equivalent batch.
+        Rows are bit-identical to ``forward`` on that batch.  Tensors may live on the host (pinned: the upload is asynchronous) or on the encoder's GPU;
+        the result is a device tensor, enqueued on torch's current stream.  ``total_tokens``: use only the first that many entries of ``token_ids``."""
+        if token_ids.dtype != torch.int32 or seq_lens.dtype != torch.int32 or not token_ids.is_contiguous() or not seq_lens.is_contiguous():
+            raise TypeError("token_ids / seq_lens must be contiguous int32 tensors")
+        B = int(seq_lens.numel())
+        T = int(token_ids.numel()) if total_tokens is None else int(total_tokens)
+        if T > token_ids.numel():
+            raise ValueError(f"total_tokens {T} exceeds the {token_ids.numel()} entries of token_ids")
+        dev = torch.device("cuda", self.device_index)
+        if out is None:
+            out = torch.empty((B, self.hidden), dtype=torch.float32, device=dev)
+        with torch.cuda.device(self.device_index):
+            _lib.check(self._lib.kr_encoder_forward_packed(self._h, token_ids.data_ptr(), seq_lens.data_ptr(), B, int(S), T, pool, out.data_ptr(),
+                                                           _lib.current_stream_ptr()))
+        return out
+
     def check(self) -> None:
         """Wait for the last device-output forward and raise if it saw a token id outside the vocabulary, a token type outside the type vocabulary, or
         non-finite activations (``kr_encoder_check``)."""
@@ -180,6 +199,21 @@ class _HipSentenceEncoder(BertModel):
         self._hip.sync(self)
         with torch.cuda.device(idx):
             return self._hip.forward(input_ids.to(p.device), attention_mask, self._pool, token_type_ids)   # token types go to the kernels (kr_encoder_forward_tt)
+
+    def forward_packed(self, token_ids: Tensor, seq_lens: Tensor, max_len: int, total_tokens: Optional[int] = None) -> Tensor:
+        """Sentence embeddings [B, hidden] from the ragged token list of a right-padded batch (int32 attended ids back to back + int32 lengths; see
+        ``HipBertForward.forward_packed``) — what the tokenizer processes of ``compute_corpus_embeddings`` ship instead of padded int64 ``input_ids`` +
+        ``attention_mask``.  Bit-identical to ``forward(input_ids, attention_mask)`` on the padded batch; eval mode only (the HIP path)."""
+        if self.training:
+            raise RuntimeError("forward_packed is the inference (HIP) path: call model.eval() first")
+        p = next(self.parameters())
+        if not p.is_cuda:
+            raise RuntimeError(f"{type(self).__name__} in eval mode runs on the MI355X HIP path only; its parameters are on {p.device}.")
+        idx = p.device.index if p.device.index is not None else torch.cuda.current_device()
+        if self._hip is None or self._hip.device_index != idx:
+            self._hip = HipBertForward(self.config, idx)
+        self._hip.sync(self)
+        return self._hip.forward_packed(token_ids, seq_lens, max_len, self._pool, total_tokens)
 
     def invalidate_hip_weights(self) -> None:
         if self._hip is not None:

@@ -106,6 +106,12 @@ class BaseRetriever(nn.Module):
         emb = self.encoder_embed(args, **kwargs)
         return torch.nn.functional.normalize(emb, dim=-1) if self.norm_doc else emb
 
+    def doc_packed(self, token_ids, seq_lens, max_len, total_tokens=None):
+        """``doc`` from the ragged token list of a right-padded batch (``encoders.forward_packed``): the corpus-encode loop's feed
+        (``kirag_amd.compute_corpus_embeddings``) ships tokens in this form; same rows, bit for bit, as ``doc({"input_ids", "attention_mask"})``."""
+        emb = self.encoder.forward_packed(token_ids, seq_lens, max_len, total_tokens)
+        return torch.nn.functional.normalize(emb, dim=-1) if self.norm_doc else emb
+
     def save_model(self, save_path):
         self.encoder.save_pretrained(save_path)
 

@@ -1,10 +1,12 @@
-"""Tokenizer worker process of ``compute_corpus_embeddings.pool_map`` (multi-process tokenisation).
+"""Tokenizer worker process of ``kirag_amd.feed.TokenFeed`` (multi-process tokenisation for ``cal_doc_embeddings``).
 
-Protocol on stdin / stdout, every message = u64 little-endian length + pickle:
-  first message   the collator (``kirag_amd.collators.E5Collator`` / ``BGECollator`` with its HF tokenizer)
-  then, per batch a list of passage strings -> reply ``(input_ids int32 [n, S], attention_mask uint8 [n, S])`` = ``collator.encode_doc(texts)``
-                  (``dataset/collators.py:59-81,143-145`` semantics: prefix, pad to the longest of the batch, truncate at doc_maxlength),
-                  or a string with the error message.
+Protocol on stdin / stdout (``kirag_amd.feed`` holds the other end and the frame layout):
+  first message   u64 length + pickle of ``{"collator": E5Collator / BGECollator with its HF tokenizer, "vocab": int or None}``
+  then, per batch u64 length + pickle of the list of passage strings  ->  one binary FRAME (``feed.pack_frame``): the batch as ``collator.encode_doc(texts)``
+                  yields it (``dataset/collators.py:59-81,143-145`` semantics: prefix, pad to the longest of the batch, truncate at doc_maxlength), but RAGGED -
+                  int32 lengths + the int32 ids of the attended positions back to back, 4-16x fewer bytes than padded int64 ``input_ids`` + ``attention_mask``,
+                  no pickle - or, for a tokenizer that does not pad on the right, the padded ids and mask; or an error frame.
+Token ids are validated against ``vocab`` HERE (attended positions only), so the consumer thread of the encode loop does no per-batch reductions.
 The process never touches the GPU and exits when stdin closes."""
 import pickle
 import struct
@@ -22,22 +24,22 @@ def main() -> None:
         (n,) = struct.unpack("<Q", head)
         return pickle.loads(inp.read(n))
 
-    def send(obj):
-        b = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
-        out.write(struct.pack("<Q", len(b))); out.write(b); out.flush()
-    collator = recv()
-    if collator is None:
+    init = recv()
+    if init is None:
         return
-    import numpy as np
+    from kirag_amd import feed
+    collator, vocab = init["collator"], init.get("vocab")
     while True:
         texts = recv()
         if texts is None:
             return
         try:
-            enc = collator.encode_doc(texts)
-            send((enc["input_ids"].numpy().astype(np.int32), enc["attention_mask"].numpy().astype(np.uint8)))
+            for part in feed.pack_frame(feed.tokens_of(collator.encode_doc(texts)), vocab):
+                out.write(part)
         except Exception as e:   # noqa: BLE001 - reported to the parent
-            send(f"{type(e).__name__}: {e}")
+            for part in feed.error_frame(f"{type(e).__name__}: {e}"):
+                out.write(part)
+        out.flush()
 
 
 if __name__ == "__main__":

@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     BIND(kr_index_search) BIND(kr_index_search_async) BIND(kr_index_search_finish) BIND(kr_index_search_finish_ex) BIND(kr_index_search_pending)
     BIND(kr_index_stats)
     BIND(kr_encoder_create_ex) BIND(kr_encoder_operand_dtype) BIND(kr_encoder_residual_lo) BIND(kr_encoder_destroy) BIND(kr_encoder_load_weight)
-    BIND(kr_encoder_finalize) BIND(kr_encoder_forward) BIND(kr_encoder_forward_tt) BIND(kr_encoder_check)
+    BIND(kr_encoder_finalize) BIND(kr_encoder_forward) BIND(kr_encoder_forward_tt) BIND(kr_encoder_forward_packed) BIND(kr_encoder_check)
     if (p_kr_abi_version() != KR_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }
     if (p_kr_device_count() < 1) { printf("no GPU visible\n"); return 3; }
 
@@ -132,6 +132,29 @@ int main(int argc, char** argv) {
             CHECK(p_kr_encoder_forward_tt(enc, ids, mask, tt0, B, S, pool, emb2, NULL));
             if (memcmp(emb, emb2, (size_t)B * H * 4)) { printf("forward_tt(zeros) differs\n"); return 1; }
             free(emb2); free(tt0);
+        }
+        /* ragged input (kr_encoder_forward_packed): when the fixture's masks are right-padded, the attended ids back to back + one length per sequence give
+         * the same rows bit for bit; lengths that do not add up are KR_EINVAL */
+        {
+            int32_t* rag = malloc((size_t)B * S * 4); int32_t* lens = malloc((size_t)B * 4); int64_t T = 0; int right = 1;
+            for (int b = 0; b < B; ++b) {
+                int n = 0;
+                for (int p = 0; p < S; ++p) {
+                    if (mask[(size_t)b * S + p]) { if (p != n) right = 0; rag[T + n] = (int32_t)ids[(size_t)b * S + p]; ++n; }
+                }
+                lens[b] = n; T += n;
+            }
+            if (right) {
+                float* emb2 = malloc((size_t)B * H * 4);
+                CHECK(p_kr_encoder_forward_packed(enc, rag, lens, B, S, T, pool, emb2, NULL));
+                if (memcmp(emb, emb2, (size_t)B * H * 4)) { printf("forward_packed differs from forward\n"); return 1; }
+                if (p_kr_encoder_forward_packed(enc, rag, lens, B, S, T - 1, pool, emb2, NULL) != KR_EINVAL || !strstr(p_kr_last_error(), "seq_lens")) {
+                    printf("inconsistent lengths not reported: %s\n", p_kr_last_error()); return 1;
+                }
+                free(emb2);
+                printf("forward_packed: bit-identical to forward (%lld tokens of %d x %d)\n", (long long)T, B, S);
+            } else printf("forward_packed: fixture is not right-padded, skipped\n");
+            free(rag); free(lens);
         }
         /* a token id outside the vocabulary: reported by the host-output call itself */
         const int64_t keep = ids[1];

@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     BIND(kr_index_stats) BIND(kr_score_topk) BIND(kr_topk_merge) BIND(kr_format_ids) BIND(kr_index_search_coarse_async) BIND(kr_index_search_global_theta) BIND(kr_index_search_rerank_async) BIND(kr_topk_merge_device) BIND(kr_comm_unique_id) BIND(kr_comm_create)
     BIND(kr_comm_destroy) BIND(kr_comm_rank) BIND(kr_comm_world) BIND(kr_shard_allgather_topk) BIND(kr_encoder_create) BIND(kr_encoder_create_ex)
     BIND(kr_encoder_operand_dtype) BIND(kr_encoder_residual_lo) BIND(kr_encoder_destroy) BIND(kr_encoder_load_weight) BIND(kr_encoder_finalize)
-    BIND(kr_encoder_forward) BIND(kr_encoder_forward_tt) BIND(kr_encoder_check) BIND(kr_encoder_last_hidden)
+    BIND(kr_encoder_forward) BIND(kr_encoder_forward_tt) BIND(kr_encoder_forward_packed) BIND(kr_encoder_check) BIND(kr_encoder_last_hidden)
     if (p_kr_abi_version() != KR_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }
 
     /* argument validation happens before any device work */

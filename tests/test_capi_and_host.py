@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.kr_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.kr_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_search_stats_struct_and_options_mirror_the_header():

@@ -64,3 +64,4 @@ def test_c_only_host_drives_index_and_encoder_on_the_gpu(tmp_path):
     out = subprocess.run([exe, os.path.join(REPO, "kirag_amd", "libkirag_amd.so"), vec], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "capi_gpu ok" in out.stdout
+    assert out.stdout.count("forward_packed: bit-identical to forward") == 2      # both encoder modes, from the ragged token list (ABI 9)

@@ -437,3 +437,71 @@ def test_small_batch_forwards_replayed_as_hip_graphs_are_bit_identical():
     ref = E.e5_encode(w, ids, mask, 2)
     for _ in range(3):
         assert np.abs(h.forward_np(ids, mask, 0) - ref).max() < 4e-3    # host-pointer path through the same replay
+
+
+@pytest.mark.parametrize("B,S", [(1, 32), (5, 300), (9, 96), (64, 40), (65, 64), (300, 33), (513, 128)])
+def test_forward_packed_is_bit_identical_to_the_padded_forward(B, S):
+    """ABI 9, kr_encoder_forward_packed: the ragged token list of a right-padded batch (int32 attended ids back to back + int32 lengths: what the tokenizer
+    processes of the corpus-encode loop ship, kirag_amd/feed.py) gives the SAME BITS as kr_encoder_forward on the padded int64 [B,S] pair
+    (dataset/collators.py:59-81 -> encoders.py:67-77 / :106-118), for both pools, the one-block (B <= 64) and the two-kernel packers, every attention
+    kernel, sequences of length 0 (mean pool: NaN like an all-zero mask) and S, host pointers and device tensors; and against the numpy oracle."""
+    import torch
+    cfg = SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=1000,
+                          max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    w = E.synth_weights(128, 2, 512, 1000, 512, seed=11)
+    h = _hip(cfg, w)
+    rng = np.random.default_rng(B * 977 + S)
+    lens = rng.integers(1, S + 1, B).astype(np.int32); lens[0] = S
+    if B > 2:
+        lens[B // 2] = 0                                                     # an empty sequence in the middle of the batch
+    ids = rng.integers(5, 1000, (B, S)); mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int64)
+    ids = ids * mask                                                         # [PAD] = 0 at the masked positions, as the tokenizer pads
+    rag = np.ascontiguousarray(ids[mask != 0].astype(np.int32))
+    for pool, fn in ((0, E.e5_encode), (1, E.bge_encode)):
+        padded = h.forward_np(ids, mask, pool)
+        out = h.forward_packed(torch.from_numpy(rag), torch.from_numpy(lens), S, pool).cpu().numpy()           # pageable host tensors
+        assert np.array_equal(out.view(np.uint32), padded.view(np.uint32)), f"pool {pool}: packed != padded"
+        dev = h.forward_packed(torch.from_numpy(rag).cuda(), torch.from_numpy(lens).cuda(), S, pool)           # device tensors, enqueue-only
+        pin_ids = torch.from_numpy(np.concatenate([rag, np.full(7, 999_999, np.int32)])).pin_memory()          # pinned slot longer than the batch (total_tokens)
+        pin = h.forward_packed(pin_ids, torch.from_numpy(lens).pin_memory(), S, pool, total_tokens=rag.size)
+        h.check()
+        assert torch.equal(dev.view(torch.int32), pin.view(torch.int32)) and np.array_equal(dev.cpu().numpy().view(np.uint32), padded.view(np.uint32))
+        live = lens > 0
+        if B > 2:
+            assert np.isnan(out[B // 2]).all()                               # nothing attended: NaN for both pools, as for an all-zero mask row
+        ref = fn(w, ids, mask, 2)
+        _check(out[live], ref[live], 4e-3, f"packed B{B} S{S} pool{pool}")
+    # the deferred error channel: lengths that do not add up / a length beyond S / an id outside the vocabulary
+    from kirag_amd._lib import KiragAmdError
+    for bad_lens, bad_rag, msg in ((np.minimum(lens + (np.arange(B) == 0), S + 1).astype(np.int32), rag, "seq_lens"),
+                                   (lens, np.where(np.arange(rag.size) == rag.size - 1, 1000, rag).astype(np.int32), "token id")):
+        with pytest.raises(KiragAmdError, match=msg):
+            h.forward_packed(torch.from_numpy(bad_rag).cuda(), torch.from_numpy(bad_lens).cuda(), S, 0)
+            h.check()
+    again = h.forward_packed(torch.from_numpy(rag), torch.from_numpy(lens), S, 0).cpu().numpy()                # the handle is usable again, same bits
+    assert np.array_equal(again.view(np.uint32), h.forward_np(ids, mask, 0).view(np.uint32))
+
+
+def test_module_forward_packed_and_doc_packed_match_the_module_forward():
+    """The module surface of the packed path (E5Encoder / BGEEncoder.forward_packed, BaseRetriever.doc_packed) against the module's own eval forward at the
+    full e5-large shape with the default (f16 + low half) mode: bit-identical rows; train mode refuses."""
+    import torch
+    from transformers import BertConfig
+    from kirag_amd import bench_support as BS
+    from kirag_amd.retriever.encoders import BGEEncoder, E5Encoder
+    cfg = BertConfig(vocab_size=30522, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, max_position_embeddings=512)
+    torch.manual_seed(0)
+    for cls in (E5Encoder, BGEEncoder):
+        m = cls(cfg, add_pooling_layer=False).cuda().eval()
+        ids, mask = BS.synthetic_tokens(torch.device("cuda:0"), 96, 128, seed=4, ragged=True)
+        ref = m(ids, mask)
+        lens = mask.sum(1).to(torch.int32)
+        rag = ids[mask.bool()].to(torch.int32)
+        out = m.forward_packed(rag.cpu(), lens.cpu(), 128)
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+        m._hip.check()
+        m.train()
+        with pytest.raises(RuntimeError, match="eval"):
+            m.forward_packed(rag, lens, 128)
+        del m
+        torch.cuda.empty_cache()

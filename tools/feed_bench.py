@@ -61,6 +61,7 @@ class Model:
     def to(self, d): return self
     def eval(self): return self
     def doc(self, a): return hip.forward(a["input_ids"], a["attention_mask"], 0)
+    def doc_packed(self, ids, lens, S, T=None): return hip.forward_packed(ids, lens, S, 0, T)
 class Corpus:
     index_to_passage_id = {i: str(i) for i in range(n)}
     def __len__(self): return n
@@ -96,6 +97,7 @@ class ModelM:
     def to(self, d): return self
     def eval(self): return self
     def doc(self, a): return mod(**a)
+    def doc_packed(self, ids, lens, S, T=None): return mod.forward_packed(ids, lens, S, T)
 warm = SimpleNamespace(local_rank=-1, save_dir=td, name="f", index_folder="warm", per_gpu_batch_size=8, num_passage_per_index_file=10**9,
                        encode_batch_size=512, prefetch_batches=8, tokenizer_workers=8, no_embedding_files=True)
 class Small(Corpus):
