@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--sync-search", action="store_true", help="one GPU: use the blocking kr_index_search per step instead of search_async + finish")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch latency block (forwards of the reference's real batch shapes + one KiRAG hop)")
+    ap.add_argument("--no-entry-point", action="store_true", help="skip the cal_doc_embeddings-from-text measurement (encode.entry_point)")
+    ap.add_argument("--entry-passages", type=int, default=32768, help="synthetic text passages of the encode.entry_point block")
     ap.add_argument("--no-surface", action="store_true", help="skip the reference-surface search measurement (Indexer.search_knn on --surface-queries queries)")
     ap.add_argument("--surface", action="store_true", help="(default on at N = 1) report queries/s of Indexer.search_knn next to the C-ABI search on the same queries")
     ap.add_argument("--surface-queries", type=int, default=4096)
@@ -211,6 +213,72 @@ def latency_block(args, encoder, index, dev):
                                  "what": "E5Encoder.forward (nn.Module surface, weight-sync check included) vs HipBertForward.forward, each followed by a device synchronisation"}
     del mod
     return out
+
+
+def entry_point_block(args, encoder, dev):
+    """passages-encoded/s at the reference's ENTRY POINT: ``cal_doc_embeddings`` (compute_corpus_embeddings.py:50-134) from passage TEXT with
+    DEFAULT flags — tokenizer feed, encoder, append to a resident index shard, shard files written — over synthetic passages in the reference's passage format
+    (bench_support.synthetic_text_corpus: 30522-entry WordPiece vocabulary, ~111 tokens per passage), next to the encoder's rate on the SAME token batches
+    pre-tokenised and resident in HBM (the figure ``encode.passages_per_s`` is the fixed-length variant of).  ``ratio`` is what the host side keeps of the kernels."""
+    import shutil
+    import tempfile
+    from types import SimpleNamespace
+    import torch
+    from kirag_amd import bench_support as BS
+    from kirag_amd import compute_corpus_embeddings as CC
+    from kirag_amd.collators import E5Collator
+    from kirag_amd.retriever.index import Indexer
+    n, bs = args.entry_passages, 512
+    td = tempfile.mkdtemp(prefix="kirag_amd_bench_")
+    try:
+        vocab_file, texts = BS.synthetic_text_corpus(n, td)
+        col = E5Collator(tokenizer=BS.wordpiece_tokenizer(vocab_file), query_maxlength=args.passage_tokens, doc_maxlength=args.passage_tokens)
+
+        class Model:
+            def __init__(self): self.encoder = SimpleNamespace(_hip=encoder, config=SimpleNamespace(vocab_size=encoder.cfg.vocab_size))
+            def to(self, d): return self
+            def eval(self): return self
+            def doc(self, a): return encoder.forward(a["input_ids"], a["attention_mask"], 0)
+            def doc_packed(self, ids, lens, S, T=None): return encoder.forward_packed(ids, lens, S, 0, T)
+
+        class Corpus:
+            def __init__(self, m): self.m = m; self.index_to_passage_id = {i: str(i) for i in range(m)}
+            def __len__(self): return self.m
+            def __getitem__(self, i): return {"index": i, "passage": texts[i]}
+        # the encoder alone on the first 8 of these batches, pre-tokenised and resident
+        pre = []
+        for s in range(0, min(n, 8 * bs), bs):
+            a = col.encode_doc(texts[s:s + bs])
+            pre.append((a["input_ids"].to(dev), a["attention_mask"].to(dev)))
+        for ids, mask in pre[:2]:
+            encoder.forward(ids, mask, 0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        reps = 6
+        for _ in range(reps):
+            for ids, mask in pre:
+                encoder.forward(ids, mask, 0)
+        torch.cuda.synchronize()
+        pre_rate = reps * sum(len(i) for i, _ in pre) / (time.perf_counter() - t0)
+        mean_tokens = float(sum(int(m.sum()) for _, m in pre) / sum(len(i) for i, _ in pre))
+        del pre
+
+        def run(m, folder):
+            a = CC.setup_parser(["--save_dir", td, "--name", "bench", "--index_folder", folder, "--doc_maxlength", str(args.passage_tokens)])   # every other flag at its default
+            ix = Indexer(encoder.hidden)
+            t0 = time.perf_counter()
+            CC.cal_doc_embeddings(a, Model(), Corpus(m), col, indexer=ix, device=dev)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            files = sorted(os.listdir(os.path.join(td, "bench", folder)))
+            assert ix.index.ntotal == m and files == [f"corpus_embeddings_0_{m - 1}.pkl", f"passage_id_list_0_{m - 1}.pkl"], files
+            return dt, dict(getattr(CC.cal_doc_embeddings, "last_feed", {}))
+        run(min(n, 4 * bs), "warm")                      # first allocations (pinned ring, workspace), tokenizer thread pool
+        dt, feed_info = run(n, "timed")
+        return {"what": "cal_doc_embeddings from TEXT, default flags (ragged token feed -> kr_encoder_forward_packed -> resident shard + .pkl shard files)",
+                "passages": n, "mean_tokens": mean_tokens, "passages_per_s": n / dt, "pretokenised_resident_passages_per_s": pre_rate, "ratio": n / dt / pre_rate,
+                "seconds": dt, "feed": feed_info}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def surface_block(args, index, q_vec, dev):
@@ -561,6 +629,8 @@ def main():
         }
         if world == 1 and encoder is not None and not args.no_latency:
             out["latency"] = latency_block(args, encoder, index, dev)
+        if world == 1 and encoder is not None and not args.no_entry_point:
+            out["encode"]["entry_point"] = entry_point_block(args, encoder, dev)
         if world == 1 and not args.no_surface:
             out["surface"] = surface_block(args, index, q_vec, dev)
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)

@@ -43,6 +43,11 @@ int kr_device_count(void);
  * (1 KiB per row at d = 1024, built by the first such search) in the final round of the coarse scan and 16-bit-score only the rows it marks;
  * results are the same exact top-k either way.  KIRAG_AMD_NO_BYTE_SCAN in the environment at kr_index_create: never for that index.
  * "debug_byte_min_rows" (rows; < 0 = default 2^19): test hook, the index size from which small blocks take that path.
+ * "debug_eps8_permille" (default 1000; <= 0 restores it): MUTATION hook of the tests — the pre-scan's error bound eps8 is multiplied by value / 1000.  With a value
+ * below 1000 the pre-scan is no longer exact (tests/test_gpu_search.py builds a row that a 750-permille bound misses and the real bound finds); never set it in production.
+ * Regimes the pre-scan does not serve: blocks of 33-128 queries, and 16-32-query blocks over anisotropic (e5-like) rows that mark more than n/8 rows four times
+ * in a row (the index then pauses the pre-scan for 1024 calls): those run the 2-byte stream at ~0.66-0.69 of HBM.  No reference caller sits there
+ * (knowledge_graph/models.py:1645 searches 1-2 queries per hop, retrieve.py whole query sets).
  * "debug_va_retired_tib" (TiB) / "debug_vmm_min_reserve_mib" (MiB; 0 = default): test hooks of the large-index address-space
  * budget and of the smallest address range reserved per large index.  Unknown names: KR_EINVAL. */
 int kr_set_option(const char* name, int value);
@@ -151,8 +156,16 @@ typedef struct {
     int64_t grow_mode;        /* this index: -1 undecided (< 256 MiB), 0 hipMalloc + copy-on-grow, 1 chunks mapped into a reserved address range */
     int64_t byte_scans;       /* query blocks whose final coarse round went through the int8 copy (kr_set_option "byte_prescan") */
     int64_t byte_marked_rows; /* rows those pre-scans marked (then scored from the 16-bit copy), summed */
+    int64_t byte_rows;        /* this index: rows its int8 copy currently covers (0: none - never built, released, or not affordable; kr_index_prepare) */
 } kr_search_stats;
 int kr_index_stats(kr_index* ix, kr_search_stats* out, int reset);
+/* Do now what the FIRST search of blocks of `nq` queries x top-`k` would otherwise do on the spot: allocate that shape's search workspaces, set the kernels'
+ * function attributes and - when such blocks take the byte pre-scan on this index (kr_set_option "byte_prescan") - build the int8 copy of the rows (8.6 ms at
+ * 5M x 1024 rows + 1 KiB per row of HBM; extended by the rows added since an earlier call) with its row bitmap.  The copy is only built while it leaves
+ * max(2 GiB, 1/16 of the device) free and is released again when kr_index_add needs the memory (derived data: results never depend on it).  Called by
+ * Indexer.index_data / deserialize_from (retriever/index.py:26-34,66-79) so that the first KiRAG hop after a load (knowledge_graph/models.py:1645) costs what
+ * every later one costs.  Enqueues on `stream`; waits for searches in flight on the handle.  An empty index: no-op. */
+int kr_index_prepare(kr_index* ix, int nq, int k, void* stream);
 
 /* Exact top-k of q . x^T for a small transient candidate set — replaces the torch.matmul + torch.topk of the KiRAG loop's aligner step
  * (knowledge_graph/models.py:1532-1538: [1-2 queries] x [T triples], top-20) and the matmul + argsort of the exemplar / dev-MRR ranking

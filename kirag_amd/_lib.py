@@ -26,7 +26,7 @@ class SearchStats(C.Structure):
                 ("reranked_rows", C.c_int64), ("coarse_rounds", C.c_int64), ("last_coarse_ms", C.c_double),
                 ("last_total_ms", C.c_double), ("fine", C.c_int64), ("exact", C.c_int64), ("fine_rounds", C.c_int64),
                 ("last_fine_ms", C.c_double), ("marked_passes", C.c_int64), ("marked_rows", C.c_int64),
-                ("va_retired_bytes", C.c_int64), ("grow_mode", C.c_int64), ("byte_scans", C.c_int64), ("byte_marked_rows", C.c_int64)]
+                ("va_retired_bytes", C.c_int64), ("grow_mode", C.c_int64), ("byte_scans", C.c_int64), ("byte_marked_rows", C.c_int64), ("byte_rows", C.c_int64)]
 
 
 class BertCfg(C.Structure):
@@ -62,6 +62,7 @@ SIGNATURES = {
     "kr_index_search_finish_ex": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
     "kr_index_search_finish_one": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "kr_index_search_pending": (C.c_int, [C.c_void_p]),
+    "kr_index_prepare": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "kr_index_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "kr_score_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kr_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

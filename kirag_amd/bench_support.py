@@ -157,3 +157,34 @@ def wordpiece_tokenizer(vocab_file: str, do_lower_case: bool = True):
     if tok.vocab_size != n_lines:
         raise RuntimeError(f"BertTokenizerFast loaded {tok.vocab_size} of the {n_lines} entries of {vocab_file}")
     return tok
+
+
+def synthetic_text_corpus(n: int, folder: str, seed: int = 0):
+    """``n`` synthetic passages as TEXT in the reference's passage format (``dataset/corpus.py:117-120``: "title:  T, text:  ...") over a synthetic 30522-entry
+    WordPiece vocabulary written to ``folder/vocab.txt`` (5 special tokens, 20000 words, 10517 "##" suffix pieces; 30 % of the words carry a suffix piece so the
+    tokenizer does real WordPiece work) — 60-99 words, ~111 tokens per passage with the "passage: " prefix.  Returns ``(vocab_file, texts)``.  Used by
+    bench.py's ``encode.entry_point`` block and tools/feed_bench.py: what ``cal_doc_embeddings`` is fed when a user runs it."""
+    import os
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
+
+    def rand_words(k, lo, hi):
+        out = set()
+        while len(out) < k:
+            lens = rng.integers(lo, hi, 2 * k)
+            flat = rng.choice(letters, int(lens.sum()))
+            cuts = np.concatenate([[0], np.cumsum(lens)])
+            out.update("".join(flat[a:b]) for a, b in zip(cuts[:-1], cuts[1:]))
+        return sorted(out)[:k]
+    words, pieces = rand_words(20000, 3, 9), rand_words(10517, 2, 5)
+    vocab_file = os.path.join(folder, "vocab.txt")
+    with open(vocab_file, "w") as f:
+        f.write("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words + ["##" + p for p in pieces]) + "\n")
+    k = rng.integers(60, 100, n)
+    total = int(k.sum())
+    wi = rng.integers(0, len(words), total); pi = rng.integers(0, len(pieces), total); glue = rng.random(total) < 0.3
+    toks = [words[a] + pieces[b] if g else words[a] for a, b, g in zip(wi.tolist(), pi.tolist(), glue.tolist())]
+    cuts = np.concatenate([[0], np.cumsum(k)]).tolist()
+    texts = ["title:  " + toks[a] + ", text:  " + " ".join(toks[a + 1:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    return vocab_file, texts

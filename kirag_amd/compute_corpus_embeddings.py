@@ -46,8 +46,8 @@ def setup_parser(argv=None):
     parser.add_argument("--encode_batch_size", type=int, default=512)
     parser.add_argument("--prefetch_batches", type=int, default=2, help="batches tokenised ahead of the GPU on a background thread")
     parser.add_argument("--tokenizer_workers", type=int, default=-1,
-                        help="> 0: tokenise in that many worker PROCESSES (each with its own tokenizer; batches come back in order); 0: one background "
-                             "thread; -1 (default): min(8, cpus / 2) processes for a GPU run over more than a few batches, else 0")
+                        help="tokenizer worker PROCESSES next to the in-process tokenizer thread (each with its own tokenizer; batches are handed out "
+                             "dynamically and come back in order); 0: the thread alone; -1 (default): min(4, cpus / 4) for a GPU run over more than a few batches")
     parser.add_argument("--no_embedding_files", action="store_true",
                         help="do not write corpus_embeddings_*.pkl / passage_id_list_*.pkl (streamed encode straight into a resident index shard)")
     return parser.parse_args(argv)
@@ -59,15 +59,16 @@ def shard_range(n: int, rank: int, world: int):
 
 
 def default_tokenizer_workers(n_batches: int, on_gpu: bool) -> int:
-    """``--tokenizer_workers -1``: one tokenizer thread alone feeds ~5.6 k passages/s, the encoder takes ~13 k (profiles/r05/feed_bench_100k.txt), so a GPU run over
-    more than a few batches gets min(8, cpus / 2) tokenizer processes; tiny corpora and host-only runs stay in-process (no process start-up cost)."""
+    """``--tokenizer_workers -1``.  The feed always tokenises on one thread of this process (with the tokenizer's own thread pool: ~11 k passages/s on the GPU
+    box against an encoder that takes ~13.6 k, profiles/r06/feed_bench.txt); worker processes add capacity for slower hosts and join the stream once they have
+    started.  A GPU run over more than a few batches gets min(4, cpus / 4) of them; tiny corpora and host-only runs none (no process start-up cost)."""
     if not on_gpu or n_batches <= 4:
         return 0
     try:
         cpus = len(os.sched_getaffinity(0))
     except AttributeError:
         cpus = os.cpu_count() or 1
-    return max(0, min(8, cpus // 2, n_batches))
+    return max(0, min(4, cpus // 4, n_batches))
 
 
 class _ShardWriter:
@@ -248,6 +249,8 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
     enc = getattr(getattr(model, "encoder", None), "_hip", None)
     if enc is not None:
         enc.check()                                          # token ids outside the vocabulary surface here at the latest
+    cal_doc_embeddings.last_feed = {"tokenizer_workers": workers, "packed_forward": bool(use_packed),
+                                    "batches_by_producer": dict(tokens.made_by) if tokens is not None else None}
     return start, end
 
 
@@ -256,7 +259,7 @@ def pool_map(make_texts, collator, items, workers: int, depth: int):
     as a thin wrapper over ``feed.TokenFeed`` (the frames travel ragged and are re-padded here; ``cal_doc_embeddings`` consumes the frames directly)."""
     items = list(items)
     pad_id = getattr(getattr(collator, "tokenizer", None), "pad_token_id", None) or 0
-    tf = feed.TokenFeed(make_texts, collator, items, max(1, workers), depth, 1, 1)
+    tf = feed.TokenFeed(make_texts, collator, items, max(1, workers), depth, 1, 1, local=False)
     for frame in tf:
         yield frame.inputs(pad_id), frame.doc_ids
 

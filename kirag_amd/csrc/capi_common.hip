@@ -24,6 +24,7 @@ int fail(int code, const char* fmt, ...) {
 std::atomic<int> g_force_exact{0};
 std::atomic<int> g_byte_prescan{1};
 std::atomic<int> g_byte_min_rows{1 << 19};
+std::atomic<int> g_eps8_permille{1000};
 std::atomic<unsigned long long> g_va_retired_bias{0};
 std::atomic<unsigned long long> g_vmm_min_reserve{16ull << 30};
 
@@ -66,6 +67,7 @@ int kr_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "force_exact_scores") == 0) { kr::g_force_exact.store(value != 0); return 0; }
     if (name && std::strcmp(name, "byte_prescan") == 0) { kr::g_byte_prescan.store(value != 0); return 0; }
     if (name && std::strcmp(name, "debug_byte_min_rows") == 0) { kr::g_byte_min_rows.store(value < 0 ? (1 << 19) : value); return 0; }
+    if (name && std::strcmp(name, "debug_eps8_permille") == 0) { kr::g_eps8_permille.store(value <= 0 ? 1000 : value); return 0; }
     if (name && std::strcmp(name, "debug_va_retired_tib") == 0) { kr::g_va_retired_bias.store((unsigned long long)(value < 0 ? 0 : value) << 40); return 0; }
     if (name && std::strcmp(name, "debug_vmm_min_reserve_mib") == 0) { kr::g_vmm_min_reserve.store(value <= 0 ? (16ull << 30) : ((unsigned long long)value << 20)); return 0; }
     return kr::fail(KR_EINVAL, "unknown option '%s'", name ? name : "(null)");

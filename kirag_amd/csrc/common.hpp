@@ -38,6 +38,7 @@ int select_device(int device);  // hipSetDevice + arch check (gfx950)
 bool is_device_pointer(const void* p);   // hipMalloc memory (as opposed to pageable / pinned host memory)
 extern std::atomic<int> g_force_exact;   // kr_set_option("force_exact_scores")
 extern std::atomic<int> g_byte_min_rows; // kr_set_option("debug_byte_min_rows"): index size from which they do (default 2^19; tests lower it)
+extern std::atomic<int> g_eps8_permille; // kr_set_option("debug_eps8_permille"): MUTATION hook of the tests - the byte pre-scan's error bound eps8 is multiplied by value / 1000 (1000 = the bound)
 extern std::atomic<int> g_byte_prescan;  // kr_set_option("byte_prescan"): small query blocks may take the int8 pre-scan (search.hip, byte_final_round)
 extern std::atomic<unsigned long long> g_vmm_min_reserve;   // kr_set_option("debug_vmm_min_reserve_mib"): smallest address range reserved for a large index (default 16 GiB)
 extern std::atomic<unsigned long long> g_va_retired_bias;   // kr_set_option("debug_va_retired_tib"): test hook of the index's address-space budget

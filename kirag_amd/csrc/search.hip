@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_quant8_rows(const float* __restrict__ x
 __global__ __launch_bounds__(256) void k_scan8_prep(const uint64_t* __restrict__ cand, int cand_cap, const uint32_t* __restrict__ cnt, const float* __restrict__ eps16,
                                                     const float* __restrict__ qf, int nq, int d, int dpad8, int k, const float* __restrict__ bounds8,
                                                     const float* __restrict__ mu8, int8_t* __restrict__ q8, float* __restrict__ thr8,
-                                                    unsigned int* __restrict__ mark_count, float* __restrict__ thr16, uint32_t* __restrict__ cnt_spread) {
+                                                    unsigned int* __restrict__ mark_count, float* __restrict__ thr16, uint32_t* __restrict__ cnt_spread, float eps8_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[5][4];
     if (blockIdx.x == 0 && threadIdx.x == 0) *mark_count = 0u;          // the list the scan behind this kernel appends to
@@ -1242,6 +1242,7 @@ __global__ __launch_bounds__(256) void k_scan8_prep(const uint64_t* __restrict__
         // rests on: an unmarked row must not even TIE with them (a tie would be decided by the row index)
         e8 += 1e-6f * (fabsf(kth) + fabsf(qm) + eps16[q]);
         e8 = e8 * 1.001f + 1e-30f;
+        e8 *= eps8_scale;                                                  // 1 in production; kr_set_option("debug_eps8_permille") lets a test run with a bound that is too small
         const float theta = kth - eps16[q] - e8 - qm;                      // bound on the byte score u^.r^ of a row that can still matter
         const bool usable = (fabsf(theta) <= 3.4028235e38f) && sq > 0.f && (sq <= 3.4028235e38f) && reinterpret_cast<const unsigned int*>(bounds8)[1] == 0u;
         float t = -INFINITY;                                               // unusable: every row is marked (slow, exact)
@@ -1450,7 +1451,18 @@ static int vmm_move(Index* ix, int64_t want) {
     return 0;
 }
 
+static void drop_byte_copy(Index* ix);
+static int grow_once(Index* ix, int64_t want);
+//  the rows come first: when the device is out of memory and the index holds its derived int8 copy, that copy is released and the growth is
+// tried once more — an add that succeeded before the copy existed must not fail because of it
 static int grow(Index* ix, int64_t want) {
+    const int rc = grow_once(ix, want);
+    if (rc != KR_ENOMEM || !ix->x8) return rc;
+    (void)hipGetLastError();
+    drop_byte_copy(ix);
+    return grow_once(ix, want);
+}
+static int grow_once(Index* ix, int64_t want) {
     if (want <= ix->cap_rows) return 0;
     const size_t row_f = (size_t)ix->d * sizeof(float), row_c = (size_t)ix->dpad * 2;
     KR_TRY(wait_adds_host(ix));
@@ -1488,7 +1500,7 @@ static int grow(Index* ix, int64_t want) {
     int64_t ncap = std::max<int64_t>(want, ix->cap_rows + ix->cap_rows / 2);
     ncap = round_up(ncap, 256);
     float* nf = nullptr; uint16_t* nc = nullptr;
-    KR_HIP(hipMalloc(&nf, (size_t)ncap * ix->d * sizeof(float)));
+    if (hipMalloc(&nf, (size_t)ncap * ix->d * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fail(KR_ENOMEM, "hipMalloc of the index rows failed (%lld rows)", (long long)ncap); }
     hipError_t e = hipMalloc(&nc, (size_t)ncap * ix->dpad * 2);
     if (e != hipSuccess) { (void)hipFree(nf); return fail(KR_ENOMEM, "hipMalloc of the coarse copy failed: %s", hipGetErrorString(e)); }
     if (ix->n > 0) {
@@ -1652,12 +1664,30 @@ static int ensure_bitmap(Index* ix) {
     return 0;
 }
 
+// The int8 copy is DERIVED data (1 KiB per row at d = 1024): whenever the index stops using it (non-finite rows, an allocation failure) or needs the memory for
+// the rows themselves (grow), it is released; a later small search may build it again unless byte_off is set.  hipFree waits for the device: searches that read
+// the copy are done.
+static void drop_byte_copy(Index* ix) {
+    if (ix->x8) (void)hipFree(ix->x8);
+    if (ix->sx8) (void)hipFree(ix->sx8);
+    ix->x8 = nullptr; ix->sx8 = nullptr; ix->n8 = 0; ix->cap8 = 0;
+}
+
+// HBM budget of the copy (it used to be allocated without looking): building it must leave max(2 GiB, 1/16 of the device) free for
+// the rows still to come, the search workspaces and the caller's own tensors; otherwise the index simply keeps answering small blocks from the 16-bit copy.
+static bool byte_copy_fits(size_t bytes) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return true; }
+    const size_t keep = std::max<size_t>((size_t)2 << 30, total_b / 16);
+    return free_b >= bytes + keep;
+}
+
 // Bring the int8 copy up to row n (kernels on `st`, behind the adds the caller has already ordered).  true: usable for this call.  An allocation failure is
 // not an error: the copy is an accelerator, the index then serves every block from the 16-bit copy (byte_off).
 static bool ensure_byte_copy(Index* ix, hipStream_t st) {
     if (ix->byte_off) return false;
     const int dpad8 = (int)round_up(ix->d, 128);
-    auto give_up = [&]() { (void)hipGetLastError(); ix->byte_off = true; return false; };
+    auto give_up = [&]() { (void)hipGetLastError(); ix->byte_off = true; drop_byte_copy(ix); return false; };
     if (!ix->thr8) {
         ix->dpad8 = dpad8;
         if (!ix->bounds8 && hipMalloc(&ix->bounds8, 4 * sizeof(float)) != hipSuccess) return give_up();
@@ -1675,6 +1705,7 @@ static bool ensure_byte_copy(Index* ix, hipStream_t st) {
         ix->x8 = nullptr; ix->sx8 = nullptr; ix->n8 = 0;
         const int64_t ncap = std::max(need, round_up(ix->cap8 + ix->cap8 / 2, 256));
         ix->cap8 = 0;
+        if (!byte_copy_fits((size_t)ncap * (dpad8 + sizeof(float)))) return false;      // not now (byte_off stays clear: memory may be free again later)
         if (hipMalloc(&ix->x8, (size_t)ncap * dpad8) != hipSuccess) return give_up();
         if (hipMalloc(&ix->sx8, (size_t)ncap * sizeof(float)) != hipSuccess) return give_up();
         ix->cap8 = ncap;
@@ -1701,7 +1732,7 @@ static int byte_final_round(Index* ix, const CoarseArgs& a, const float* qf, int
     unsigned int* cnt_word = ix->bitmap + words;                         // (the list-length word behind the bitmap pass 2's marking scan uses)
     const size_t prep_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int);
     hipLaunchKernelGGL(k_scan8_prep, dim3(32), dim3(256), prep_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->eps, qf, nq, ix->d, ix->dpad8, k, ix->bounds8, ix->mu8,
-                       ix->q8, ix->thr8, cnt_word, ix->thr, ix->cnt_spread);
+                       ix->q8, ix->thr8, cnt_word, ix->thr, ix->cnt_spread, (float)g_eps8_permille.load() * 1e-3f);
     CoarseArgs m = a;
     m.xc = reinterpret_cast<const uint16_t*>(ix->x8); m.dpad = ix->dpad8 / 2;
     m.qc = reinterpret_cast<const uint16_t*>(ix->q8); m.qc2 = reinterpret_cast<const uint16_t*>(ix->q8 + (size_t)32 * ix->dpad8);
@@ -1903,7 +1934,10 @@ static int pass1_coarse(Index* ix, const float* q, int nq, int k, int blk, hipSt
     bool byte_ok = plan_block(ix, nq, k).q32 && nq <= BYTE_NQ_MAX && !ix->byte_off && g_byte_prescan.load() != 0 && ix->n >= (int64_t)g_byte_min_rows.load() && byte_dim_ok(ix->d);
     if (byte_ok && ix->byte_pause > 0) { --ix->byte_pause; byte_ok = false; }
     if (byte_ok) byte_ok = ensure_byte_copy(ix, st);
-    if (byte_ok) KR_TRY(ensure_bitmap(ix));
+    if (byte_ok && ensure_bitmap(ix) != 0) {        // 8 B per row of bitmap / row list / query masks: without them the 16-bit round serves the block
+        (void)hipGetLastError();
+        byte_ok = false; ix->byte_off = true; drop_byte_copy(ix);
+    }
     const BlockPlan p = plan_block(ix, nq, k, byte_ok);
     rmax = p.rmax;
     byte_used = false;
@@ -2147,7 +2181,7 @@ static int finish_one(Index* ix, int64_t* flagged_out) {
             // rows (data on which the byte bound does not separate) pause it for the next 1024 small blocks
             const int64_t marked = (int64_t)rec[2 * QBLK + 1];
             ix->st.byte_scans++; ix->st.byte_marked_rows += marked;
-            if (rec[2 * QBLK + 2] != 0u) ix->byte_off = true;
+            if (rec[2 * QBLK + 2] != 0u) { ix->byte_off = true; if (ix->pend_n <= 1) drop_byte_copy(ix); }   // (a newer call in flight may still read it: kr_index_destroy frees it then)
             else if (marked > ix->n / 8) { if (++ix->byte_bad >= 4) { ix->byte_bad = 0; ix->byte_pause = 1024; } }
             else ix->byte_bad = 0;
         }
@@ -2300,6 +2334,25 @@ static std::mutex g_scratch_mu;
 }  // namespace kr
 
 using namespace kr;
+
+// Everything the FIRST search of a (nq, k) shape would otherwise do on the spot, done now (the first KiRAG hop after a load paid 8.6 ms of
+// quantisation + a 5-GB allocation at 5M rows + the workspace allocations): the search workspaces for that shape, the kernels' function attributes, and - when
+// blocks of nq queries take the byte pre-scan on this index - the int8 copy (extended, if it exists, by the rows added since) with its bitmap / row list.
+// The copy is re-derived rather than stored in shard files on purpose: quantising 5M rows takes 8.6 ms on the device, reading 5 GB back from disk seconds.
+template <class T>
+static int prepare_t(Index* ix, int nq, int k, hipStream_t st) {
+    bool byte_ok = plan_block(ix, nq, k).q32 && nq <= BYTE_NQ_MAX && !ix->byte_off && g_byte_prescan.load() != 0 && ix->n >= (int64_t)g_byte_min_rows.load() && byte_dim_ok(ix->d);
+    if (byte_ok) {
+        if (ix->ev_add) KR_HIP(hipStreamWaitEvent(st, ix->ev_add, 0));
+        byte_ok = ensure_byte_copy(ix, st);
+    }
+    if (byte_ok && ensure_bitmap(ix) != 0) { (void)hipGetLastError(); byte_ok = false; ix->byte_off = true; drop_byte_copy(ix); }
+    const BlockPlan p = plan_block(ix, nq, k, byte_ok);
+    KR_TRY(ensure_ws(ix, k, p.cap));
+    KR_TRY(search_attrs(ix));
+    KR_TRY(ensure_status(ix, (nq + QBLK - 1) / QBLK));
+    return 0;
+}
 
 extern "C" {
 
@@ -2500,6 +2553,26 @@ int kr_index_search(kr_index* h, const float* q, int nq, int k, float* scores, i
     return 0;
 }
 
+int kr_index_prepare(kr_index* h, int nq, int k, void* stream) {
+    if (!h) return fail(KR_EINVAL, "index is NULL");
+    Index* ix = reinterpret_cast<Index*>(h);
+    if (nq <= 0 || k <= 0 || k > EXACT_RC) return fail(KR_EINVAL, "kr_index_prepare: nq > 0 and 0 < k <= %d", EXACT_RC);
+    if (ix->n == 0) return 0;
+    KR_TRY(select_device(ix->device));
+    KR_TRY(finish_search(ix));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    nq = std::min(nq, QBLK); k = (int)std::min<int64_t>(k, ix->n);
+    const int64_t n8_before = ix->x8 ? ix->n8 : -1;
+    KR_TRY(ix->coarse == KR_COARSE_BF16 ? prepare_t<BF16>(ix, nq, k, st) : prepare_t<F16>(ix, nq, k, st));
+    if ((ix->x8 ? ix->n8 : -1) != n8_before) {
+        // the copy was built / extended by kernels on `st`: searches on ANOTHER stream must not read it early - they already wait for ev_add (the event behind
+        // the last asynchronous add), so it is recorded again behind these kernels
+        if (!ix->ev_add) KR_HIP(hipEventCreateWithFlags(&ix->ev_add, hipEventDisableTiming));
+        KR_HIP(hipEventRecord(ix->ev_add, st));
+    }
+    return 0;
+}
+
 int kr_index_search_async(kr_index* h, const float* q, int nq, int k, float* scores, int64_t* rows, void* stream) {
     if (!h) return fail(KR_EINVAL, "index is NULL");
     Index* ix = reinterpret_cast<Index*>(h);
@@ -2644,6 +2717,7 @@ int kr_index_stats(kr_index* h, kr_search_stats* out, int reset) {
     *out = ix->st;
     out->va_retired_bytes = (int64_t)va_retired_total();
     out->grow_mode = ix->vmm;
+    out->byte_rows = ix->x8 ? ix->n8 : 0;
     if (reset) ix->st = kr_search_stats{};
     return 0;
 }

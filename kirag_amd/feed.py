@@ -6,12 +6,15 @@ What travels is RAGGED: the int32 ids of the attended positions of every sequenc
 returns, as raw buffers (a 32-byte header + two arrays), never a pickle.  A batch whose mask is not "1^len 0^(S-len)" (a tokenizer that pads on the left)
 travels padded instead and takes the ``model.doc({"input_ids", "attention_mask"})`` route; results are the same rows either way.
 
-``TokenFeed`` runs the tokenizer in ``workers`` PROCESSES (``python -m kirag_amd.tokenize_worker``; 0 = one background thread in this process).  Every worker
+``TokenFeed`` tokenises on one background thread of this process (HF fast tokenizers release the GIL and bring their own thread pool) and, when
+``workers > 0``, in that many PROCESSES as well (``python -m kirag_amd.tokenize_worker``).  Batches are handed out dynamically - whoever is free takes the
+next one - so the local thread carries the stream while the workers are still starting (importing torch + transformers takes seconds: a static split made a
+100 k-passage run 25 % slower than no workers at all) and the workers add capacity on hosts where one tokenizer cannot keep the encoder fed.  Every worker
 has a serve thread here that builds the batch's strings (dataset access stays in the parent), sends them, and reads the reply STRAIGHT INTO a slot of a
 persistent pinned ring (``readinto``: no intermediate bytes object, no per-batch ``pin_memory()`` allocation, the GIL is released while the pipe is read).
 Token ids are validated where they are produced (``pack_frame``), so the consumer - the one Python thread that launches the encoder - does nothing per batch
-but take the next frame.  Slot j % R serves batch j and is handed back by ``release`` once the upload that read it has completed; a worker may run at most
-R batches ahead of the last released one, so the ring cannot deadlock (the next batch in order always finds its slot free once R >= 3).
+but take the next frame.  Slot j % R serves batch j and is handed back by ``release`` once the upload that read it has completed; batch j may be started
+only when j < released + R, and batches are started in increasing order, so the ring cannot deadlock (the oldest outstanding batch always has its slot).
 """
 from __future__ import annotations
 
@@ -23,10 +26,13 @@ import sys
 import threading
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
+import logging
+
 import numpy as np
 
+logger = logging.getLogger(__name__)
 FRAME_MAGIC = 0x4654524B          # "KRTF"
-KIND_RAGGED, KIND_PADDED, KIND_ERROR, KIND_BAD_ID = 0, 1, 2, 3
+KIND_RAGGED, KIND_PADDED, KIND_ERROR, KIND_BAD_ID, KIND_READY = 0, 1, 2, 3, 4
 _HEAD = struct.Struct("<IIIIqQ")  # magic, kind, n sequences, S (padded width), T (tokens | n*S | message bytes), aux (KIND_BAD_ID: (min << 32) | max as two int32)
 
 
@@ -80,6 +86,11 @@ def pack_frame(t: Tokens, vocab: Optional[int] = None) -> List[bytes]:
 def error_frame(message: str) -> List[bytes]:
     b = message.encode("utf-8", "replace")
     return [_HEAD.pack(FRAME_MAGIC, KIND_ERROR, 0, 0, len(b), 0), b]
+
+
+def ready_frame() -> List[bytes]:
+    """Sent once by a worker when its collator is loaded: its serve thread takes batches only from then on."""
+    return [_HEAD.pack(FRAME_MAGIC, KIND_READY, 0, 0, 0, 0)]
 
 
 def bad_id_message(first_passage_id, vocab, lo, hi) -> str:
@@ -153,33 +164,42 @@ def _read_exact(f, view: memoryview) -> None:
 class TokenFeed:
     """Ordered stream of token ``Frame``s for ``items`` (see the module docstring).
 
-    ``make_texts(item) -> (texts, doc_ids)`` builds a batch's strings in this process; ``collator.encode_doc`` tokenises them (in a worker process when
-    ``workers > 0``).  ``max_seqs`` / ``max_len``: the largest batch / padded width to expect (slots are sized for it and grow if a batch exceeds it).
+    ``make_texts(item) -> (texts, doc_ids)`` builds a batch's strings in this process; ``collator.encode_doc`` tokenises them (on the local thread or in a
+    worker process).  ``max_seqs`` / ``max_len``: the largest batch / padded width to expect (slots are sized for it and grow if a batch exceeds it).
     ``vocab``: validate attended ids against [0, vocab); a violation raises ``ValueError`` at the consumer when that batch's turn comes.
-    ``depth``: frames buffered beyond one per worker.  Iterate once; ``close()`` (or exhausting / abandoning the iterator) stops threads and processes."""
+    ``depth``: frames buffered beyond one per tokenizer.  ``local=False``: worker processes only (tests).  Iterate once; ``close()`` (or exhausting /
+    abandoning the iterator) stops threads and processes."""
 
     def __init__(self, make_texts: Callable, collator, items: Iterable, workers: int, depth: int, max_seqs: int, max_len: int, vocab: Optional[int] = None,
-                 pinned: bool = False):
+                 pinned: bool = False, local: bool = True):
         self.make_texts, self.collator, self.items = make_texts, collator, list(items)
         self.vocab = int(vocab) if vocab else None
         self.workers = max(0, min(int(workers), len(self.items)))
-        self.R = max(3, self.workers + max(1, int(depth)) + 2)
+        self.local = bool(local) or self.workers == 0
+        self.R = max(3, self.workers + int(self.local) + max(1, int(depth)) + 2)
         self.slots = [Slot(max_seqs, max_seqs * max_len, pinned) for _ in range(min(self.R, max(1, len(self.items))))]
         self.R = len(self.slots) if len(self.slots) < self.R else self.R
         self.cond = threading.Condition()
         self.ready = {}             # batch index -> Frame | BaseException
+        self.next_j = 0             # next batch to hand to a tokenizer
         self.released = 0           # every batch < released has given its slot back
         self.pending_release = []   # (batch index, event) in order
         self.stop = False
+        self.made_by = {"local": 0, "workers": 0}   # batches per producer kind (diagnostics)
         self.procs: List[subprocess.Popen] = []
         self.threads: List[threading.Thread] = []
         self._started = False
 
     # ---- producer side -------------------------------------------------------------------------------------------------------------------------------
-    def _wait_turn(self, j: int) -> bool:
+    def _take(self) -> int:
+        """The next batch index for a free tokenizer (-1: none left / stopping); returns once its ring slot is free."""
         with self.cond:
+            if self.stop or self.next_j >= len(self.items):
+                return -1
+            j = self.next_j
+            self.next_j += 1
             self.cond.wait_for(lambda: self.stop or j < self.released + self.R)
-            return not self.stop
+            return -1 if self.stop else j
 
     def _post(self, j: int, what) -> None:
         with self.cond:
@@ -192,53 +212,78 @@ class TokenFeed:
         return f
 
     def _serve_local(self) -> None:
-        """workers == 0: tokenise on this background thread (HF fast tokenizers release the GIL)."""
+        """Tokenise on this background thread (HF fast tokenizers release the GIL)."""
+        j = -1
         try:
-            for j, item in enumerate(self.items):
-                if not self._wait_turn(j):
+            while True:
+                j = self._take()
+                if j < 0:
                     return
-                texts, doc_ids = self.make_texts(item)
+                texts, doc_ids = self.make_texts(self.items[j])
                 t = tokens_of(self.collator.encode_doc(texts))
                 if self.vocab is not None:
                     r = attended_range(t)
                     if r is not None and (r[0] < 0 or r[1] >= self.vocab):
                         self._post(j, ValueError(bad_id_message(doc_ids[0] if doc_ids else "?", self.vocab, r[0], r[1])))
-                        return
+                        continue
                 slot = self.slots[j % self.R]
                 slot.fit(t.n, t.T, t.kind == KIND_PADDED)
                 slot.lens[:t.n] = t.lens
                 slot.ids[:t.T] = t.ids
                 if t.kind == KIND_PADDED:
                     slot.mask_t.numpy()[:t.T] = t.mask
+                self.made_by["local"] += 1
                 self._post(j, self._frame(j, doc_ids, t.kind, t.n, t.S, t.T))
-        except BaseException as e:   # noqa: BLE001 - forwarded to the consumer
-            self._post(-1, e)
+        except BaseException as e:   # noqa: BLE001 - forwarded to the consumer (as the failure of the batch this thread held)
+            self._fail(j, e)
+
+    def _fail(self, j: int, e: BaseException) -> None:
+        with self.cond:
+            if not self.stop:
+                if j >= 0:
+                    self.ready.setdefault(j, e)
+                else:
+                    self.ready.setdefault(-1, e)
+            self.cond.notify_all()
 
     def _serve_worker(self, w: int, blob: bytes) -> None:
         p = self.procs[w]
-        j = w
+        j = -1
 
         def send(payload: bytes) -> None:
             p.stdin.write(struct.pack("<Q", len(payload))); p.stdin.write(payload); p.stdin.flush()
+
+        def header():
+            _read_exact(p.stdout, memoryview(head))
+            magic, kind, n, S, T, aux = _HEAD.unpack(head)
+            if magic != FRAME_MAGIC:
+                raise RuntimeError("tokenizer worker: corrupt frame header (did a library write to the worker's stdout?)")
+            if kind == KIND_ERROR:
+                msg = bytearray(T); _read_exact(p.stdout, memoryview(msg))
+                raise RuntimeError("tokenizer worker: " + msg.decode("utf-8", "replace"))
+            return kind, n, S, T, aux
         try:
-            send(blob)
             head = bytearray(_HEAD.size)
-            for j in range(w, len(self.items), len(self.procs)):
-                if not self._wait_turn(j):
+            send(blob)
+            try:
+                if header()[0] != KIND_READY:        # the worker has imported its libraries and un-pickled the collator: only now does it take batches
+                    raise RuntimeError("tokenizer worker: expected the ready frame")
+            except Exception as e:   # noqa: BLE001 - a worker that cannot start is a lost speed-up, not a lost result, as long as the local thread runs
+                if not self.local:
+                    raise
+                logger.warning("tokenizer worker %d did not start (%s); continuing with the remaining tokenizers", w, e)
+                return
+            while True:
+                j = self._take()
+                if j < 0:
                     return
                 texts, doc_ids = self.make_texts(self.items[j])
                 send(pickle.dumps(texts, protocol=pickle.HIGHEST_PROTOCOL))
-                _read_exact(p.stdout, memoryview(head))
-                magic, kind, n, S, T, aux = _HEAD.unpack(head)
-                if magic != FRAME_MAGIC:
-                    raise RuntimeError("tokenizer worker: corrupt frame header (did a library write to the worker's stdout?)")
-                if kind == KIND_ERROR:
-                    msg = bytearray(T); _read_exact(p.stdout, memoryview(msg))
-                    raise RuntimeError("tokenizer worker: " + msg.decode("utf-8", "replace"))
+                kind, n, S, T, aux = header()
                 if kind == KIND_BAD_ID:
                     lo, hi = struct.unpack("<ii", struct.pack("<II", (aux >> 32) & 0xffffffff, aux & 0xffffffff))
                     self._post(j, ValueError(bad_id_message(doc_ids[0] if doc_ids else "?", self.vocab, lo, hi)))
-                    return
+                    continue
                 slot = self.slots[j % self.R]
                 slot.fit(n, T, kind == KIND_PADDED)
                 _read_exact(p.stdout, memoryview(slot.lens[:n]).cast("B"))
@@ -247,26 +292,29 @@ class TokenFeed:
                     _read_exact(p.stdout, memoryview(slot.mask_t.numpy()[:T]).cast("B"))
                 if n != len(doc_ids):
                     raise RuntimeError(f"tokenizer worker returned {n} sequences for a batch of {len(doc_ids)}")
+                self.made_by["workers"] += 1
                 self._post(j, self._frame(j, doc_ids, kind, n, S, T))
-        except BaseException as e:   # noqa: BLE001 - forwarded to the consumer (as the failure of the first batch this worker still owed)
-            with self.cond:
-                if not self.stop:
-                    self.ready.setdefault(j, e)
-                    self.ready.setdefault(-1, e)
-                self.cond.notify_all()
+        except BaseException as e:   # noqa: BLE001 - forwarded to the consumer
+            self._fail(j, e)
 
     def _start(self) -> None:
         self._started = True
-        if self.workers == 0:
-            self.threads = [threading.Thread(target=self._serve_local, daemon=True, name="kirag-amd-tokenize")]
-        else:
+        self.threads = [threading.Thread(target=self._serve_local, daemon=True, name="kirag-amd-tokenize")] if self.local else []
+        if self.workers > 0:
             env = dict(os.environ, TOKENIZERS_PARALLELISM="false", PYTHONPATH=os.pathsep.join(
                 [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p]))
-            blob = pickle.dumps({"collator": self.collator, "vocab": self.vocab}, protocol=pickle.HIGHEST_PROTOCOL)
+            try:
+                blob = pickle.dumps({"collator": self.collator, "vocab": self.vocab}, protocol=pickle.HIGHEST_PROTOCOL)
+            except Exception as e:   # noqa: BLE001 - e.g. a tokenizer object that cannot be pickled
+                if not self.local:
+                    raise
+                logger.warning("the collator cannot be sent to tokenizer processes (%s); tokenising in-process only", e)
+                self.workers = 0
+        if self.workers > 0:
             # plain child processes: no fork of a process that holds a GPU context and a tokenizer thread pool, no re-import of the caller's __main__
             self.procs = [subprocess.Popen([sys.executable, "-m", "kirag_amd.tokenize_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
                           for _ in range(self.workers)]
-            self.threads = [threading.Thread(target=self._serve_worker, args=(w, blob), daemon=True, name=f"kirag-amd-feed-{w}") for w in range(self.workers)]
+            self.threads += [threading.Thread(target=self._serve_worker, args=(w, blob), daemon=True, name=f"kirag-amd-feed-{w}") for w in range(self.workers)]
         for t in self.threads:
             t.start()
 

@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     BIND(kr_abi_version) BIND(kr_last_error) BIND(kr_device_count)
     BIND(kr_index_create) BIND(kr_index_destroy) BIND(kr_index_reserve) BIND(kr_index_add) BIND(kr_index_ntotal) BIND(kr_index_get_rows)
     BIND(kr_index_search) BIND(kr_index_search_async) BIND(kr_index_search_finish) BIND(kr_index_search_finish_ex) BIND(kr_index_search_pending)
-    BIND(kr_index_stats)
+    BIND(kr_index_stats) BIND(kr_index_prepare)
     BIND(kr_encoder_create_ex) BIND(kr_encoder_operand_dtype) BIND(kr_encoder_residual_lo) BIND(kr_encoder_destroy) BIND(kr_encoder_load_weight)
     BIND(kr_encoder_finalize) BIND(kr_encoder_forward) BIND(kr_encoder_forward_tt) BIND(kr_encoder_forward_packed) BIND(kr_encoder_check)
     if (p_kr_abi_version() != KR_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }

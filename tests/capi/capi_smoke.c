@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     BIND(kr_index_destroy) BIND(kr_index_reserve) BIND(kr_index_add) BIND(kr_index_ntotal) BIND(kr_index_dim) BIND(kr_index_get_rows)
     BIND(kr_index_coarse_dim) BIND(kr_index_coarse_dtype) BIND(kr_index_get_coarse) BIND(kr_index_get_bounds) BIND(kr_index_add_raw)
     BIND(kr_index_search) BIND(kr_index_search_async) BIND(kr_index_search_finish) BIND(kr_index_search_finish_ex) BIND(kr_index_search_finish_one) BIND(kr_index_search_pending)
-    BIND(kr_index_stats) BIND(kr_score_topk) BIND(kr_topk_merge) BIND(kr_format_ids) BIND(kr_index_search_coarse_async) BIND(kr_index_search_global_theta) BIND(kr_index_search_rerank_async) BIND(kr_topk_merge_device) BIND(kr_comm_unique_id) BIND(kr_comm_create)
+    BIND(kr_index_stats) BIND(kr_index_prepare) BIND(kr_score_topk) BIND(kr_topk_merge) BIND(kr_format_ids) BIND(kr_index_search_coarse_async) BIND(kr_index_search_global_theta) BIND(kr_index_search_rerank_async) BIND(kr_topk_merge_device) BIND(kr_comm_unique_id) BIND(kr_comm_create)
     BIND(kr_comm_destroy) BIND(kr_comm_rank) BIND(kr_comm_world) BIND(kr_shard_allgather_topk) BIND(kr_encoder_create) BIND(kr_encoder_create_ex)
     BIND(kr_encoder_operand_dtype) BIND(kr_encoder_residual_lo) BIND(kr_encoder_destroy) BIND(kr_encoder_load_weight) BIND(kr_encoder_finalize)
     BIND(kr_encoder_forward) BIND(kr_encoder_forward_tt) BIND(kr_encoder_forward_packed) BIND(kr_encoder_check) BIND(kr_encoder_last_hidden)

@@ -37,10 +37,10 @@ def test_search_stats_struct_and_options_mirror_the_header():
     end = hdr.index("} kr_search_stats;")
     body = hdr[hdr.rindex("typedef struct {", 0, end):end]
     fields = re.findall(r"^\s*(?:int64_t|double)\s+([a-z0-9_]+)\s*;", body, flags=re.M)
-    assert fields == [f for f, _ in _lib.SearchStats._fields_] and fields[-2:] == ["byte_scans", "byte_marked_rows"]
+    assert fields == [f for f, _ in _lib.SearchStats._fields_] and fields[-3:] == ["byte_scans", "byte_marked_rows", "byte_rows"]
     assert C.sizeof(_lib.SearchStats) == 8 * len(fields)
     lib = _lib.load()
-    for name, back in ((b"byte_prescan", 1), (b"debug_byte_min_rows", -1), (b"force_exact_scores", 0)):
+    for name, back in ((b"byte_prescan", 1), (b"debug_byte_min_rows", -1), (b"force_exact_scores", 0), (b"debug_eps8_permille", 1000)):
         assert name.decode() in hdr
         assert lib.kr_set_option(name, 0) == 0 and lib.kr_set_option(name, back) == 0
     assert lib.kr_set_option(b"no_such_option", 1) == -22
@@ -358,7 +358,7 @@ def test_faiss_flat_file_layout_byte_for_byte(tmp_path):
     bytes / 4, then the raw float32 rows).  The expected bytes are assembled by hand from that field list — this pins our writer / reader to the
     published layout; it is NOT a round trip through faiss (not installable here), so interoperability stays unverified."""
     import struct
-    from kirag_amd.retriever import index as I
+    from kirag_amd.retriever import formats as I
 
     class Rows:                                                   # the three members write_faiss_flat_ip touches
         d = 4; ntotal = 3
@@ -393,6 +393,13 @@ def test_bulk_id_strings_equal_str_per_id():
     assert out == [[str(v) for v in row] for row in a.tolist()] and all(type(v) is str for row in out for v in row)
     assert ids_to_str_rows(a[:, ::2]) == [[str(v) for v in row] for row in a[:, ::2].tolist()]          # non-contiguous view
     assert ids_to_str_rows(np.empty((3, 0), np.int64)) == [[], [], []] and ids_to_str_rows(np.empty((0, 5), np.int64)) == []
+    # both implementations: the _fastids C extension (built next to the library when Python.h is present) and the kr_format_ids + split form behind it
+    from kirag_amd.retriever import flat_index as F
+    assert F._ids_to_str_rows_ascii(np.ascontiguousarray(a)) == out
+    if os.path.exists(os.path.join(REPO, "kirag_amd", "_fastids.so")):
+        assert F._fastids is not None and F._fastids.ids_to_str_rows(memoryview(np.ascontiguousarray(a)).cast("B"), 37, 11) == out
+        with pytest.raises(ValueError):
+            F._fastids.ids_to_str_rows(memoryview(np.ascontiguousarray(a)).cast("B"), 37, 12)
     lib = _lib.load()
     import ctypes as C
     buf = C.create_string_buffer(8); n = C.c_int64(0)

@@ -85,8 +85,8 @@ def test_token_feed_frames_arrive_in_order_and_equal_the_collator(collator, work
     def mk(s):
         return texts[s:s + 10], [str(i) for i in range(s, min(s + 10, 227))]
     items = list(range(0, 227, 10))
-    tf = feed.TokenFeed(mk, collator, items, workers, 1, 10, 12, vocab=15)
-    assert tf.R <= workers + 3
+    tf = feed.TokenFeed(mk, collator, items, workers, 1, 10, 12, vocab=15, local=False)     # workers > 0: the worker processes alone (the local thread would finish
+    assert tf.R <= workers + 4                                                              # these 23 tiny batches before a worker has imported torch)
 
     class SlowEvent:                                # stands for the upload's completion: the feed must wait for it before handing the slot on
         def __init__(self): self.done = False
@@ -105,7 +105,7 @@ def test_token_feed_frames_arrive_in_order_and_equal_the_collator(collator, work
         ev = SlowEvent(); events[id(frame.slot)] = ev
         tf.release(frame, ev)
         seen.append(frame.index)
-    assert seen == list(range(len(items)))
+    assert seen == list(range(len(items))) and tf.made_by == ({"local": 23, "workers": 0} if workers == 0 else {"local": 0, "workers": 23})
     assert not tf.procs and all(not t.is_alive() or t.join(2) is None for t in tf.threads)
 
 
@@ -123,12 +123,12 @@ def test_token_feed_reports_a_bad_batch_at_its_turn_and_worker_failures(collator
         return clean[s:s + 10], list(range(s, s + 10))
     got = []
     with pytest.raises(ValueError, match=r"starting at passage id 30 contain a token id outside \[0, 13\) \(min 2, max 13\)"):
-        for f in feed.TokenFeed(mk2, collator, range(0, 60, 10), workers, 2, 10, 12, vocab=13):
+        for f in feed.TokenFeed(mk2, collator, range(0, 60, 10), workers, 2, 10, 12, vocab=13, local=False):
             got.append(f.index)
     assert got == [0, 1, 2]
     # an exception inside the tokenizer (an empty batch: the collator raises) surfaces at the consumer, the feed shuts down
     with pytest.raises((RuntimeError, ValueError), match="text_list is None or an empty"):
-        list(feed.TokenFeed(lambda s: ([], [s]), collator, range(3), workers, 1, 10, 12))
+        list(feed.TokenFeed(lambda s: ([], [s]), collator, range(3), workers, 1, 10, 12, local=False))
     # abandoning the iterator stops workers and threads
     n0 = threading.active_count()
     tf = feed.TokenFeed(mk, collator, range(0, 60, 10), workers, 1, 10, 12)
@@ -195,10 +195,37 @@ def test_shard_files_are_identical_through_every_feed(tmp_path, collator):
     torch.testing.assert_close(e, ref)
 
 
+def test_local_thread_and_workers_share_one_stream_and_a_worker_that_cannot_start_is_not_fatal(collator, caplog):
+    """Dynamic hand-out: the local tokenizer thread carries the stream while worker processes start and both kinds produce frames of one ordered stream; a
+    collator that cannot be pickled (or a worker that dies on start) costs the speed-up, not the run."""
+    texts = texts_of(400)
+
+    def mk(s):
+        time.sleep(0.05)                       # slow dataset access: keeps the stream alive long enough for the workers to join in
+        return texts[s:s + 4], list(range(s, s + 4))
+    tf = feed.TokenFeed(mk, collator, range(0, 400, 4), 2, 2, 4, 12)
+    for k, frame in enumerate(tf):
+        assert frame.index == k
+        ref = collator.encode_doc(texts[4 * k:4 * k + 4])
+        assert torch.equal(frame.inputs()["input_ids"], ref["input_ids"])
+    assert tf.made_by["local"] > 0 and tf.made_by["local"] + tf.made_by["workers"] == 100
+    # (whether a worker got a batch depends on how fast this machine imports torch; the pure-worker path is covered above)
+
+    class Unpicklable(E5Collator):
+        def __reduce__(self):
+            raise TypeError("no pickle for you")
+    col2 = Unpicklable(tokenizer=collator.tokenizer, query_maxlength=16, doc_maxlength=12)
+    with caplog.at_level("WARNING"):
+        out = [f.index for f in feed.TokenFeed(lambda s: (texts[s:s + 4], [s]), col2, range(0, 40, 4), 2, 1, 4, 12)]
+    assert out == list(range(10)) and "tokenising in-process only" in caplog.text
+    with pytest.raises(TypeError):
+        list(feed.TokenFeed(lambda s: (texts[s:s + 4], [s]), col2, range(0, 40, 4), 2, 1, 4, 12, local=False))
+
+
 def test_default_tokenizer_workers_and_writer_errors(tmp_path):
     assert CC.default_tokenizer_workers(1000, on_gpu=False) == 0 and CC.default_tokenizer_workers(3, on_gpu=True) == 0
     w = CC.default_tokenizer_workers(1000, on_gpu=True)
-    assert 0 <= w <= 8 and w <= max(1, len(os.sched_getaffinity(0)) // 2)
+    assert 0 <= w <= 4 and w <= max(1, len(os.sched_getaffinity(0)) // 4)
     assert CC.setup_parser([]).tokenizer_workers == -1
     # a failure on the writer thread (here: the folder vanished) reaches the encode thread
     wr = CC._ShardWriter(str(tmp_path / "missing" / "dir"), 0, 8, 4, 4, on_gpu=False)

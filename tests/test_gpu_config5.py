@@ -159,9 +159,13 @@ def test_config5_three_hops_at_size(kind):
             # ---- retrieval step: nq = 1 (hop 0) or 2, top-10 over the 5M rows ----------------------------------------------------------------------
             nq = 1 if hop == 0 else 2
             for qv in (planted[2 * hop: 2 * hop + nq].contiguous(), torch.from_numpy(qe[:nq]).to(dev).contiguous()):
+                scans_before = ix.stats()["byte_scans"]
                 s, i = ix.search(qv, 10)
                 st = ix.stats()
                 assert st["exact"] == 0, st
+                # the hop's search really took the int8 pre-scan (a silently switched-off path - feedback state, a failed allocation -
+                # would otherwise pass this test on the 16-bit round); the independent top-k below then checks what that path returned
+                assert st["byte_scans"] == scans_before + 1 and st["byte_rows"] == N_ROWS, st
                 searched_q.append(qv); searched.append((s, i))
             s_p, i_p = searched[-2]
             assert i_p[:, 0].tolist() == list(range(2 * hop, 2 * hop + nq))          # planted neighbour first

@@ -665,6 +665,50 @@ def test_metric_size_5M_all_queries_vs_independent_topk(kind):
         assert np.array_equal(ia.cpu().numpy(), np.roll(i, r, axis=0)) and np.array_equal(sa.cpu().numpy().view(np.uint32), np.roll(s, r, axis=0).view(np.uint32))
 
 
+@pytest.mark.parametrize("kind", ["gaussian", "e5like"])
+def test_metric_size_5M_small_blocks_take_the_byte_prescan_and_meet_the_independent_topk(kind):
+    """The int8 pre-scan at the metric's size against a formulation that shares nothing with it (only nq <= 2 met the independent
+    top-k at 5M rows): blocks of 1 / 8 / 32 queries, top-10 and top-100, over 5M x 1024 rows — every search must have taken the pre-scan (byte_scans), every
+    query is compared with the fp32 sgemm + topk over the regenerated corpus, the score bits of the 8-query block with the C oracle on the gathered rows, and
+    every result equals the same search with the pre-scan switched off bit for bit.  (e5like blocks of 32 queries mark more than n / 8 rows: still exact, and
+    after four such blocks the index pauses the path - the feedback the state-machine test below drives on purpose.)"""
+    import torch
+    n, d = 5_000_000, 1024
+    ix, cd, _, head = _build_resident(n, d, kind, keep_chunks=False)
+    gq = torch.Generator(device="cuda"); gq.manual_seed(2)
+    q_all = cd.queries_near(head[:41], gq)
+    cases = [(q_all[0:1], 10), (q_all[1:9], 100), (q_all[9:41], 10)]
+    got = []
+    _opt(b"byte_prescan", 1); _opt(b"debug_byte_min_rows", -1)
+    try:
+        for q, k in cases:
+            q = q.contiguous()
+            before = ix.stats()["byte_scans"]
+            s, i = ix.search(q, k)
+            st = ix.stats()
+            assert st["byte_scans"] == before + 1 and st["byte_rows"] == n and st["exact"] == 0, (len(q), k, st)
+            _opt(b"byte_prescan", 0)
+            s0, i0 = ix.search(q, k)
+            _opt(b"byte_prescan", 1)
+            assert ix.stats()["byte_scans"] == before + 1
+            assert np.array_equal(i, i0) and np.array_equal(s.view(np.uint32), s0.view(np.uint32)), (len(q), k)
+            got.append((s, i))
+            print(f"[5M {kind}] nq={len(q)} k={k}: pre-scan marked {st['byte_marked_rows']} rows so far, total {st['last_total_ms']:.2f} ms")
+    finally:
+        _opt(b"byte_prescan", 1)
+    rs, ri = IC.torch_topk_fp32(q_all.contiguous(), _regen_chunks(n, d, kind), 100 + 32)
+    rs, ri = rs.cpu().numpy(), ri.cpu().numpy()
+    lo = 0
+    for (q, k), (s, i) in zip(cases, got):
+        out = IC.check_membership(s, i, rs[lo:lo + len(q), :k + 32], ri[lo:lo + len(q), :k + 32], k)
+        assert out["queries"] == len(q)
+        lo += len(q)
+    s, i = got[1]
+    xs = ix.reconstruct_rows(i.reshape(-1))
+    sc = S.scores_at(q_all[1:9].cpu().numpy(), xs, np.arange(i.size).reshape(i.shape).astype(np.int64))
+    assert np.array_equal(sc.view(np.uint32), s.view(np.uint32))
+
+
 def test_config4_size_21M_search_only_vs_independent_topk():
     """BASELINE config 4's corpus size on ONE GPU: 21,015,324 x 1024 (43 GB bf16 + 86 GB fp32 resident), 256 queries, top-100, search only;
     every query against the kernel-independent fp32 sgemm + topk over the regenerated corpus."""
@@ -794,12 +838,14 @@ def test_byte_prescan_f16_coarse_copy_and_row_shards_in_split_form(byte_everywhe
     assert np.array_equal(mi, io) and np.array_equal(ms.view(np.uint32), so.view(np.uint32))
 
 
-def test_byte_prescan_bound_holds_for_a_row_built_to_reach_it(byte_everywhere):
+def _row_built_to_reach_the_byte_bound():
     """Random data leaves the byte bound ~30 x slack, so a too-small eps8 would pass every other test.  Here a row of the exact top-k is BUILT so that its byte
-    score underestimates its exact score by ~96 % of the Cauchy-Schwarz bound: the query has equal-magnitude components (the inequality is tight), every
-    component of the row sits 1/64 of a step short of a rounding boundary on the side that loses against the query's sign, one component pins the row's scale to
-    a power of two, the first 65 536 rows come in +- pairs (centre exactly 0, unit weights).  k - 1 anchors and one further anchor with exact scores just
-    below the built row's sit in the tiles of the 16-bit rounds, the built row in a tile of the byte round: it must displace the lowest anchor."""
+    score underestimates its exact score by > 99.9 % of |u| |r - r^|, the Cauchy-Schwarz term that dominates eps8 (k_scan8_prep): the query has equal-magnitude
+    components (the inequality is tight), every component of the row sits 1/64 of a step short of a rounding boundary on the side that loses against the query's
+    sign (31/64 of a step lost per component, against the 1/2 the worst case allows: the built row also sets max |r - r^| over the index), one component pins the
+    row's scale to a power of two, the first 65 536 rows come in +- pairs (centre exactly 0, unit weights).  k - 1 anchors and one further anchor with exact
+    scores just below the built row's sit in the tiles of the 16-bit rounds, the built row in a tile of the byte round: it must displace the lowest anchor.
+    Returns (x, q, k, built row, anchor rows)."""
     from math import gcd
     rng = np.random.default_rng(20260)
     n, d, k = 400_000, 1024, 10
@@ -849,14 +895,44 @@ def test_byte_prescan_bound_holds_for_a_row_built_to_reach_it(byte_everywhere):
     exact_built = float((q[0].astype(np.float64) * row).sum())
     err = row - s_ * np.rint(row / s_)                             # what the int8 copy loses of the built row
     under = float((q[0].astype(np.float64) * err).sum())
-    assert abs(exact_built - target) < 2e-5 and under > 0.95 * float(np.linalg.norm(err)) > 0.013, (exact_built, under, float(np.linalg.norm(err)))
-    ix = _mk(d, x)
+    assert abs(exact_built - target) < 2e-5 and under > 0.999 * float(np.linalg.norm(err)) > 0.013, (exact_built, under, float(np.linalg.norm(err)))
+    return x, q, k, built, anchor_rows
+
+
+def test_byte_prescan_bound_holds_for_a_row_built_to_reach_it(byte_everywhere):
+    """The real bound (debug_eps8_permille = 1000, the default) marks the built row: rows and score bits equal the C oracle's."""
+    x, q, k, built, anchor_rows = _row_built_to_reach_the_byte_bound()
+    ix = _mk(x.shape[1], x)
     s, i = ix.index.search(q, k)
     st = ix.index.stats(reset=True)
     so, io = S.search_canonical(q, x, k)
     assert st["byte_scans"] == 1, st
     assert built in io[0] and anchor_rows[0] not in io[0]          # the oracle agrees with the construction
     assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32)), (i, io)
+
+
+def test_byte_prescan_mutant_bound_misses_the_built_row(byte_everywhere):
+    """The test above has teeth (that claim used to live in a commit message): the SAME index searched with the pre-scan's bound scaled to
+    750 permille (kr_set_option "debug_eps8_permille", a mutation hook) does NOT mark the built row — the lowest anchor stays in the result, which is therefore
+    wrong — while 1000 permille, set explicitly before and after, returns the oracle's rows.  The pre-scan ran in all three searches (byte_scans)."""
+    x, q, k, built, anchor_rows = _row_built_to_reach_the_byte_bound()
+    ix = _mk(x.shape[1], x)
+    so, io = S.search_canonical(q, x, k)
+    try:
+        got = {}
+        for permille in (1000, 750, 1000):
+            _opt(b"debug_eps8_permille", permille)
+            s, i = ix.index.search(q, k)
+            st = ix.index.stats(reset=True)
+            assert st["byte_scans"] == 1, (permille, st)
+            got.setdefault(permille, []).append((s.copy(), i.copy()))
+        for s, i in got[1000]:
+            assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+        s, i = got[750][0]
+        assert built not in i[0] and anchor_rows[0] in i[0], "a bound 25 % too small still found the built row: the construction has lost its teeth"
+        assert sorted(set(io[0]) - set(i[0])) == [built]               # everything else is still right: the one row the bound exists for is the one that is lost
+    finally:
+        _opt(b"debug_eps8_permille", 1000)
 
 
 def test_byte_prescan_rows_added_later_and_anisotropic_rows(byte_everywhere):
@@ -909,6 +985,91 @@ def test_byte_prescan_nan_row_marks_everything_once_then_steps_aside(byte_everyw
         assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32)) and not (i == 12345).any()
         assert st["byte_scans"] == (1 if call == 0 else 0), (call, st)
     
+
+def test_byte_prescan_feedback_pause_and_resume_state_machine(byte_everywhere):
+    """The feedback that keeps the pre-scan off data it cannot separate (search.hip: byte_bad / byte_pause).  A quarter of the rows are near-duplicates of one
+    direction: a block aiming at that cluster has all of them inside the byte bound (marks > n / 8 rows), a block aiming anywhere else marks a handful.
+    Three bad blocks, one good one (the count starts over), three bad ones (still scanning), the FOURTH bad block in a row pauses the path for the next 1024 small
+    blocks (16-bit final round), block 1029 takes the pre-scan again, and four more bad blocks pause it again.  Results are the C oracle's through every
+    transition."""
+    rng = np.random.default_rng(1707)
+    n, d, k = 24_000, 1024, 5
+    x = _unit(rng, n, d)
+    b = x[0].copy()
+    z = rng.standard_normal((6000, d)).astype(np.float32)
+    x[:6000] = b + 3e-5 * z
+    x[:6000] /= np.linalg.norm(x[:6000], axis=1, keepdims=True)
+    bad = (b + 1e-3 * rng.standard_normal((2, d)).astype(np.float32)); bad /= np.linalg.norm(bad, axis=1, keepdims=True)
+    good, _ = _queries_near(rng, x[10_000:10_100], 2)
+    ix = _mk(d, x)
+    ref = {id(bad): S.search_canonical(bad, x, k), id(good): S.search_canonical(good, x, k)}
+
+    def one(q, scan, many=None):
+        s, i = ix.index.search(q, k)
+        st = ix.index.stats(reset=True)
+        so, io = ref[id(q)]
+        assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32))
+        assert st["byte_scans"] == (1 if scan else 0), st
+        if many is not None:
+            assert (st["byte_marked_rows"] > n // 8) == many, st
+    for _ in range(3):
+        one(bad, True, many=True)
+    one(good, True, many=False)            # resets the count
+    for _ in range(3):
+        one(bad, True, many=True)
+    one(bad, True, many=True)              # the fourth in a row: paused from here on
+    for c in range(1024):
+        one(bad if c % 2 else good, False)
+    one(bad, True, many=True)              # block 1029: resumed
+    for _ in range(3):
+        one(bad, True, many=True)
+    one(good, False)                       # ... and paused again after four more bad blocks
+
+
+def test_index_prepare_builds_the_byte_copy_ahead_of_the_first_hop_and_gives_it_up_for_rows():
+    """kr_index_prepare (ABI 9; Indexer.index_data / deserialize_from call it from 2^19 rows on): the int8 copy and the workspaces of a one-query top-10 search exist
+    BEFORE the first hop (byte_rows == ntotal, first search = byte scan), rows added later extend the copy at the next prepare, searches on a torch side stream
+    see a complete copy, results equal the unprepared index's bit for bit; an index below the threshold, a 33-query shape or byte_prescan = 0 build nothing."""
+    import torch
+    from kirag_amd.retriever.index import FlatIPIndex, Indexer
+    n, d = 600_000, 1024
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(21)
+    x = torch.nn.functional.normalize(torch.randn(n, d, device=dev, generator=g), dim=1)
+    q = torch.nn.functional.normalize(x[:2] + 0.05 * torch.randn(2, d, device=dev, generator=g), dim=1)
+    plain = FlatIPIndex(d, device=0); plain.add(x)
+    assert plain.stats()["byte_rows"] == 0
+    s_ref, i_ref = plain.search(q, 10)
+    ixr = Indexer(d)
+    ixr.index_data([str(v) for v in range(400_000)], x[:400_000])
+    assert ixr.index.stats()["byte_rows"] == 0                       # below 2^19 rows: nothing prepared
+    ixr.index_data([str(v) for v in range(400_000, n)], x[400_000:])
+    st = ixr.index.stats()
+    assert st["byte_rows"] == n and st["byte_scans"] == 0, st        # built by index_data, no search yet
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                                    # a search on another stream right behind the build
+        s1, i1 = ixr.index.search(q, 10)
+    st = ixr.index.stats()
+    assert st["byte_scans"] == 1 and np.array_equal(i1, i_ref) and np.array_equal(s1.view(np.uint32), s_ref.view(np.uint32)), st
+    extra = torch.nn.functional.normalize(q[:1] + 0.01 * torch.randn(3, d, device=dev, generator=g), dim=1)
+    ixr.index_data(["900001", "900002", "900003"], extra)            # the copy follows the rows
+    assert ixr.index.stats()["byte_rows"] == n + 3
+    res = ixr.search_knn(q[:1].cpu().numpy(), 5, verbose=False)
+    assert set(res[0][0][:4]) == {"0", "900001", "900002", "900003"}
+    # shapes / settings that do not take the pre-scan prepare workspaces only
+    other = FlatIPIndex(d, device=0); other.add(x)
+    other.prepare(33, 10)
+    assert other.stats()["byte_rows"] == 0
+    _opt(b"byte_prescan", 0)
+    try:
+        other.prepare(1, 10)
+        assert other.stats()["byte_rows"] == 0
+    finally:
+        _opt(b"byte_prescan", 1)
+    other.prepare(1, 10)
+    assert other.stats()["byte_rows"] == n
+    FlatIPIndex(d, device=0).prepare(1, 10)                          # an empty index: no-op
+
 
 def test_byte_prescan_at_the_product_threshold_600k_rows():
     """The product's own switch-over (>= 2^19 rows): 600k x 1024 rows, 1 / 2 / 8 / 32 queries, top-10 and top-100, option on == option off bit for bit, a query

@@ -76,14 +76,23 @@ for _ in range(20):
 torch.cuda.synchronize()
 enc_rate = 20 * 512 / (time.perf_counter() - t0)
 print(f"[encoder] pre-tokenised resident batches of 512: {enc_rate:.0f} passages/s", flush=True)
-for depth, workers in ((2, 0), (8, 0), (2, 8), (8, 8)):
-    args = SimpleNamespace(local_rank=-1, save_dir=td, name="f", index_folder=f"d{depth}w{workers}", per_gpu_batch_size=8, num_passage_per_index_file=10**9,
-                           encode_batch_size=512, prefetch_batches=depth, tokenizer_workers=workers, no_embedding_files=True)
+def run_loop(label, model, **kw):
+    args = SimpleNamespace(local_rank=-1, save_dir=td, name="f", index_folder=label.replace(" ", "_"), per_gpu_batch_size=8, num_passage_per_index_file=10**6,
+                           encode_batch_size=512, **kw)
     t0 = time.perf_counter()
-    CC.cal_doc_embeddings(args, Model(), Corpus(), col, device=dev)
+    CC.cal_doc_embeddings(args, model, Corpus(), col, device=dev)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"[end to end] prefetch_batches={depth} tokenizer_workers={workers}: {n / dt:.0f} passages/s = {n / dt / enc_rate * 100:.0f} % of the encoder-only rate", flush=True)
+    print(f"[end to end] {label}: {n / dt:.0f} passages/s = {n / dt / enc_rate * 100:.0f} % of the encoder-only rate", flush=True)
+    import shutil
+    shutil.rmtree(os.path.join(td, "f", args.index_folder), ignore_errors=True)
+run_loop("warm-up (process start, first allocations)", Model(), no_embedding_files=True)
+run_loop("DEFAULT flags (tokenizer_workers=-1, prefetch_batches=2), shard files written", Model())
+run_loop("default flags, no_embedding_files", Model(), no_embedding_files=True)
+for depth, workers in ((2, 0), (2, 4), (2, 8), (8, 8)):
+    run_loop(f"prefetch_batches={depth} tokenizer_workers={workers} no_embedding_files", Model(), prefetch_batches=depth, tokenizer_workers=workers, no_embedding_files=True)
+run_loop("padded_feed=True (the rounds 3-5 upload: int64 input_ids + attention_mask) tokenizer_workers=8 no_embedding_files", Model(), padded_feed=True,
+         tokenizer_workers=8, no_embedding_files=True)
 
 # the same loop through the MODULE surface the reference's callers use (E5Encoder.forward with input_ids / attention_mask / token_type_ids on the device):
 # until round 3 its token_type_ids test synchronised the host on every forward (round 4: the types go to the kernels, nothing is tested on the host)
@@ -98,19 +107,6 @@ class ModelM:
     def eval(self): return self
     def doc(self, a): return mod(**a)
     def doc_packed(self, ids, lens, S, T=None): return mod.forward_packed(ids, lens, S, T)
-warm = SimpleNamespace(local_rank=-1, save_dir=td, name="f", index_folder="warm", per_gpu_batch_size=8, num_passage_per_index_file=10**9,
-                       encode_batch_size=512, prefetch_batches=8, tokenizer_workers=8, no_embedding_files=True)
-class Small(Corpus):
-    def __len__(self): return 4096
-CC.cal_doc_embeddings(warm, ModelM(), Small(), col, device=dev)
-for sync in (False, True):
-    if sync:      # emulate the old behaviour: a host round trip per forward
-        orig_fwd = mod._hip.forward
-        mod._hip.forward = lambda *a, **k: (torch.cuda.synchronize(), orig_fwd(*a, **k))[1]
-    args = SimpleNamespace(**{**vars(warm), "index_folder": "m%d" % int(sync)})
-    t0 = time.perf_counter()
-    CC.cal_doc_embeddings(args, ModelM(), Corpus(), col, device=dev)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tag = " + a host synchronisation per forward (the rounds 1-2 behaviour)" if sync else ""
-    print(f"[end to end, module surface{tag}] prefetch_batches=8 tokenizer_workers=8: {n / dt:.0f} passages/s = {n / dt / enc_rate * 100:.0f} % of the encoder-only rate", flush=True)
+run_loop("module surface (E5Encoder.forward_packed), DEFAULT flags, shard files written", ModelM())
+run_loop("module surface, padded_feed=True tokenizer_workers=8 (E5Encoder.forward on int64 input_ids / attention_mask)", ModelM(), padded_feed=True, tokenizer_workers=8,
+         no_embedding_files=True)
