@@ -16,11 +16,12 @@ import logging
 import os
 import pickle
 import threading
+import time
 from typing import Optional
 
 import torch
 
-from . import feed
+from . import feed, tensor_pickle
 from .collators import COLLATOR_MAP
 from .retriever.retrievers import InBatchRetriever
 from .utils import prefetch_map, to_device
@@ -47,7 +48,7 @@ def setup_parser(argv=None):
     parser.add_argument("--prefetch_batches", type=int, default=2, help="batches tokenised ahead of the GPU on a background thread")
     parser.add_argument("--tokenizer_workers", type=int, default=-1,
                         help="tokenizer worker PROCESSES next to the in-process tokenizer thread (each with its own tokenizer; batches are handed out "
-                             "dynamically and come back in order); 0: the thread alone; -1 (default): min(4, cpus / 4) for a GPU run over more than a few batches")
+                             "dynamically and come back in order); 0: the thread alone; -1 (default): 0 below 200k passages per rank, else min(4, usable cpus / 4)")
     parser.add_argument("--no_embedding_files", action="store_true",
                         help="do not write corpus_embeddings_*.pkl / passage_id_list_*.pkl (streamed encode straight into a resident index shard)")
     return parser.parse_args(argv)
@@ -58,28 +59,55 @@ def shard_range(n: int, rank: int, world: int):
     return min(rank * per, n), min((rank + 1) * per, n)
 
 
-def default_tokenizer_workers(n_batches: int, on_gpu: bool) -> int:
-    """``--tokenizer_workers -1``.  The feed always tokenises on one thread of this process (with the tokenizer's own thread pool: ~11 k passages/s on the GPU
-    box against an encoder that takes ~13.6 k, profiles/r06/feed_bench.txt); worker processes add capacity for slower hosts and join the stream once they have
-    started.  A GPU run over more than a few batches gets min(4, cpus / 4) of them; tiny corpora and host-only runs none (no process start-up cost)."""
-    if not on_gpu or n_batches <= 4:
-        return 0
+def effective_cpus() -> int:
+    """CPUs this process may really use: the affinity mask, capped by the cgroup's CPU quota (a 16-CPU share of a 256-CPU machine shows 256 in both
+    ``os.cpu_count()`` and the affinity mask; thread pools sized by those get throttled by the scheduler, and every thread of the group stalls with them)."""
     try:
-        cpus = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        cpus = os.cpu_count() or 1
-    return max(0, min(4, cpus // 4, n_batches))
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),):
+        try:
+            q, period = parse(open(path).read())
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(period))))
+        except (OSError, ValueError, IndexError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and period > 0:
+            n = min(n, max(1, q // period))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+WORKERS_FROM_PASSAGES = 200_000
+
+
+def default_tokenizer_workers(n_passages: int, on_gpu: bool) -> int:
+    """``--tokenizer_workers -1``.  The feed always tokenises on one thread of this process, with the tokenizer's own thread pool: on the GPU box (16-CPU share)
+    that alone delivers 97 % of the encoder's rate (profiles/r06/feed_probe.txt).  Worker processes add capacity for hosts with a slower tokenizer, at a price:
+    each takes 2-3 s to import torch + transformers, during which the CPU burst gets the cgroup throttled (-15 % on a 50 k-passage run), so they are started
+    only when this rank's share is large enough to amortise that (>= 200 k passages, ~15 s of encoding): min(4, usable cpus / 4) of them."""
+    if not on_gpu or n_passages < WORKERS_FROM_PASSAGES:
+        return 0
+    return max(0, min(4, effective_cpus() // 4))
 
 
 class _ShardWriter:
-    """The D2H -> file-buffer -> ``.pkl`` half of the loop on its own thread: the encode loop hands over (event, pinned rows, passage ids) and goes on launching;
-    this thread waits for the copy, appends the rows to the buffer of the current shard file (allocated at its final size: no list of chunks, no ``torch.cat``)
-    and writes ``corpus_embeddings_{s}_{e}.pkl`` / ``passage_id_list_{s}_{e}.pkl`` (compute_corpus_embeddings.py:101-120) whenever ``cap`` rows are complete."""
+    """The D2H -> ``.pkl`` half of the loop on its own thread: the encode loop hands over (event, pinned rows, passage ids) and goes on launching; this thread waits
+    for the copy and appends the rows to the current shard file, which is written as a STREAM (``tensor_pickle.StreamingTensorPickle``: the same tensor pickle the
+    reference's ``pickle.dump`` writes, compute_corpus_embeddings.py:101-115, emitted head - rows - tail) straight from the pinned landing buffer: no [n, hidden]
+    staging tensor on the host, no ``torch.cat``, and nothing left to do after the last batch.  ``passage_id_list_{s}_{e}.pkl`` follows when ``cap`` rows
+    (or the rank's last rows) are complete.  ``stream=False`` (or a torch whose tensor pickle the stream writer does not recognise): rows are buffered in a
+    tensor allocated at the file's final size and written with ``pickle.dump``."""
 
-    def __init__(self, folder: str, start: int, end: int, cap: int, bs: int, on_gpu: bool, depth: int = 4):
+    def __init__(self, folder: str, start: int, end: int, cap: int, bs: int, on_gpu: bool, depth: int = 4, stream: bool = True):
         import queue
         self.folder, self.end, self.cap, self.bs, self.on_gpu = folder, end, cap, bs, on_gpu
-        self.file_start, self.rows, self.ids, self.buf = start, 0, [], None
+        self.stream = bool(stream) and tensor_pickle.available()
+        self.file_start, self.rows, self.ids, self.buf, self.out, self.rows_total = start, 0, [], None, None, 0
         self.free: "queue.Queue" = queue.Queue()
         self.work: "queue.Queue" = queue.Queue()
         self.depth, self.made, self.error = depth, 0, None
@@ -105,28 +133,48 @@ class _ShardWriter:
         if self.error is not None:
             raise self.error
 
-    def _flush(self) -> None:
+    def _names(self, upto: int):
+        return (os.path.join(self.folder, f"corpus_embeddings_{self.file_start}_{upto - 1}.pkl"),
+                os.path.join(self.folder, f"passage_id_list_{self.file_start}_{upto - 1}.pkl"))
+
+    def _finish_file(self) -> None:
+        """``self.rows`` rows of the current file are in: close / write the embeddings file, write the id list, start over."""
         if not self.ids:
             return
         upto = self.file_start + self.rows
-        emb = self.buf if self.rows == self.buf.shape[0] else self.buf[:self.rows].clone()
+        emb_file, ids_file = self._names(upto)
         logger.info(f"Finished calculating embeddings from {self.file_start} to {upto - 1}. Saving embeddings to {self.folder} ...")
-        with open(os.path.join(self.folder, f"corpus_embeddings_{self.file_start}_{upto - 1}.pkl"), "wb") as f:
-            pickle.dump(emb, f)
-        with open(os.path.join(self.folder, f"passage_id_list_{self.file_start}_{upto - 1}.pkl"), "wb") as f:
+        if self.out is not None:
+            self.out.close()                                 # (raises if fewer rows than announced were streamed: the .tmp file is removed)
+        else:
+            emb = self.buf if self.rows == self.buf.shape[0] else self.buf[:self.rows].clone()
+            with open(emb_file, "wb") as f:
+                pickle.dump(emb, f)
+        with open(ids_file, "wb") as f:
             pickle.dump(self.ids, f)
-        self.file_start, self.rows, self.ids, self.buf = upto, 0, [], None
+        self.file_start, self.rows, self.ids, self.buf, self.out = upto, 0, [], None, None
 
     def _append(self, emb: torch.Tensor, ids) -> None:
+        emb_np = emb.numpy()
         while len(ids):
-            if self.buf is None:
-                self.buf = torch.empty((max(1, min(self.cap, self.end - self.file_start)), emb.shape[1]), dtype=torch.float32)
-            take = min(len(ids), self.buf.shape[0] - self.rows)
-            self.buf[self.rows:self.rows + take].copy_(emb[:take])
+            if self.buf is None and self.out is None:
+                self.rows_total = max(1, min(self.cap, self.end - self.file_start))
+                if self.stream:
+                    self.out = tensor_pickle.StreamingTensorPickle(self._names(self.file_start + self.rows_total)[0], self.rows_total, emb_np.shape[1])
+                else:
+                    self.buf = torch.empty((self.rows_total, emb_np.shape[1]), dtype=torch.float32)
+                    self.buf_np = self.buf.numpy()
+            take = min(len(ids), self.rows_total - self.rows)
+            if self.out is not None:
+                self.out.append(emb_np[:take])               # file write straight from the pinned landing buffer (the GIL is released in the system call)
+            else:
+                # numpy, not Tensor.copy_: a 2-MB torch CPU copy fans out over the intra-op pool (128 threads on the GPU box) and the burst gets the whole
+                # cgroup throttled - writing the files cost 55 cpu-seconds and a fifth of the encoder's rate that way (profiles/r06/feed_probe.txt)
+                self.buf_np[self.rows:self.rows + take] = emb_np[:take]
             self.ids.extend(ids[:take]); self.rows += take
-            emb, ids = emb[take:], ids[take:]
-            if self.rows == self.buf.shape[0]:
-                self._flush()
+            emb_np, ids = emb_np[take:], ids[take:]
+            if self.rows == self.rows_total:
+                self._finish_file()
 
     def _run(self) -> None:
         while True:
@@ -146,8 +194,13 @@ class _ShardWriter:
     def close(self, flush: bool = True) -> None:
         self.work.put(None)
         self.thread.join()
-        if flush and self.error is None:
-            self._flush()
+        try:
+            if flush and self.error is None:
+                self._finish_file()                          # a partial last file (only if fewer rows arrived than the rank's range holds)
+        except BaseException as e:   # noqa: BLE001
+            self.error = self.error or e
+        if self.out is not None:                             # an unfinished stream: never leave half a pickle behind
+            self.out.abort(); self.out = None
         self.check()
 
 
@@ -176,7 +229,7 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
     on_gpu = torch.device(device).type == "cuda"
     workers = int(getattr(args, "tokenizer_workers", -1))
     if workers < 0:
-        workers = default_tokenizer_workers(len(batches), on_gpu)
+        workers = default_tokenizer_workers(end - start, on_gpu)
     use_packed = on_gpu and hasattr(model, "doc_packed") and not bool(getattr(args, "padded_feed", False))
     # Token ids are validated on the HOST, before the batch goes anywhere: the HIP forward reports an id outside the vocabulary only after the fact
     # (deferred error word, enc.check() below), by which time the batch's rows would already sit in the resident shard and in the .pkl buffers.
@@ -204,9 +257,10 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
         source = tokens
     else:
         source = prefetch_map(collate_checked, batches, depth=depth)
-    writer = _ShardWriter(folder, start, end, cap, bs, on_gpu) if write_files else None
+    writer = _ShardWriter(folder, start, end, cap, bs, on_gpu, stream=not bool(getattr(args, "buffered_shard_files", False))) if write_files else None
     pad_id = getattr(getattr(collator, "tokenizer", None), "pad_token_id", None) or 0
     ok = False
+    t_loop = time.perf_counter()
     try:
         for item in source:
             ev_in = None
@@ -235,7 +289,9 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
                     ev = torch.cuda.Event(); ev.record()
                 writer.put(ev, host, emb.shape[0], ids)
         ok = True
+        t_loop = time.perf_counter() - t_loop
     finally:
+        t_tail = time.perf_counter()
         if tokens is not None:
             tokens.close()
         if writer is not None:
@@ -249,7 +305,7 @@ def cal_doc_embeddings(args, model, corpus_dataset, collator, rank: int = 0, wor
     enc = getattr(getattr(model, "encoder", None), "_hip", None)
     if enc is not None:
         enc.check()                                          # token ids outside the vocabulary surface here at the latest
-    cal_doc_embeddings.last_feed = {"tokenizer_workers": workers, "packed_forward": bool(use_packed),
+    cal_doc_embeddings.last_feed = {"tokenizer_workers": workers, "packed_forward": bool(use_packed), "loop_s": t_loop, "tail_s": time.perf_counter() - t_tail,
                                     "batches_by_producer": dict(tokens.made_by) if tokens is not None else None}
     return start, end
 

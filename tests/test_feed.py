@@ -188,6 +188,8 @@ def test_shard_files_are_identical_through_every_feed(tmp_path, collator):
     assert sorted(base) == ["corpus_embeddings_0_49.pkl", "corpus_embeddings_100_130.pkl", "corpus_embeddings_50_99.pkl",
                             "passage_id_list_0_49.pkl", "passage_id_list_100_130.pkl", "passage_id_list_50_99.pkl"]
     same(run("procs", tokenizer_workers=3, prefetch_batches=1), base)
+    same(run("buffered", tokenizer_workers=0, buffered_shard_files=True), base)          # pickle.dump of a staged tensor (rounds 1-5) == the streamed file
+    assert not [f for f in os.listdir(os.path.join(str(tmp_path), "inproc", "f")) if f.endswith(".tmp")]
     e = base["corpus_embeddings_100_130.pkl"]
     assert isinstance(e, torch.Tensor) and tuple(e.shape) == (31, 16)
     assert pickle.loads(base["passage_id_list_100_130.pkl"]) == [str(3 * i + 7) for i in range(100, 131)]
@@ -223,9 +225,9 @@ def test_local_thread_and_workers_share_one_stream_and_a_worker_that_cannot_star
 
 
 def test_default_tokenizer_workers_and_writer_errors(tmp_path):
-    assert CC.default_tokenizer_workers(1000, on_gpu=False) == 0 and CC.default_tokenizer_workers(3, on_gpu=True) == 0
-    w = CC.default_tokenizer_workers(1000, on_gpu=True)
-    assert 0 <= w <= 4 and w <= max(1, len(os.sched_getaffinity(0)) // 4)
+    assert CC.default_tokenizer_workers(10**7, on_gpu=False) == 0 and CC.default_tokenizer_workers(199_999, on_gpu=True) == 0
+    w = CC.default_tokenizer_workers(10**7, on_gpu=True)
+    assert 0 <= w <= 4 and w <= max(1, len(os.sched_getaffinity(0)) // 4) and 1 <= CC.effective_cpus() <= len(os.sched_getaffinity(0))
     assert CC.setup_parser([]).tokenizer_workers == -1
     # a failure on the writer thread (here: the folder vanished) reaches the encode thread
     wr = CC._ShardWriter(str(tmp_path / "missing" / "dir"), 0, 8, 4, 4, on_gpu=False)
@@ -233,3 +235,36 @@ def test_default_tokenizer_workers_and_writer_errors(tmp_path):
     wr.put(None, host, 4, ["a", "b", "c", "d"])
     with pytest.raises(FileNotFoundError):
         wr.close()
+
+
+def test_streaming_tensor_pickle_is_a_tensor_pickle(tmp_path):
+    """kirag_amd/tensor_pickle.py: the streamed ``corpus_embeddings_*.pkl`` is what the reference's reader opens (faiss_index_corpus.py:38 ``pickle.load`` -> fp32
+    ``torch.Tensor [n, hidden]``): loads equal to ``pickle.dump(tensor)``'s result (values bit for bit, dtype, shape, strides, exactly-sized storage, no grad), the
+    storage container head is torch's own byte for byte (selftest), row blocks of any size may be appended, and a stream that is not completed leaves nothing."""
+    from kirag_amd import tensor_pickle as TP
+    assert TP.selftest() and TP.available()
+    rng = np.random.default_rng(0)
+    for rows, d in ((1, 16), (1000, 1024), (257, 384)):
+        x = rng.standard_normal((rows, d)).astype(np.float32)
+        x[0, 0] = np.nan; x[-1, -1] = -0.0
+        p = str(tmp_path / f"s_{rows}_{d}.pkl")
+        w = TP.StreamingTensorPickle(p, rows, d)
+        cuts = sorted(set([0, rows] + rng.integers(0, rows + 1, 5).tolist()))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            w.append(x[a:b])
+        w.close()
+        assert not os.path.exists(p + ".tmp")
+        got = pickle.load(open(p, "rb"))
+        ref = pickle.loads(pickle.dumps(torch.from_numpy(x.copy())))
+        assert type(got) is torch.Tensor and got.dtype == ref.dtype and got.shape == ref.shape and got.stride() == ref.stride() and not got.requires_grad
+        assert got.untyped_storage().nbytes() == rows * d * 4 and torch.equal(got.view(torch.int32), ref.view(torch.int32))
+        assert abs(os.path.getsize(p) - len(pickle.dumps(torch.from_numpy(x)))) < 64           # the same container around the same bytes
+    w = TP.StreamingTensorPickle(str(tmp_path / "short.pkl"), 10, 4)
+    w.append(np.zeros((3, 4), np.float32))
+    with pytest.raises(ValueError):
+        w.append(np.zeros((8, 4), np.float32))                  # more rows than announced
+    with pytest.raises(ValueError):
+        w.append(np.zeros((2, 4), np.float64))
+    with pytest.raises(RuntimeError, match="3 of the 10"):
+        w.close()
+    assert not os.path.exists(str(tmp_path / "short.pkl")) and not os.path.exists(str(tmp_path / "short.pkl.tmp"))

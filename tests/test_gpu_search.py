@@ -993,14 +993,16 @@ def test_byte_prescan_feedback_pause_and_resume_state_machine(byte_everywhere):
     blocks (16-bit final round), block 1029 takes the pre-scan again, and four more bad blocks pause it again.  Results are the C oracle's through every
     transition."""
     rng = np.random.default_rng(1707)
-    n, d, k = 24_000, 1024, 5
+    n, d, k = 40_000, 1024, 5
     x = _unit(rng, n, d)
     b = x[0].copy()
-    z = rng.standard_normal((6000, d)).astype(np.float32)
-    x[:6000] = b + 3e-5 * z
-    x[:6000] /= np.linalg.norm(x[:6000], axis=1, keepdims=True)
+    z = rng.standard_normal((10_000, d)).astype(np.float32)
+    x[:10_000] = b + 3e-5 * z
+    x[:10_000] /= np.linalg.norm(x[:10_000], axis=1, keepdims=True)
     bad = (b + 1e-3 * rng.standard_normal((2, d)).astype(np.float32)); bad /= np.linalg.norm(bad, axis=1, keepdims=True)
-    good, _ = _queries_near(rng, x[10_000:10_100], 2)
+    good, _ = _queries_near(rng, x[20_000:20_100], 2)
+    good -= (good @ b)[:, None] * b[None, :]                  # orthogonal to the cluster's direction: its 10 000 rows score ~0 for these queries
+    good = (good / np.linalg.norm(good, axis=1, keepdims=True)).astype(np.float32)
     ix = _mk(d, x)
     ref = {id(bad): S.search_canonical(bad, x, k), id(good): S.search_canonical(good, x, k)}
 

@@ -12,24 +12,9 @@ sys.path.insert(0, REPO)
 import numpy as np
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40_000
-rng = np.random.default_rng(0)
-letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
-def rand_words(k, lo, hi):
-    out = set()
-    while len(out) < k:
-        out.add("".join(rng.choice(letters, int(rng.integers(lo, hi)))))
-    return sorted(out)
-words = rand_words(20000, 3, 9); pieces = ["##" + w for w in rand_words(10517, 2, 5)]
 td = tempfile.mkdtemp()
-with open(os.path.join(td, "vocab.txt"), "w") as f:
-    f.write("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words + pieces) + "\n")
-wa = np.array(words); pa = np.array([p[2:] for p in pieces])
-def passage():
-    k = int(rng.integers(60, 100))
-    ws = rng.choice(wa, k)
-    glue = rng.random(k) < 0.3                                   # 30 % of the words carry a suffix piece -> real WordPiece work
-    return "title:  " + ws[0] + ", text:  " + " ".join(w + (s if g else "") for w, s, g in zip(ws[1:], rng.choice(pa, k - 1), glue[1:]))
-texts = [passage() for _ in range(n)]
+from kirag_amd.bench_support import synthetic_text_corpus
+_, texts = synthetic_text_corpus(n, td)
 
 def tok_rate(parallel, label):
     os.environ["TOKENIZERS_PARALLELISM"] = "true" if parallel else "false"
@@ -83,13 +68,16 @@ def run_loop(label, model, **kw):
     CC.cal_doc_embeddings(args, model, Corpus(), col, device=dev)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"[end to end] {label}: {n / dt:.0f} passages/s = {n / dt / enc_rate * 100:.0f} % of the encoder-only rate", flush=True)
+    lf = CC.cal_doc_embeddings.last_feed
+    print(f"[end to end] {label}: {n / dt:.0f} passages/s = {n / dt / enc_rate * 100:.0f} % of the encoder-only rate   (loop {lf['loop_s']:.2f} s + tail {lf['tail_s']:.2f} s; "
+          f"batches by producer {lf['batches_by_producer']})", flush=True)
     import shutil
     shutil.rmtree(os.path.join(td, "f", args.index_folder), ignore_errors=True)
 run_loop("warm-up (process start, first allocations)", Model(), no_embedding_files=True)
 run_loop("DEFAULT flags (tokenizer_workers=-1, prefetch_batches=2), shard files written", Model())
 run_loop("default flags, no_embedding_files", Model(), no_embedding_files=True)
-for depth, workers in ((2, 0), (2, 4), (2, 8), (8, 8)):
+run_loop("tokenizer_workers=0, shard files written", Model(), tokenizer_workers=0)
+for depth, workers in ((2, 0), (2, 2), (2, 4), (2, 8), (8, 8)):
     run_loop(f"prefetch_batches={depth} tokenizer_workers={workers} no_embedding_files", Model(), prefetch_batches=depth, tokenizer_workers=workers, no_embedding_files=True)
 run_loop("padded_feed=True (the rounds 3-5 upload: int64 input_ids + attention_mask) tokenizer_workers=8 no_embedding_files", Model(), padded_feed=True,
          tokenizer_workers=8, no_embedding_files=True)
