@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch latency block (forwards of the reference's real batch shapes + one KiRAG hop)")
     ap.add_argument("--no-entry-point", action="store_true", help="skip the cal_doc_embeddings-from-text measurement (encode.entry_point)")
-    ap.add_argument("--entry-passages", type=int, default=32768, help="synthetic text passages of the encode.entry_point block")
+    ap.add_argument("--entry-passages", type=int, default=65536, help="synthetic text passages of the encode.entry_point block")
     ap.add_argument("--no-surface", action="store_true", help="skip the reference-surface search measurement (Indexer.search_knn on --surface-queries queries)")
     ap.add_argument("--surface", action="store_true", help="(default on at N = 1) report queries/s of Indexer.search_knn next to the C-ABI search on the same queries")
     ap.add_argument("--surface-queries", type=int, default=4096)
@@ -211,6 +211,55 @@ def latency_block(args, encoder, index, dev):
         t0 = time.perf_counter(); encoder.forward(ids, mask, 0); torch.cuda.synchronize(); raw.append((time.perf_counter() - t0) * 1e3)
     out["one_at_a_time_1x32"] = {"module_surface_ms": float(np.median(one)), "c_abi_ms": float(np.median(raw)),
                                  "what": "E5Encoder.forward (nn.Module surface, weight-sync check included) vs HipBertForward.forward, each followed by a device synchronisation"}
+    # ONE HOP AT THE REFERENCE'S SURFACE (knowledge_graph/models.py:1645 `self.retriever(queries, topk)` = DenseRetriever.forward -> batch_retrieve,
+    # retrievers.py:250-291): a query STRING in, a list of {"id", "score"} out - tokenizer, collator, E5Encoder module forward, Indexer.search_knn, result parsing -
+    # over the resident rows, next to the C-ABI pieces (HipBertForward.forward + FlatIPIndex.search) on the same tokens
+    import shutil
+    import tempfile
+    import torch.nn as nn
+    from kirag_amd.collators import E5Collator
+    from kirag_amd.retriever.index import Indexer
+    from kirag_amd.retriever.retrievers import BaseRetriever, DenseRetriever
+    td = tempfile.mkdtemp(prefix="kirag_amd_hop_")
+    try:
+        vocab_file, texts = BS.synthetic_text_corpus(8, td, seed=5)
+        col = E5Collator(tokenizer=BS.wordpiece_tokenizer(vocab_file), query_maxlength=256, doc_maxlength=128)
+
+        class Ret(BaseRetriever):
+            def __init__(self, encoder):
+                nn.Module.__init__(self)
+                self.encoder = encoder
+                self.norm_query = self.norm_doc = False
+                self.temperature, self.local_rank, self.world_size = 1.0, -1, 1
+        ixr = Indexer.__new__(Indexer)
+        ixr.faiss_padding = False; ixr.index = index
+        ixr.index_id_to_db_id = np.arange(index.ntotal, dtype=np.int64) * 3 + 1_000_000
+        dr = DenseRetriever(retriever=Ret(mod), collator=col, indexer=ixr, corpus=None, batch_size=4)
+        words = texts[0].split()[3:]
+        query = "which {} ?\nknowledge triples: {}.".format(" ".join(words[:12]), ". ".join("<" + " ".join(texts[1 + i % 7].split()[3 + i:12 + i]) + ">" for i in range(16)))
+        a = col.encode_query([query], max_length=256)
+        ntok = int(a["attention_mask"].sum())
+        ids, mask = a["input_ids"].to(dev), a["attention_mask"].to(dev)
+
+        def timed(fn, reps=30):
+            for _ in range(4):
+                fn()
+            torch.cuda.synchronize(); ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+            return float(np.median(ts))
+        res = dr([query], 10)
+        qv = mod._hip.forward(ids, mask, 0)
+        s_abi, r_abi = index.search(qv, 10)
+        same = [d_["id"] for d_ in res] == [str(v) for v in ixr.index_id_to_db_id[r_abi[0]].tolist()]
+        t_surface = timed(lambda: dr([query], 10))
+        t_abi = timed(lambda: index.search(mod._hip.forward(ids, mask, 0), 10))
+        t_tok = timed(lambda: col.encode_query([query], max_length=256))
+        out["kirag_hop_nq1_surface"] = {"ms": t_surface, "c_abi_same_tokens_ms": t_abi, "ratio_to_c_abi": t_surface / t_abi, "tokenizer_collator_ms": t_tok, "query_tokens": ntok,
+                                        "same_ids_as_c_abi": bool(same),
+                                        "what": "DenseRetriever([query_text], 10) over the resident rows (string in, list of {id, score} out) vs HipBertForward.forward + FlatIPIndex.search on its tokens"}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
     del mod
     return out
 

@@ -166,8 +166,12 @@ class DenseRetriever(nn.Module):
         encode = self.collator.encode_query if which == "query" else self.collator.encode_doc
         embed = self.retriever.query if which == "query" else self.retriever.doc
         chunks = []
+        enc = getattr(self.retriever, "encoder", None)
+        host_ok = bool(getattr(enc, "accepts_host_inputs", False)) and not getattr(enc, "training", True)
         for s in range(0, len(texts), self.encode_batch_size):
-            inputs = to_device(encode(texts[s:s + self.encode_batch_size], max_length=max_length, **kwargs), self.device)
+            inputs = encode(texts[s:s + self.encode_batch_size], max_length=max_length, **kwargs)
+            if not host_ok:                                 # (retrievers.py:205 `to_device`; the HIP encoders upload the collator's CPU tensors themselves,
+                inputs = to_device(inputs, self.device)     #  from pinned staging, asynchronously)
             chunks.append(embed(inputs).detach())
         out = chunks[0] if len(chunks) == 1 else torch.cat(chunks, dim=0)
         if on_device and out.is_cuda:
