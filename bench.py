@@ -248,7 +248,7 @@ def latency_block(args, encoder, index, dev):
             for _ in range(reps):
                 t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
             return float(np.median(ts))
-        res = dr([query], 10)
+        res = dr([query], 10)[0]
         qv = mod._hip.forward(ids, mask, 0)
         s_abi, r_abi = index.search(qv, 10)
         same = [d_["id"] for d_ in res] == [str(v) for v in ixr.index_id_to_db_id[r_abi[0]].tolist()]

@@ -26,6 +26,7 @@ import sys
 import threading
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
+import itertools
 import logging
 
 import numpy as np
@@ -61,6 +62,24 @@ def tokens_of(enc) -> Tokens:
         return Tokens(KIND_RAGGED, n, S, int(rag.size), np.ascontiguousarray(rag), np.ascontiguousarray(lens))
     return Tokens(KIND_PADDED, n, S, n * S, np.ascontiguousarray(ids, dtype=np.int32).reshape(-1), np.ascontiguousarray(lens),
                   np.ascontiguousarray(on, dtype=np.uint8).reshape(-1))
+
+
+def tokens_from_rows(rows, S: int) -> Tokens:
+    """``Tokens`` (ragged) from per-sequence id lists (``collator.encode_doc_ragged``): no padded [n,S] arrays are ever built."""
+    lens = np.fromiter((len(r) for r in rows), dtype=np.int32, count=len(rows))
+    flat = np.fromiter(itertools.chain.from_iterable(rows), dtype=np.int64, count=int(lens.sum()))
+    flat = np.clip(flat, -2**31, 2**31 - 1).astype(np.int32)
+    return Tokens(KIND_RAGGED, len(rows), int(S), int(flat.size), flat, lens)
+
+
+def tokenize_batch(collator, texts) -> Tokens:
+    """One batch of passage strings -> ``Tokens``: through the collator's ragged fast path when it has one, else ``encode_doc`` (padded) stripped of its padding."""
+    ragged = getattr(collator, "encode_doc_ragged", None)
+    if ragged is not None:
+        out = ragged(texts)
+        if out is not None:
+            return tokens_from_rows(*out)
+    return tokens_of(collator.encode_doc(texts))
 
 
 def attended_range(t: Tokens) -> Optional[Tuple[int, int]]:
@@ -220,7 +239,7 @@ class TokenFeed:
                 if j < 0:
                     return
                 texts, doc_ids = self.make_texts(self.items[j])
-                t = tokens_of(self.collator.encode_doc(texts))
+                t = tokenize_batch(self.collator, texts)
                 if self.vocab is not None:
                     r = attended_range(t)
                     if r is not None and (r[0] < 0 or r[1] >= self.vocab):

@@ -43,7 +43,7 @@ def main() -> None:
         if texts is None:
             return
         try:
-            for part in feed.pack_frame(feed.tokens_of(collator.encode_doc(texts)), vocab):
+            for part in feed.pack_frame(feed.tokenize_batch(collator, texts), vocab):
                 out.write(part)
         except Exception as e:   # noqa: BLE001 - reported to the parent
             for part in feed.error_frame(f"{type(e).__name__}: {e}"):

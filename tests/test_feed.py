@@ -268,3 +268,40 @@ def test_streaming_tensor_pickle_is_a_tensor_pickle(tmp_path):
     with pytest.raises(RuntimeError, match="3 of the 10"):
         w.close()
     assert not os.path.exists(str(tmp_path / "short.pkl")) and not os.path.exists(str(tmp_path / "short.pkl.tmp"))
+
+
+def test_collator_fast_path_equals_the_reference_call_and_switches_itself_off_on_a_mismatch(collator, caplog):
+    """``RetrieverCollator.encode``'s fast path (the Rust tokenizer called directly, padded with numpy) against the reference's call
+    ``tokenizer(texts, max_length, padding, truncation=True, return_tensors="pt")`` (dataset/collators.py:76-80): the same int64 tensors for ragged batches,
+    truncated texts, a single string, ``padding="max_length"`` and the ``max_length`` override; the ragged form equals the padded one stripped; a tokenizer for
+    which the two differ (here: one that pads on the left) keeps the reference call."""
+    texts = texts_of(64) + ["hello " * 40, "", "bars"]
+    for col, maxlen in ((collator, None), (collator, 7), (E5Collator(tokenizer=collator.tokenizer, query_maxlength=9, doc_maxlength=9, doc_padding="max_length"), None)):
+        kw = {} if maxlen is None else {"max_length": maxlen}
+        got = col.encode_doc(texts, **kw)
+        ml = maxlen or col.doc_maxlength
+        ref = col._encode_reference([col.doc_prefix + t for t in texts], ml, col.doc_padding)
+        assert torch.equal(got["input_ids"], ref["input_ids"]) and torch.equal(got["attention_mask"], ref["attention_mask"]) and got["input_ids"].dtype == torch.int64
+        assert (ml, col.doc_padding) in col._fast_checked and not getattr(col, "_fast_off", False)
+        rows, S = col.encode_doc_ragged(texts, **kw)
+        t = feed.tokens_from_rows(rows, S); r = feed.tokens_of(ref)
+        assert (t.kind, t.n, t.S, t.T) == (r.kind, r.n, r.S, r.T) and np.array_equal(t.ids, r.ids) and np.array_equal(t.lens, r.lens)
+    q = collator.encode_query(["which bar ?"]); rq = collator._encode_reference(["query: which bar ?"], 16, "max_sequence")
+    assert torch.equal(q["input_ids"], rq["input_ids"]) and torch.equal(q["attention_mask"], rq["attention_mask"])
+    # a left-padding tokenizer: the fast path is not taken at all; a backend whose output differs: compared once, switched off, reference results from then on
+    import copy
+    left = copy.deepcopy(collator.tokenizer); left.padding_side = "left"
+    cl = E5Collator(tokenizer=left, query_maxlength=16, doc_maxlength=12)
+    out = cl.encode_doc(texts[:5])
+    assert out["attention_mask"][0, 0] == 0 or out["attention_mask"].all() and cl.encode_doc_ragged(texts[:5]) is None and not getattr(cl, "_fast_checked", None)
+
+    class Odd(E5Collator):
+        def _pad_rows(self, rows, maxlength, padding):                      # stands for "this backend tokenises differently": shifted ids
+            out = super()._pad_rows(rows, maxlength, padding)
+            out["input_ids"] = out["input_ids"] + 1
+            return out
+    odd = Odd(tokenizer=collator.tokenizer, query_maxlength=16, doc_maxlength=12)
+    with caplog.at_level("WARNING"):
+        o = odd.encode_doc(texts[:5])
+    r = collator._encode_reference(["passage: " + t for t in texts[:5]], 12, "max_sequence")
+    assert torch.equal(o["input_ids"], r["input_ids"]) and odd._fast_off and "switched off" in caplog.text and odd.encode_doc_ragged(texts[:5]) is None

@@ -19,17 +19,11 @@ from kirag_amd.retriever.retrievers import BaseRetriever, DenseRetriever
 total = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5_000_000
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
-letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
-def rand_words(k, lo, hi):
-    out = set()
-    while len(out) < k:
-        out.add("".join(rng.choice(letters, int(rng.integers(lo, hi)))))
-    return sorted(out)
-words = rand_words(20000, 3, 9); pieces = ["##" + w for w in rand_words(10517, 2, 5)]
 td = tempfile.mkdtemp()
-with open(os.path.join(td, "vocab.txt"), "w") as f:
-    f.write("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words + pieces) + "\n")
-tok = wordpiece_tokenizer(os.path.join(td, "vocab.txt"))
+from kirag_amd.bench_support import synthetic_text_corpus
+vocab_file, _texts = synthetic_text_corpus(8, td, seed=5)
+words = [l.strip() for l in open(vocab_file) if l.strip().isalpha()]
+tok = wordpiece_tokenizer(vocab_file)
 cfg = BertConfig(vocab_size=30522, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, max_position_embeddings=512)
 enc = E5Encoder(cfg, add_pooling_layer=False).to(dev).eval()
 
@@ -83,4 +77,5 @@ if "--profile" in sys.argv:
     pr = cProfile.Profile(); pr.enable()
     for _ in range(50): hop_surface()
     pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(25)
