@@ -252,6 +252,14 @@ def latency_block(args, encoder, index, dev):
         qv = mod._hip.forward(ids, mask, 0)
         s_abi, r_abi = index.search(qv, 10)
         same = [d_["id"] for d_ in res] == [str(v) for v in ixr.index_id_to_db_id[r_abi[0]].tolist()]
+        if os.environ.get("KIRAG_BENCH_PROFILE_HOP"):          # diagnostic: where the surface hop spends its time in THIS process
+            import cProfile
+            import pstats
+            pr = cProfile.Profile(); pr.enable()
+            for _ in range(50):
+                dr([query], 10)
+            pr.disable()
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
         t_surface = timed(lambda: dr([query], 10))
         t_abi = timed(lambda: index.search(mod._hip.forward(ids, mask, 0), 10))
         t_tok = timed(lambda: col.encode_query([query], max_length=256))
@@ -612,7 +620,7 @@ def main():
         st = index.stats()
         # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the figure comes from the
         # committed rocprofv3 --pmc passes of this same workload (tools/profile_round.sh -> profiles/rNN/traffic.json), newest round.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_range = None, None, None
         import glob
         for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "traffic*.json")), reverse=True):
             with open(cand) as f:
@@ -620,6 +628,7 @@ def main():
             if (tj.get("rows"), tj.get("dim"), tj.get("queries"), tj.get("topk"), tj.get("coarse_dtype")) == (n, d, nq, k, args.coarse_dtype):
                 traffic = tj["hbm_bytes_per_scan"] / 1e9
                 traffic_src = os.path.relpath(cand, REPO)
+                traffic_range = [v / 1e9 for v in tj["hbm_bytes_per_scan_range"]] if tj.get("hbm_bytes_per_scan_range") else None
                 break
         # MFMA-pipe utilisation of the same kernel from the committed counter pass (tools/profile_round.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES
         # GRBM_GUI_ACTIVE; tools/pmc_mfma.py): busy cycles of the matrix pipes / (kernel cycles x 1024 SIMDs)
@@ -664,7 +673,7 @@ def main():
                                        f"per-shard top-k, device merge")},
             "roofline": {"bound": "mfma", "achieved": flops / coarse / 1e12, "peak": PEAK_MFMA_DENSE_16BIT / 1e12, "unit": "TFLOP/s",
                          "frac": flops / coarse / PEAK_MFMA_DENSE_16BIT, "traffic": traffic, "traffic_unit": "GB per scan (FETCH_SIZE x2 + WRITE_SIZE)",
-                         "traffic_source": traffic_src, "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src,
+                         "traffic_source": traffic_src, "traffic_range_over_boxes": traffic_range, "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src,
                          "algorithmic_gb": n * d * 2 / 1e9, "kernel": "k_coarse", "rows_scanned": n,
                          "launch_ms": coarse * 1e3,
                          "sustained_clock_ghz": clock_ghz, "sustained_clock_source": clock_src,

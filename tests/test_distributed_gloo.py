@@ -92,3 +92,70 @@ def test_sharded_search_and_gathers_world2_gloo():
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret.get(0) == "ok" and ret.get(1) == "ok", (ret.get(0), ret.get(1))
+
+
+def _worker4(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import search_np as S
+        from kirag_amd.parallel import ShardedSearcher
+        from kirag_amd.retriever.index import ShardedIndexer
+        rng = np.random.default_rng(4)
+        n, d, k = 700, 24, 16
+        x = rng.standard_normal((n, d)).astype(np.float32); q = rng.standard_normal((11, d)).astype(np.float32)
+        x[650] = x[2]; x[13] = x[2]                                # ties across three shards
+        cuts = [0, 9, 300, 310, n]                                 # uneven: shards of 9 (< k), 291, 10 (< k) and 390 rows
+        a, b = cuts[rank], cuts[rank + 1]
+
+        class Shard:
+            ntotal = b - a
+            def search(self, qq, kk): return S.search_canonical(np.asarray(qq), x[a:b], kk)
+        so, io = S.search_canonical(q, x, k)
+        for exchange_first in (True, False):                        # the searcher's setting must not matter where the enqueue-only path cannot run
+            sr = ShardedSearcher(Shard(), row_offset=a, world=world, exchange_first=exchange_first)
+            s, i = sr.search(torch.from_numpy(q), k)
+            assert np.array_equal(i, io) and np.array_equal(s, so), exchange_first
+            with pytest.raises(ValueError):                         # host queries / a shard below k: the deferred form refuses, on EVERY rank alike
+                sr.search_deferred(torch.from_numpy(q), k)
+        # k beyond the whole corpus' smallest shards but within the corpus; and k > corpus: padded tail, the same on every rank
+        s2, i2 = ShardedSearcher(Shard(), row_offset=a, world=world).search(q, n)
+        so2, io2 = S.search_canonical(q, x, n)
+        assert np.array_equal(i2, io2) and np.array_equal(s2, so2)
+        s3, i3 = ShardedSearcher(Shard(), row_offset=a, world=world).search(q, n + 5)
+        assert np.array_equal(i3[:, :n], io2) and (i3[:, n:] == -1).all() and np.isneginf(s3[:, n:]).all()
+        # ShardedIndexer over the same uneven shards: the deferred / blocking decision comes from the smallest shard, which every rank knows
+        class Rows:
+            def __init__(self): self.x = np.empty((0, d), np.float32); self.device = 0
+            @property
+            def ntotal(self): return len(self.x)
+            def add(self, e): self.x = np.concatenate([self.x, np.asarray(e, np.float32)])
+            def search(self, qq, kk): return S.search_canonical(np.asarray(qq), self.x, kk)
+            def prepare(self, *a_, **k_): pass
+        sx = ShardedIndexer.__new__(ShardedIndexer)
+        sx.group, sx.rank, sx.world, sx.faiss_padding = None, rank, world, False
+        sx.index, sx.index_id_to_db_id = Rows(), np.empty((0), dtype=np.int64)
+        sx.row_offset, sx.ntotal_global, sx._local_ids, sx._dirty, sx._min_shard_rows, sx.deferred_blocks = 0, 0, [], False, None, 0
+        sx.index_data([str(5 * j + 3) for j in range(a, b)], x[a:b])
+        res = sx.search_knn(q, k, index_batch_size=4)
+        assert sx._min_shard_rows == 9 and sx.row_offset == a and sx.ntotal_global == n and not sx._deferred_ok(k) and sx.deferred_blocks == 0
+        for j, (ids, sc) in enumerate(res):
+            assert ids == [str(5 * int(r) + 3) for r in io[j]] and np.array_equal(np.asarray(sc), so[j])
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_world4_uneven_shards_below_k_gloo():
+    """four ranks, shards of 9 / 291 / 10 / 390 rows with k = 16 (two shards hold fewer than k rows), searcher configured with
+    exchange_first=True and False: the blocking search is the unsharded canonical answer on every rank, the enqueue-only form refuses on every rank alike, k up to
+    and beyond the corpus size pads identically, and ShardedIndexer takes the deferred / blocking decision from the smallest shard (known to all ranks)."""
+    from oracle import search_np as S
+    S.build()
+    port = _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_worker4, args=(4, port, ret), nprocs=4, join=True)
+    assert all(ret.get(r) == "ok" for r in range(4)), [ret.get(r) for r in range(4)]

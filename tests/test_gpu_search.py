@@ -253,6 +253,69 @@ def test_split_search_exchange_before_rerank_two_shards_in_one_process():
     assert np.array_equal(i2, i1)
 
 
+def test_global_theta_of_eight_shard_blocks_with_padding_vs_a_numpy_restatement():
+    """kr_index_search_global_theta at the node's world size without the node: the gathered [8][nq][k + 1] blocks of eight shards - this
+    shard's own block (from kr_index_search_coarse_async), synthetic blocks for the others, one of them all -inf (a shard that had fewer than k candidates for
+    a query, as k_local_topk writes it), one with a larger error bound, in arbitrary rank order - against a numpy restatement of the bound
+    theta[q] = (k-th largest of the 8 k coarse scores) - (max error bound + this shard's own) * 1.000001, in fp32; then the eight-shard search itself: eight
+    row shards of one corpus in ONE process, split form with the gather done by hand, merged == the unsharded canonical answer bit for bit."""
+    import torch
+    from kirag_amd import _lib
+    from kirag_amd.retriever.index import FlatIPIndex
+    rng = np.random.default_rng(88)
+    n, d, nq, k, W = 48_000, 256, 33, 20, 8
+    x = _unit(rng, n, d)
+    q = (x[rng.choice(n, nq)] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    qd = torch.from_numpy(q).cuda()
+    cuts = [0, 300, 9000, 9000 + 25, 20000, 26000, 33000, 41000, n]          # uneven: one shard of 25 rows (>= k), one of 300
+    shards = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ix = FlatIPIndex(d); ix.add(torch.from_numpy(x[a:b]).cuda()); shards.append((ix, a))
+    # (1) the bound, on shard 4's handle, from synthetic neighbours
+    ix4 = shards[4][0]
+    tk = torch.empty((nq, k + 1), dtype=torch.float32, device="cuda")
+    ix4.search_coarse_async(qd, k, tk)
+    own = tk.cpu().numpy()
+    blocks = [own]
+    for w in range(1, W):
+        b = np.sort(rng.uniform(-0.2, 0.9, (nq, k)).astype(np.float32), axis=1)[:, ::-1].copy()
+        e = np.full((nq, 1), 1e-3 * w, np.float32)
+        if w == 3:
+            b[:] = -np.inf                                             # a shard without k candidates for any query
+        if w == 5:
+            b[::2] = -np.inf; e[:] = 0.05                              # ... for every other query, and the largest error bound of all
+        blocks.append(np.concatenate([b, e], axis=1))
+    order = [6, 0, 3, 7, 5, 1, 4, 2]
+    gathered = torch.from_numpy(np.concatenate([blocks[w] for w in order], axis=0)).cuda().contiguous()
+    theta = torch.empty((nq,), dtype=torch.float32, device="cuda")
+    ix4.search_global_theta(gathered, W, theta)
+    allsc = np.concatenate([blk[:, :k] for blk in blocks], axis=1)         # [nq, W * k]
+    bg = np.sort(allsc, axis=1)[:, ::-1][:, k - 1].astype(np.float32)
+    emax = np.max(np.stack([blk[:, k] for blk in blocks]), axis=0).astype(np.float32)
+    want = (bg - ((emax + own[:, k]).astype(np.float32) * np.float32(1.000001)).astype(np.float32)).astype(np.float32)
+    assert np.array_equal(theta.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    sc = torch.empty((nq, k), dtype=torch.float32, device="cuda"); rw = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    ix4.search_rerank_async(theta, sc, rw); ix4.finish()                   # the call is completed (a synthetic bound: the rows are not looked at)
+    # (2) the eight-shard split search, gather by hand
+    tks = []
+    for ix, a in shards:
+        t = torch.empty((nq, k + 1), dtype=torch.float32, device="cuda"); ix.search_coarse_async(qd, k, t); tks.append(t)
+    gathered = torch.cat([tks[w] for w in order], dim=0).contiguous()
+    outs = []
+    for ix, a in shards:
+        th = torch.empty((nq,), dtype=torch.float32, device="cuda")
+        sc = torch.empty((nq, k), dtype=torch.float32, device="cuda"); rw = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        ix.search_global_theta(gathered, W, th); ix.search_rerank_async(th, sc, rw); ix.finish()
+        r = rw.cpu().numpy()
+        outs.append((sc.cpu().numpy(), np.where(r >= 0, r + a, -1)))
+    sc_all = np.ascontiguousarray(np.stack([o[0] for o in outs])); id_all = np.ascontiguousarray(np.stack([o[1] for o in outs]))
+    ms = np.empty((nq, k), np.float32); mi = np.empty((nq, k), np.int64)
+    _lib.check(_lib.load().kr_topk_merge(sc_all.ctypes.data, id_all.ctypes.data, W, nq, k, ms.ctypes.data, mi.ctypes.data))
+    so, io = S.search_canonical(q, x, k)
+    assert np.array_equal(mi, io) and np.array_equal(ms.view(np.uint32), so.view(np.uint32))
+    assert (id_all < 0).mean() > 0.5                                       # most of the 8 x k slots are padding: each shard re-ranked only what can be in the global top-k
+
+
 def test_duplicates_tie_rule_and_k_equals_n():
     rng = np.random.default_rng(10)
     x = _unit(rng, 500, 64)

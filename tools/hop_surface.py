@@ -68,6 +68,16 @@ t_tok = timed(lambda: col.encode_query([query], max_length=256))
 t_emb = timed(lambda: dr.calculate_query_embeddings(queries=[query], max_length=256))
 qe = dr.calculate_query_embeddings(queries=[query], max_length=256).numpy()
 t_knn = timed(lambda: ix.search_knn(qe, 10, verbose=False))
+# the collator's fast path on / off, interleaved on this box
+ab = {True: [], False: []}
+for rep in range(6):
+    for fast in (True, False):
+        col._fast_off = not fast
+        ab[fast].append((timed(hop_surface, 20), timed(lambda: col.encode_query([query], max_length=256), 20)))
+col._fast_off = False
+for fast in (True, False):
+    hs, ts = zip(*ab[fast])
+    print(f"  collator fast path {'on ' if fast else 'off'}: hop {np.median(hs):.2f} ms (runs {' '.join('%.2f' % h for h in hs)}), tokenizer + collator {np.median(ts):.3f} ms")
 print(f"one hop, nq = 1, query of {ntok} tokens, top-10 over {total} rows:")
 print(f"  reference surface  DenseRetriever([query], 10)                       {t_surface:.2f} ms")
 print(f"  C ABI              HipBertForward.forward + FlatIPIndex.search         {t_abi:.2f} ms")
