@@ -35,6 +35,11 @@ class ShardedSearcher:
     DEVICE_MERGE_MAX = 8192      # kr_topk_merge_device holds nshards * k entries per query in LDS
     RING = 8                     # deferred searches that may be outstanding between two finish_deferred() calls (at least the world size)
     PEND_MAX = 16                # Index::PEND_MAX of csrc/search.hip: asynchronous searches one index keeps outstanding
+    # Blocks of fewer queries than this (BASELINE config 5: the KiRAG loop's 1-2 queries per hop on 8 GPUs, a 0.25-ms search) skip the exchange of coarse scores:
+    # what it saves is the re-rank of ~200 rows per query (<= 32 queries: < 10 us of scattered 4-KiB gathers per rank), what it costs is one more latency-bound
+    # collective (10-20 us over xGMI).  Every rank sees the same nq, so the ranks branch alike.  Such a hop then has ONE all-gather on its data path (the result
+    # block) + the 4-byte certificate all-reduce of finish_deferred; DESIGN.md section 5 describes folding that word into the result block as well.
+    EXCHANGE_FIRST_MIN_NQ = 33
 
     def __init__(self, index, row_offset: int = 0, world: Optional[int] = None, group=None, collective: str = "torch", exchange_first: bool = True):
         """``collective``: "torch" — ``torch.distributed.all_gather_into_tensor`` of the process group + ``kr_topk_merge_device``; "kr_comm" — the
@@ -126,7 +131,7 @@ class ShardedSearcher:
         mine, loc = self._slots[j]
         ids = mine[:nq * k * 8].view(torch.int64).view(nq, k)
         sc = mine[nq * k * 8:nq * k * 12].view(torch.float32).view(nq, k)
-        if self.exchange_first and self.world > 1 and nq <= 1024:     # the split search takes one block of at most 1024 queries
+        if self.exchange_first and self.world > 1 and self.EXCHANGE_FIRST_MIN_NQ <= nq <= 1024:     # the split search takes one block of at most 1024 queries
             # coarse scan -> all-gather of the shards' k best coarse scores (+ error bound) per query -> the global bound -> re-rank above it: enqueue only
             tk, tk_all, theta = self._topk_bufs(nq, k, dev)
             self.index.search_coarse_async(q, k, tk)

@@ -9,9 +9,13 @@
   * index (round 5): the byte pre-scan of small query blocks (kr_set_option "byte_prescan") is enabled for EVERY index size here (debug_byte_min_rows = 0), so
     blocks of <= 32 queries at d in {512, 768, 1024} take it whenever their last round is not the direct one; every seventh case plants a NaN row (the int8
     copy then marks every row: slow, still exact); every fifth case adds rows AFTER the first search (the int8 copy is extended) and searches again;
+  * index (round 6): every third case calls kr_index_prepare(nq, k) before its first search (the int8 copy and the workspaces exist up front; results must not change);
+  * encoder (round 6): when every mask of a case is right-padded... every case also runs the RAGGED forward (kr_encoder_forward_packed) on the right-padded twin
+    of its batch, which must equal the padded forward of that twin bit for bit;
   * encoder (tiny config): the projection main loops / skinny tile shapes (KIRAG_AMD_PROJ_TILE = 256 / 130 / 128 / 64 / 32) must agree bit for bit, and a
     sequence's embedding must not depend on the rest of the batch.
-Exits non-zero on the first mismatch; prints one line per 25 cases."""
+Exits non-zero on the first mismatch; prints a progress line every 30 s (the GPU box kills a silent run) and ONE summary line at the end: profiles/rNN keeps the
+summary, not the log."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from types import SimpleNamespace
@@ -28,6 +32,8 @@ from kirag_amd.retriever.encoders import HipBertForward
 t_end = time.time() + budget
 cases = 0
 byte_scans = 0
+last_print = time.time()
+tot = {"certified": 0, "fine": 0, "exact": 0}
 _lib.check(_lib.load().kr_set_option(b"debug_byte_min_rows", 0))
 
 
@@ -61,6 +67,8 @@ while time.time() < t_end - budget * 0.35:
     pick = torch.from_numpy(rng.integers(0, n, nq)).cuda()
     pick[pick == n // 2] = 0                            # (never the planted NaN row)
     q = torch.nn.functional.normalize(x[pick] + 0.3 * torch.randn(nq, d, device="cuda") / d ** 0.5, dim=1)
+    if cases % 3 == 2:
+        ix.prepare(min(nq, 1024), k)                    # round 6: everything the first search would set up, done ahead of it
     force = cases % 4 == 3
     if force:
         _lib.check(_lib.load().kr_set_option(b"force_exact_scores", 1))
@@ -141,9 +149,12 @@ while time.time() < t_end - budget * 0.35:
         sys.exit(1)
     cases += 1
     byte_scans += ix.stats()["byte_scans"]
-    if cases % 25 == 0:
-        print(f"[stress] {cases} cases ok, {byte_scans} blocks through the byte pre-scan (last index case n={n} d={d} nq={nq} k={k}, stats {ix.stats()['certified']} certified / {ix.stats()['fine']} fine / {ix.stats()['exact']} exact of {ix.stats()['queries']})", flush=True)
+    tot["certified"] += ix.stats()["certified"]; tot["fine"] += ix.stats()["fine"]; tot["exact"] += ix.stats()["exact"]
+    if time.time() - last_print > 30:
+        last_print = time.time()
+        print(f"[stress] {cases} index cases ok, {byte_scans} blocks through the byte pre-scan (last case n={n} d={d} nq={nq} k={k})", flush=True)
     del ix, x
+index_cases = cases
 
 # ---- encoder -----------------------------------------------------------------------------------------------------------------------------
 from oracle import encoder_np as E   # synthetic-weights generator (this file lives under tests/: the oracle is test infrastructure)
@@ -171,7 +182,21 @@ while time.time() < t_end:
     if not ok or not np.isfinite(auto).all():
         print("ENCODER MISMATCH", dict(B=B, S=S, pool=pool, seed=seed, case=cases), flush=True)
         sys.exit(1)
+    # the ragged forward on the right-padded twin of this batch (same lengths, every sequence moved to the left edge)
+    rmask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int64)
+    rids = np.zeros_like(ids)
+    for b in range(B):
+        rids[b, :lens[b]] = ids[b][mask[b] != 0]
+    padded = enc.forward_np(rids, rmask, pool)
+    rag = np.ascontiguousarray(rids[rmask != 0].astype(np.int32))
+    packed = enc.forward_packed(torch.from_numpy(rag), torch.from_numpy(lens.astype(np.int32)), S, pool).cpu().numpy()
+    enc.check()
+    if not np.array_equal(packed.view(np.uint32), padded.view(np.uint32)):
+        print("ENCODER MISMATCH (packed forward)", dict(B=B, S=S, pool=pool, seed=seed, case=cases), flush=True)
+        sys.exit(1)
     cases += 1
-    if cases % 25 == 0:
+    if time.time() - last_print > 30:
+        last_print = time.time()
         print(f"[stress] {cases} cases ok (last encoder case B={B} S={S} pool={pool})", flush=True)
-print(f"[stress] done: {cases} cases, no mismatch", flush=True)
+print(f"[stress] done: seed {seed}, {budget:.0f} s, {cases} cases ({index_cases} index: {tot['certified']} queries certified / {tot['fine']} pass 2 / {tot['exact']} pass 3, "
+      f"{byte_scans} blocks through the byte pre-scan; {cases - index_cases} encoder incl. the packed forward), no mismatch", flush=True)
