@@ -1,6 +1,7 @@
 """Handle life cycle through the C ABI: repeated create / use / destroy of indexes and encoders returns all device memory (no leak), growing an
 index keeps its rows, workspaces adapt to changing query counts / k / batch shapes, and error returns leave handles usable."""
 import ctypes as C
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -317,3 +318,56 @@ def test_address_budget_fallback_and_move_to_a_larger_reservation():
         del ix
     finally:
         _lib.check(lib.kr_set_option(b"debug_vmm_min_reserve_mib", 0))
+
+
+def test_first_search_after_a_load_costs_what_later_ones_cost(tmp_path):
+    """the first KiRAG hop after `Indexer.deserialize_from` used to pay the int8 copy's quantisation, a 1-KiB-per-row allocation and the
+    workspace allocations.  `deserialize_from` (and `index_data`) now call kr_index_prepare: after a reload of 600 k rows the copy exists before any search, the FIRST
+    one-query top-10 search takes the byte pre-scan and costs about what the following ones cost (printed; the bar here is loose — 2 x the median — because a first call
+    also pays one-time host work: pinned scratch, first-use function attributes of kernels no earlier search launched)."""
+    import time
+    import torch
+    from kirag_amd.retriever.index import Indexer
+    n, d = 600_000, 512
+    g = torch.Generator(device="cuda"); g.manual_seed(31)
+    x = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g), dim=1)
+    src = Indexer(d); src.index_data([str(3 * i) for i in range(n)], x)
+    folder = str(tmp_path / "ix"); os.makedirs(folder)
+    src.serialize(folder)
+    q = torch.nn.functional.normalize(x[:1] + 0.05 * torch.randn(1, d, device="cuda", generator=g), dim=1).cpu().numpy()
+    ref = src.search_knn(q, 10, verbose=False)
+    del src, x
+    ix = Indexer(d); ix.deserialize_from(folder)
+    torch.cuda.synchronize()
+    st = ix.index.stats()
+    assert st["byte_rows"] == n and st["byte_scans"] == 0, st            # prepared by the load itself
+    ts = []
+    for _ in range(12):
+        t0 = time.perf_counter(); res = ix.search_knn(q, 10, verbose=False); ts.append((time.perf_counter() - t0) * 1e3)
+    assert res[0][0] == ref[0][0] and np.array_equal(res[0][1], ref[0][1])
+    steady = float(np.median(ts[2:]))
+    print(f"[first search after load] first {ts[0]:.3f} ms, second {ts[1]:.3f} ms, steady {steady:.3f} ms (600 k x 512 rows reloaded, nq = 1, top-10)")
+    assert ix.index.stats()["byte_scans"] == 12 and ts[0] <= 2.0 * steady + 0.3, ts[:3]
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs: the encoder on one, the index on the other")
+def test_queries_from_another_gpu_are_moved_in_stream_order():
+    """`batch_retrieve` hands the encoder's CUDA embeddings straight to `search_knn`; when the encoder lives on cuda:1 and the index on cuda:0 the
+    search must not read the embeddings before the kernels that produce them have finished.  `Indexer` / `FlatIPIndex` move such a tensor with `.to()` (ordered on both
+    devices).  A long-running producer kernel on cuda:1 writes the queries late; the result must be the result for the FINAL values."""
+    import torch
+    from kirag_amd.retriever.index import Indexer
+    n, d = 50_000, 256
+    x = torch.nn.functional.normalize(torch.randn(n, d, device="cuda:0"), dim=1)
+    ix = Indexer(d, device=0); ix.index_data([str(i) for i in range(n)], x)
+    want = x[:5].cpu().numpy()
+    with torch.cuda.device(1):
+        big = torch.randn(8192, 8192, device="cuda:1")
+        q1 = torch.zeros(5, d, device="cuda:1")
+        for _ in range(20):
+            big = big @ big * 1e-4                                        # keeps cuda:1 busy while the host runs ahead
+        q1.copy_(torch.from_numpy(want).to("cuda:1"), non_blocking=True)  # the queries' final values arrive behind that work
+        res = ix.search_knn(q1, 3, verbose=False)                         # enqueued immediately
+    assert [r[0][0] for r in res] == [str(i) for i in range(5)]
+    s, i = ix.index.search(q1, 1)
+    assert i[:, 0].tolist() == list(range(5))
