@@ -149,9 +149,9 @@ class Indexer(object):
         # (nothing here creates reference cycles; collection resumes when the call returns)
         import gc
         gc_was_on = gc.isenabled()
-        gc.disable()
         with torch.cuda.device(dev):
             try:
+                gc.disable()
                 enqueue(0)
                 if len(blocks) > 1:
                     enqueue(1)                                          # two calls in flight: the device goes from block j straight into block j + 1
