@@ -164,6 +164,9 @@ class HipBertForward:
         n = B * S
         ring = getattr(self, "_pin_ring", None)
         if ring is None or ring[0][0].numel() < 2 * n:
+            for old in ring or []:                                # uploads still reading the old (smaller) buffers finish before torch may reuse that pinned memory
+                if old[1] is not None:
+                    old[1].synchronize()
             cap = max(2 * n, 2 * 4096)
             ring = self._pin_ring = [[torch.empty(cap, dtype=torch.int64, pin_memory=True), None] for _ in range(self.PIN_SLOTS)]
             self._pin_next = 0
