@@ -80,7 +80,6 @@ struct Knobs {
     int force_tile = 0;    // KIRAG_AMD_PROJ_TILE: 32 / 128 / 130 / 256 force a projection path (tests run every parity case through all of them)
     int ratio8 = 5;        // KIRAG_AMD_SMALL_RATIO: eighths of the CU count below which the 128x128 tiling is used (tools/ab_encoder.py)
     bool attn_lds = false, attn_dma = false;   // KIRAG_AMD_ATTN_LDS / KIRAG_AMD_ATTN_DMA: force one attention kernel (A/B)
-    int fuse_ln = 0;       // KIRAG_AMD_FUSE_LN=1: forwards of <= 32 packed tokens recompute both LayerNorms in their consumers' prologues (k_proj_skinny_ln; experiment)
     void read() {
         auto geti = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         pw = geti("KIRAG_AMD_PATCH_W", 8); if (pw < 1) pw = 8;
@@ -91,7 +90,6 @@ struct Knobs {
         ratio8 = geti("KIRAG_AMD_SMALL_RATIO", 5);
         attn_lds = getenv("KIRAG_AMD_ATTN_LDS") != nullptr;
         attn_dma = geti("KIRAG_AMD_ATTN_DMA", 0) != 0;
-        fuse_ln = geti("KIRAG_AMD_FUSE_LN", 0);
     }
 };
 
@@ -110,8 +108,6 @@ struct Encoder {
     int *seq_off = nullptr, *seq_nk = nullptr, *seq_nq = nullptr, *seq_cls = nullptr, *seq_has0 = nullptr, *d_T = nullptr, *d_err = nullptr;
     int *tok_id = nullptr, *tok_pos = nullptr, *tok_type = nullptr;
     float *out = nullptr;
-    uint16_t* xb2 = nullptr; uint8_t* xlo2 = nullptr;   // second residual buffer of the fused-LayerNorm path (256 rows: forwards of <= 32 tokens)
-    const uint16_t* fin_hi = nullptr; const uint8_t* fin_lo = nullptr;   // where the last forward left the final hidden state (xb / xlo, or xb2 / xlo2)
     uint8_t *xlo = nullptr;    // low half of the residual stream, one byte per element (lo_encode): written by every LayerNorm with use_lo, else by the last one only
     bool use_lo = false;       // KIRAG_AMD_RESIDUAL_LO=1 at kr_encoder_create
     uint16_t *y = nullptr, *xb = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *ctx = nullptr, *h = nullptr;
@@ -539,45 +535,6 @@ struct Ln16 {
             }
         }
     }
-    // the same arithmetic, the packed 16-bit words (and low-half bytes) of each 8-element run handed to `emit(i, hi words uint4, lo bytes uint2)` instead of stored:
-    // the LayerNorm-in-prologue projection (k_proj_skinny_ln) writes them into its LDS-resident A operand
-    template <class Emit>
-    __device__ __forceinline__ void normalize_emit(const float (&v)[NS][8], int H, float eps, int lane, Emit&& emit) const {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-            if (lane * 8 + j * 512 < H)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) s += v[j][c];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        const float mu = s / (float)H;
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-            if (lane * 8 + j * 512 < H)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { const float dlt = v[j][c] - mu; q += dlt * dlt; }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
-        const float rstd = 1.0f / sqrtf(q / (float)H + eps);
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            const int i = lane * 8 + j * 512;
-            if (i < H) {
-                float o[8];
-                unsigned int ob[4], ol[2] = {0u, 0u};
-#pragma unroll
-                for (int c = 0; c < 8; ++c) o[c] = (v[j][c] - mu) * rstd * gg[j][c] + bb[j][c];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) ob[c] = pack_bf16x2(o[2 * c], o[2 * c + 1]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    ol[c >> 1] |= (lo_encode(o[2 * c], unpack_lo16(ob[c])) | (lo_encode(o[2 * c + 1], unpack_hi16(ob[c])) << 8)) << (16 * (c & 1));
-                emit(i, make_uint4(ob[0], ob[1], ob[2], ob[3]), make_uint2(ol[0], ol[1]));
-            }
-        }
-    }
     // mean / variance over the wave, normalise, store the 16-bit row and (xlo_row != nullptr) its low-half bytes.  NTS: the low half stored non-temporally
     template <bool NTS>
     __device__ __forceinline__ void normalize_store(const float (&v)[NS][8], int H, float eps, int lane, uint16_t* xb_row, uint8_t* xlo_row) const {
@@ -905,166 +862,6 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void k_proj_skinny(ProjArgs a) 
             }
         }
     });
-}
-
-// EXPERIMENT (round 6; KIRAG_AMD_FUSE_LN=1, forwards of at most 32 packed tokens): the LayerNorm in front of a projection recomputed in the
-// projection's prologue.  Every 32-token x 32-feature block normalises the tile's rows itself (LayerNorm(y + ybias + residual), the arithmetic of Ln16 / k_ln16, one
-// wave per row) into an LDS-RESIDENT A operand (K / 64 K-tiles x 4 KiB in the ring's swizzled image) while its four staging waves already stream the weights; the
-// block of feature tile 0 also writes the normalised rows (16-bit + low half) to the OTHER residual buffer (res_out != res_in: the other column blocks still read
-// res_in).  B-only ring of 16 x 4 KiB, two K-tiles per barrier, the same MFMA chain per output element as every other projection path.
-struct LnFuse {
-    const uint16_t* y; const float* ybias; const float* g; const float* bta; float eps;
-    const uint16_t* res_hi; const uint8_t* res_lo;      // residual in: 16-bit stream + low half (or nullptr)
-    uint16_t* out_hi; uint8_t* out_lo;                    // normalised rows out (written by blockIdx.x == 0); out_lo may be nullptr
-};
-constexpr int LNF_RING = 16, LNF_LNW = 8, LNF_THREADS = (LNF_LNW + 4) * 64;   // waves 0 .. 7 normalise 4 rows each (wave 0 then multiplies), waves 8 .. 11 stage the weights
-
-template <int EPI, int NS>
-__global__ __launch_bounds__(LNF_THREADS) void k_proj_skinny_ln(ProjArgs a, LnFuse f) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
-    const int T = *a.Tp;
-    if (m0 >= T) return;                                   // every wave, before any barrier
-    const int H = a.K, nk = a.K / 64;
-    char* const ares = smem;                               // [nk][32 rows][128 B]
-    char* const ring = smem + (size_t)nk * 4096;           // [LNF_RING][32 rows][128 B]
-    constexpr int GRP = 2;
-    if (wave >= LNF_LNW) {
-        // ---------------------------------------------------------------- producers (B only: one 1-KiB piece per wave and K-tile) -------------------------------
-        const int lw = wave - LNF_LNW;
-        const int row = lw * 8 + (lane >> 3);
-        const int64_t b_left = a.F - n0;
-        const int64_t rb = row >= b_left ? b_left - 1 : row;
-        const char* pb = reinterpret_cast<const char*>(a.W + (n0 + rb) * (int64_t)a.K) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
-        int pf = 0;
-        auto stage_next = [&]() {
-            __builtin_amdgcn_global_load_lds((gbl_void*)(pb + (int64_t)pf * 128), (lds_void*)(ring + (pf & (LNF_RING - 1)) * 4096 + lw * 1024), 16, 0, 0);
-            ++pf;
-        };
-        for (int p = 0; p < LNF_RING - GRP; ++p)
-            if (pf < nk) stage_next();
-        auto allowed = [&](int need) { return pf - 1 - need; };
-        constexpr int FULLG = LNF_RING - 2 * GRP - 1;
-        wait_vmcnt_upto<FULLG>(allowed(nk > GRP ? GRP : nk - 1));
-        __builtin_amdgcn_s_barrier();                                    // start barrier (also: every row of A is in LDS)
-        for (int g = 0; g < nk; g += GRP) {
-            wait_vmcnt_upto<FULLG>(allowed(g + GRP < nk ? g + GRP : nk - 1));
-            __builtin_amdgcn_s_barrier();
-#pragma unroll
-            for (int i = 0; i < GRP; ++i)
-                if (pf < nk) stage_next();
-        }
-        return;
-    }
-    {   // LayerNorm of the tile's rows: wave w takes rows w, w + 8, w + 16, w + 24 — all their loads are issued before the first row is reduced; the arithmetic of k_ln16
-        Ln16<NS> ln;
-        ln.load_params(f.g, f.bta, f.ybias, H, lane);
-        const bool writer = blockIdx.x == 0;
-        constexpr int RPW = 32 / LNF_LNW;
-        uint4 ya[RPW][NS], rh[RPW][NS]; uint2 rl[RPW][NS];
-#pragma unroll
-        for (int it = 0; it < RPW; ++it) {
-            const int64_t row = m0 + wave + it * LNF_LNW;
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                const int i = lane * 8 + j * 512;
-                ya[it][j] = rh[it][j] = make_uint4(0u, 0u, 0u, 0u); rl[it][j] = make_uint2(0x80808080u, 0x80808080u);
-                if (i < H && row < T) {
-                    ya[it][j] = *reinterpret_cast<const uint4*>(f.y + row * H + i);
-                    rh[it][j] = *reinterpret_cast<const uint4*>(f.res_hi + row * H + i);
-                    if (f.res_lo) rl[it][j] = *reinterpret_cast<const uint2*>(f.res_lo + row * H + i);
-                }
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < RPW; ++it) {
-            const int r = wave + it * LNF_LNW;
-            const int64_t row = m0 + r;
-            char* const arow = ares + r * 128;
-            const int swz = (r >> 1) & 7;
-            if (row < T) {
-                float v[NS][8];
-                ln.combine(ya[it], rh[it], rl[it], v);
-                ln.normalize_emit(v, H, f.eps, lane, [&](int i, uint4 hi, uint2 lo) {
-                    *reinterpret_cast<uint4*>(arow + (i >> 6) * 4096 + ((((i & 63) >> 3) ^ swz) << 4)) = hi;
-                    if (writer) {
-                        *reinterpret_cast<uint4*>(f.out_hi + row * H + i) = hi;
-                        if (f.out_lo) *reinterpret_cast<uint2*>(f.out_lo + row * H + i) = lo;
-                    }
-                });
-            } else {
-#pragma unroll
-                for (int j = 0; j < NS; ++j) {
-                    const int i = lane * 8 + j * 512;
-                    if (i < H) *reinterpret_cast<uint4*>(arow + (i >> 6) * 4096 + ((((i & 63) >> 3) ^ swz) << 4)) = make_uint4(0u, 0u, 0u, 0u);
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's rows of A are in LDS before it arrives at the start barrier
-    if (wave >= 1) {                                        // the other normalising waves are done: they leave after the start barrier (an ended wave no longer counts)
-        __builtin_amdgcn_s_barrier();
-        return;
-    }
-    // -------------------------------------------------------------------- consumer (wave 0) -------------------------------------------------------------------
-    f32x4 bias4[4];
-    if constexpr (EPI != EPI_DENSE) {
-        const int h = lane >> 5;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(a.bias + n0 + 8 * g + 4 * h);
-    }
-    const int frow = lane & 31, fh = lane >> 5;
-    const int fswz = (frow >> 1) & 7;
-    uint4 af[4], bf[4];
-    auto load_frags = [&](int g, int ks, int buf) {
-        const int off = frow * 128 + (((2 * ks + fh) ^ fswz) << 4);
-        af[buf] = *reinterpret_cast<const uint4*>(ares + (g < nk ? g : nk - 1) * 4096 + off);
-        bf[buf] = *reinterpret_cast<const uint4*>(ring + (g & (LNF_RING - 1)) * 4096 + off);
-    };
-    AccTile<ShapeSkinny> acc;
-    acc.m_wave = 0; acc.n_wave = 0; acc.lane = lane;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc.v[0][0][r] = 0.f;
-    __builtin_amdgcn_s_barrier();                          // start barrier
-    load_frags(0, 0, 0); load_frags(0, 1, 1);
-    for (int g = 0; g < nk; g += GRP) {
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int ks = 0; ks < 4 * GRP; ++ks) {
-            load_frags(g + ((ks + 2) >> 2), (ks + 2) & 3, (ks + 2) & 3);
-            __builtin_amdgcn_sched_barrier(0);
-            acc.v[0][0] = ET::mfma(bf[ks & 3], af[ks & 3], acc.v[0][0]);      // swapped operands, as in every projection path
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    const int64_t t0 = m0, f0 = n0;
-    const int c = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 v = {acc.v[0][0][4 * g], acc.v[0][0][4 * g + 1], acc.v[0][0][4 * g + 2], acc.v[0][0][4 * g + 3]};
-        const int ff = (int)f0 + 8 * g + 4 * h;
-        if constexpr (EPI == EPI_QKV) {
-            const int region = (int)f0 / a.H;
-            if (region == 2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a.outT[(int64_t)(ff - 2 * a.H + j) * a.ldT + t0 + c] = ET::from_f32(v[j]);
-                continue;
-            }
-            v = v + bias4[g];
-            uint2 w; w.x = pack_bf16x2(v.x, v.y); w.y = pack_bf16x2(v.z, v.w);
-            *reinterpret_cast<uint2*>((region ? a.out1 : a.out0) + (t0 + c) * a.H + (ff - region * a.H)) = w;
-        } else {
-            if constexpr (EPI == EPI_GELU) {
-                v = v + bias4[g];
-                const f32x2 lo = gelu_erf_fast2(f32x2{v.x, v.y}), hi = gelu_erf_fast2(f32x2{v.z, v.w});
-                v = f32x4{lo.x, lo.y, hi.x, hi.y};
-            }
-            uint2 w; w.x = pack_bf16x2(v.x, v.y); w.y = pack_bf16x2(v.z, v.w);
-            *reinterpret_cast<uint2*>(a.out0 + (t0 + c) * a.ldo + ff) = w;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1719,9 +1516,6 @@ static int dmalloc(P** p, size_t bytes) {
 
 static void free_ws(Encoder* e) {
     if (!e->graphs.empty()) { (void)hipDeviceSynchronize(); drop_graphs(e); }   // captured kernels hold workspace pointers
-    if (e->xb2) (void)hipFree(e->xb2);
-    if (e->xlo2) (void)hipFree(e->xlo2);
-    e->xb2 = nullptr; e->xlo2 = nullptr;
     void* ptrs[] = {e->d_ids, e->d_mask, e->d_tt, e->tok_type, e->seq_off, e->seq_nk, e->seq_nq, e->seq_cls, e->seq_has0, e->tok_id, e->tok_pos, e->xlo, e->y, e->out,
                     e->xb, e->q, e->k, e->vT, e->ctx, e->h, e->c_ctx, e->c_xb, e->c_y, e->c_h, e->c_xlo, e->c_off, e->c_nk, e->c_cls, e->d_B};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1748,7 +1542,6 @@ static int ensure_ws(Encoder* e, int B, int S) {
     KR_TRY(dmalloc(&e->d_ids, capBS * 8)); KR_TRY(dmalloc(&e->d_mask, capBS * 8)); KR_TRY(dmalloc(&e->d_tt, capBS * 8));
     KR_TRY(dmalloc(&e->seq_off, capB * 4)); KR_TRY(dmalloc(&e->seq_nk, capB * 4)); KR_TRY(dmalloc(&e->seq_nq, capB * 4)); KR_TRY(dmalloc(&e->seq_cls, capB * 4)); KR_TRY(dmalloc(&e->seq_has0, capB * 4));
     KR_TRY(dmalloc(&e->tok_id, capT * 4)); KR_TRY(dmalloc(&e->tok_pos, capT * 4)); KR_TRY(dmalloc(&e->tok_type, capT * 4));
-    KR_TRY(dmalloc(&e->xb2, (size_t)256 * H * 2)); KR_TRY(dmalloc(&e->xlo2, (size_t)256 * H));
     KR_TRY(dmalloc(&e->xlo, capT * H)); KR_TRY(dmalloc(&e->y, capT * H * 2)); KR_TRY(dmalloc(&e->out, (size_t)capB * H * 4));
     KR_TRY(dmalloc(&e->xb, capT * H * 2)); KR_TRY(dmalloc(&e->q, capT * H * 2));
     KR_TRY(dmalloc(&e->k, (capT + 64) * H * 2));    // 64 rows of slack: k_attn_dma reads whole 64-key chunks (the rows past a sequence are masked)
@@ -2141,39 +1934,13 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, b
     uint8_t* const lo_rw = e->use_lo ? e->xlo : nullptr;       // low half read / written by the inner LayerNorms
     const bool shortcut = pool == KR_POOL_CLS && e->cls_shortcut && e->c_ctx != nullptr;
     e->last_shortcut = shortcut;
-    e->fin_hi = e->xb; e->fin_lo = e->xlo;
-    // EXPERIMENT (KIRAG_AMD_FUSE_LN=1): at most 32 packed tokens -> both LayerNorms of a layer are recomputed in the prologue of the projection that consumes them
-    // (k_proj_skinny_ln): LayerNorm 1 inside FF1 (residual xb -> xb2), LayerNorm 2 inside the NEXT layer's QKV (residual xb2 -> xb); 5 launches per layer instead of 7
-    const bool fuse = e->kn.fuse_ln != 0 && maxT <= 32 && H <= 1024 && e->xb2 != nullptr;
-    uint8_t* const lo2_rw = e->use_lo ? e->xlo2 : nullptr;
-    const LayerW* pend_ln2 = nullptr;                          // fused path: the layer whose LayerNorm 2 has not been applied yet (y holds its FF2 output)
-    auto launch_fused = [&](int epi, const ProjArgs& pa, const LnFuse& lf) -> int {
-        const int nk = pa.K / 64;
-        const size_t lds = (size_t)(nk + LNF_RING) * 4096;
-        const dim3 grid((unsigned)(pa.F / 32), (unsigned)((maxT + 31) / 32));
-        ProjArgs q = pa;
-        if (q.ldo == 0) q.ldo = q.F;
-        auto go = [&](auto kern) -> int {
-            KR_TRY(set_lds_once(reinterpret_cast<const void*>(kern), (int)lds, e->device));
-            hipLaunchKernelGGL(kern, grid, dim3(LNF_THREADS), lds, st, q, lf);
-            return 0;
-        };
-        if (H <= 512) return epi == EPI_QKV ? go(&k_proj_skinny_ln<EPI_QKV, 1>) : go(&k_proj_skinny_ln<EPI_GELU, 1>);
-        return epi == EPI_QKV ? go(&k_proj_skinny_ln<EPI_QKV, 2>) : go(&k_proj_skinny_ln<EPI_GELU, 2>);
-    };
     for (const LayerW& l : e->L) {
         const bool last = (&l == &e->L.back());
         ProjArgs a{};
         a.Tp = e->d_T; a.H = H;
         // q | k | v^T in one GEMM (F = 3H)
         a.W = l.wqkv; a.X = e->xb; a.F = 3 * H; a.K = H; a.bias = l.bqkv; a.out0 = e->q; a.out1 = e->k; a.outT = e->vT; a.ldT = e->ldv; a.ldx = 0; a.ldo = 0;
-        if (pend_ln2) {
-            const LnFuse lf{e->y, pend_ln2->b2, pend_ln2->ln2g, pend_ln2->ln2b, eps, e->xb2, lo2_rw, e->xb, lo_rw};
-            KR_TRY(launch_fused(EPI_QKV, a, lf));
-            pend_ln2 = nullptr;
-        } else {
-            KR_TRY(launch_proj(EPI_QKV, a, maxT, e, st));
-        }
+        KR_TRY(launch_proj(EPI_QKV, a, maxT, e, st));
         {
             const int cap = (int)round_up(S, 32);
             const int nqt = nqt_max;
@@ -2206,19 +1973,6 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, b
         // attention.output.dense + residual -> LayerNorm
         a.W = l.wo; a.X = e->ctx; a.F = H; a.K = H; a.bias = l.bo_eff; a.out0 = e->y; a.ldx = 0; a.ldo = 0;
         KR_TRY(launch_proj(EPI_DENSE, a, maxT, e, st));
-        if (fuse) {
-            // LayerNorm 1 in FF1's prologue: residual xb (+ xlo) -> xb2 (+ xlo2), h = gelu(LN1 . W1^T + b1)
-            a.W = l.w1; a.X = nullptr; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h; a.ldx = 0; a.ldo = FF + e->h_pad;
-            const LnFuse lf{e->y, l.bo_eff, l.ln1g, l.ln1b, eps, e->xb, lo_rw, e->xb2, lo2_rw};
-            KR_TRY(launch_fused(EPI_GELU, a, lf));
-            a.W = l.w2; a.X = e->h; a.F = H; a.K = FF; a.bias = l.b2; a.out0 = e->y; a.ldx = FF + e->h_pad; a.ldo = 0;
-            KR_TRY(launch_proj(EPI_DENSE, a, maxT, e, st));
-            if (!last) { pend_ln2 = &l; continue; }            // LayerNorm 2 happens in the next layer's QKV
-            // the last LayerNorm: in place on the second buffer (its residual lives there), always with the low half
-            hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.b2, e->d_T, l.ln2g, l.ln2b, eps, H, lo2_rw, e->xlo2, e->xb2);
-            e->fin_hi = e->xb2; e->fin_lo = e->xlo2;
-            continue;
-        }
         hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.bo_eff, e->d_T, l.ln1g, l.ln1b, eps, H, lo_rw, lo_rw, e->xb);
         // intermediate.dense + GELU
         a.W = l.w1; a.X = e->xb; a.F = FF; a.K = H; a.bias = l.b1; a.out0 = e->h; a.ldx = 0; a.ldo = FF + e->h_pad;
@@ -2230,7 +1984,7 @@ static int enqueue_forward(Encoder* e, int B, int S, int pool, hipStream_t st, b
         hipLaunchKernelGGL(ln_kernel, dim3(ln_grid), dim3(256), 0, st, e->y, l.b2, e->d_T, l.ln2g, l.ln2b, eps, H, lo_rw, last ? e->xlo : lo_rw, e->xb);
     }
     KR_TRY(set_lds_once(reinterpret_cast<const void*>(pool_kernel), pool_lds, e->device));
-    hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(POOL_WAVES * 64), pool_lds, st, e->fin_hi, e->fin_lo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out, e->d_err);
+    hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(POOL_WAVES * 64), pool_lds, st, e->xb, e->xlo, e->seq_off, e->seq_nk, e->seq_cls, H, pool, e->out, e->d_err);
     KR_HIP(hipGetLastError());
     return 0;
 }
@@ -2424,8 +2178,8 @@ int enc_last_hidden(void* h, float* out, int B, int S) {
     KR_HIP(hipMemcpy(pos.data(), e->tok_pos, (size_t)T * 4, hipMemcpyDeviceToHost));
     {   // the final hidden state is stored as (16-bit hi, 8-bit lo in units of ulp(hi) / 256): see lo_encode
         std::vector<uint16_t> hi((size_t)T * H); std::vector<uint8_t> lo((size_t)T * H);
-        KR_HIP(hipMemcpy(hi.data(), e->fin_hi ? e->fin_hi : e->xb, hi.size() * 2, hipMemcpyDeviceToHost));
-        KR_HIP(hipMemcpy(lo.data(), e->fin_lo ? e->fin_lo : e->xlo, lo.size(), hipMemcpyDeviceToHost));
+        KR_HIP(hipMemcpy(hi.data(), e->xb, hi.size() * 2, hipMemcpyDeviceToHost));
+        KR_HIP(hipMemcpy(lo.data(), e->xlo, lo.size(), hipMemcpyDeviceToHost));
 #ifdef KR_ENC_BUILD_F16
         auto f = [](uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); };
 #else
