@@ -125,6 +125,8 @@ struct Index {
     float* theta1 = nullptr;   // [THETA_BLOCKS, QBLK] pass 1's b_k - 2 eps per query (k_rerank)
     float* thr_mark = nullptr; // [32] the same, compacted for the group being pre-scanned
     uint32_t* bitmap = nullptr; size_t bitmap_words = 0;   // one bit per row (+ one word: the list length) — pass 2 pre-scan
+    size_t cnt_word_at = (size_t)-1;   // where the list-length word behind the bits was last put (index (n + 31) / 32 at that time): it holds a count afterwards, and the
+                                       // bitmap is allocated for more rows than the index has, so it is zeroed when the row count moves it (move_count_word)
     uint32_t* rowlist = nullptr;                           // the marked rows, compacted
     uint32_t* qmask = nullptr;                             // byte pre-scan: per row, the queries of the block that marked it (all-zero between searches)
     // byte pre-scan of small query blocks (see byte_final_round): an int8 copy of the rows with one scale per row.  A DERIVED structure: built lazily from
@@ -1650,8 +1652,11 @@ static bool byte_dim_ok(int d) { const int dp = (int)round_up(d, 128); return dp
 
 // the bitmap / row list shared by pass 2's marking scan and the byte pre-scan (one bit per row + one word: the list length; the marked rows, compacted)
 static int ensure_bitmap(Index* ix) {
-    const size_t words = (size_t)((ix->n + 31) / 32);
+    size_t words = (size_t)((ix->n + 31) / 32);
     if (words <= ix->bitmap_words) return 0;
+    // sized for the rows the index has room for (at least 1.5 x the previous size): kr_index_prepare runs after every append of a streamed build
+    // (Indexer.index_data), and a re-allocation - hipFree waits for the device - per 512-row batch would stall that pipeline
+    words = std::max(words, std::max((size_t)((ix->cap_rows + 31) / 32), ix->bitmap_words + ix->bitmap_words / 2));
     if (ix->bitmap) (void)hipFree(ix->bitmap);
     if (ix->rowlist) (void)hipFree(ix->rowlist);
     if (ix->qmask) (void)hipFree(ix->qmask);
@@ -1662,6 +1667,17 @@ static int ensure_bitmap(Index* ix) {
     KR_HIP(hipMemset(ix->bitmap, 0, (words + 1) * sizeof(uint32_t)));        // from here on k_compact_rows leaves it all-zero behind every scan
     KR_HIP(hipMemset(ix->qmask, 0, words * 32 * sizeof(uint32_t)));          // ... and k_score_list the per-row query masks
     ix->bitmap_words = words;
+    ix->cnt_word_at = (size_t)-1;
+    return 0;
+}
+
+// the list-length word sits right behind the bits of the CURRENT row count; when rows were added since its last use the old word (a stale count) now lies inside
+// the bitmap proper, which every scan expects to be all-zero: clear it (stream-ordered, 4 bytes, only when n changed)
+static int move_count_word(Index* ix, size_t words, hipStream_t st) {
+    if (ix->cnt_word_at != words) {
+        if (ix->cnt_word_at != (size_t)-1 && ix->cnt_word_at <= ix->bitmap_words) KR_HIP(hipMemsetAsync(ix->bitmap + ix->cnt_word_at, 0, sizeof(uint32_t), st));
+        ix->cnt_word_at = words;
+    }
     return 0;
 }
 
@@ -1730,6 +1746,7 @@ static bool ensure_byte_copy(Index* ix, hipStream_t st) {
 template <class T>
 static int byte_final_round(Index* ix, const CoarseArgs& a, const float* qf, int nq, int k, hipStream_t st) {
     const size_t words = (size_t)((ix->n + 31) / 32);
+    KR_TRY(move_count_word(ix, words, st));
     unsigned int* cnt_word = ix->bitmap + words;                         // (the list-length word behind the bitmap pass 2's marking scan uses)
     const size_t prep_lds = (size_t)ix->cand_cap * sizeof(uint64_t) + 264 * sizeof(unsigned int);
     hipLaunchKernelGGL(k_scan8_prep, dim3(32), dim3(256), prep_lds, st, ix->cand, ix->cand_cap, ix->cnt, ix->eps, qf, nq, ix->d, ix->dpad8, k, ix->bounds8, ix->mu8,
@@ -2045,6 +2062,7 @@ static int slow_passes(Index* ix, const float* q, int nq, int k, float* scores, 
             if (can_mark) {
                 const size_t words = (size_t)((ix->n + 31) / 32);
                 KR_TRY(ensure_bitmap(ix));                                              // (+ 1 word: the list length lives behind the bits)
+                KR_TRY(move_count_word(ix, words, st));
                 KR_HIP(hipMemsetAsync(ix->bitmap, 0, (words + 1) * sizeof(uint32_t), st));
                 hipLaunchKernelGGL(k_prep_queries<T>, dim3(32), dim3(64), 0, st, ix->q_f2, ix->q_c, g, ix->d, ix->dpad, ix->bounds, ix->eps, ix->thr, ix->cnt, ix->flags);
                 hipLaunchKernelGGL(k_gather_theta, dim3(1), dim3(64), 0, st, ix->theta1 + (size_t)blk * QBLK, qmap, g, ix->thr_mark);

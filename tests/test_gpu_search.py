@@ -1031,6 +1031,32 @@ def test_byte_prescan_rows_added_later_and_anisotropic_rows(byte_everywhere):
         assert st["byte_scans"] == 1 and (i[0, : 5 * (it + 1)] >= 60_000).all() and (i[0] >= n_before).sum() == 5, (st, i[0])
 
 
+def test_byte_prescan_through_a_streamed_build_of_small_appends(byte_everywhere):
+    """A streamed build (cal_doc_embeddings(..., indexer=...): Indexer.index_data per batch, each followed by kr_index_prepare) interleaved with small searches: the
+    int8 copy, the row bitmap (allocated for the index's CAPACITY, not re-allocated per append) and the list-length word behind the bits (which moves with the row count
+    and must not leave a stale count inside the bitmap) follow 25 appends of odd sizes; every search equals the C oracle bit for bit and takes the pre-scan."""
+    rng = np.random.default_rng(4242)
+    d, k = 512, 7
+    x = _unit(rng, 30_000 + 25 * 61, d)
+    n = 30_000
+    from kirag_amd.retriever.index import Indexer
+    ix = Indexer(d)
+    ix.index.reserve(len(x))
+    ix.index_data([str(i) for i in range(n)], x[:n])
+    ix.index.prepare(2, k)
+    for step in range(25):
+        q, pick = _queries_near(rng, x[:n], 2)
+        s, i = ix.index.search(q, k)
+        st = ix.index.stats(reset=True)
+        so, io = S.search_canonical(q, x[:n], k)
+        assert np.array_equal(i, io) and np.array_equal(s.view(np.uint32), so.view(np.uint32)), step
+        assert st["byte_scans"] == 1 and st["byte_rows"] == n and st["byte_marked_rows"] < n // 4, (step, st)
+        m = 61 if step % 3 else 29                                   # odd sizes: the bitmap's word count changes on some appends and not on others
+        ix.index_data([str(i) for i in range(n, n + m)], x[n:n + m]); n += m
+        ix.index.prepare(2, k)
+        assert ix.index.stats()["byte_rows"] == n
+
+
 def test_byte_prescan_nan_row_marks_everything_once_then_steps_aside(byte_everywhere):
     """A non-finite element anywhere makes the byte bound meaningless: the pre-scan of that call marks every row (exact, slow), the index never takes
     the path again; NaN rows are never returned either way."""
