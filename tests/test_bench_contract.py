@@ -39,6 +39,15 @@ def test_committed_bench_line_has_the_contract_fields():
         assert sf["lists_match_c_abi"] is True and abs(sf["ratio"] - sf["search_knn_queries_per_s"] / sf["c_abi_queries_per_s"]) < 1e-6
 
 
+    if os.path.basename(os.path.dirname(path)) >= "r06":     # round 6 on: passages-encoded/s at the reference's ENTRY POINT (cal_doc_embeddings from text) and the hop at its surface
+        ep = d["encode"]["entry_point"]
+        assert ep["passages"] >= 32768 and abs(ep["ratio"] - ep["passages_per_s"] / ep["pretokenised_resident_passages_per_s"]) < 1e-9
+        assert ep["ratio"] >= 0.95 and ep["feed"]["packed_forward"] is True, ep          # VERDICT r05 item 1's bar, in the line the round ships
+        hs = d["latency"]["kirag_hop_nq1_surface"]
+        assert hs["same_ids_as_c_abi"] is True and abs(hs["ratio_to_c_abi"] - hs["ms"] / hs["c_abi_same_tokens_ms"]) < 1e-9 and hs["ms"] < 2 * hs["c_abi_same_tokens_ms"]
+        assert r.get("traffic_range_over_boxes") is None or r["traffic_range_over_boxes"][0] <= r["traffic"] <= r["traffic_range_over_boxes"][1]
+
+
 def test_bench_defaults_are_the_metric_configuration():
     import importlib.util
     import sys
