@@ -314,6 +314,8 @@ class TokenFeed:
                 self.made_by["workers"] += 1
                 self._post(j, self._frame(j, doc_ids, kind, n, S, T))
         except BaseException as e:   # noqa: BLE001 - forwarded to the consumer
+            if isinstance(e, OSError):                          # a broken pipe: the worker is gone
+                e = RuntimeError(f"tokenizer worker exited unexpectedly ({type(e).__name__}: {e})")
             self._fail(j, e)
 
     def _start(self) -> None:

@@ -305,3 +305,21 @@ def test_collator_fast_path_equals_the_reference_call_and_switches_itself_off_on
         o = odd.encode_doc(texts[:5])
     r = collator._encode_reference(["passage: " + t for t in texts[:5]], 12, "max_sequence")
     assert torch.equal(o["input_ids"], r["input_ids"]) and odd._fast_off and "switched off" in caplog.text and odd.encode_doc_ragged(texts[:5]) is None
+
+
+def test_a_tokenizer_process_that_dies_mid_stream_fails_the_run_loudly(collator):
+    """A worker killed while it owes a batch: the consumer gets a RuntimeError at that batch's turn (never a silently shorter or re-ordered stream), and the feed shuts down."""
+    texts = texts_of(200)
+
+    def mk(s):
+        time.sleep(0.02)
+        return texts[s:s + 4], list(range(s, s + 4))
+    tf = feed.TokenFeed(mk, collator, range(0, 200, 4), 1, 1, 4, 12, local=False)
+    got = []
+    with pytest.raises(RuntimeError, match="exited unexpectedly|Broken pipe|tokenizer worker"):
+        for frame in tf:
+            got.append(frame.index)
+            if frame.index == 3:
+                tf.procs[0].kill()
+    assert got[:4] == [0, 1, 2, 3] and len(got) < 50 and got == list(range(len(got)))
+    assert not tf.procs
