@@ -359,6 +359,7 @@ def surface_block(args, index, q_vec, dev):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         index.search_into(q, k, ps, pi)
         t = time.perf_counter() - t0
+        res = None                                  # the previous iteration's result (410 k str objects) is freed before the clock starts, not inside search_knn's time
         t0 = time.perf_counter()
         res = ix.search_knn(q_host, k, verbose=False)
         t2 = time.perf_counter() - t0

@@ -39,20 +39,31 @@ def wrap(obj, name, label):
         finally:
             acc[label] = acc.get(label, 0.0) + time.perf_counter() - t0
     setattr(obj, name, timed)
+stamps = []
+_fo = ix.index.finish_one
+def _fo_stamped(*a, **kw):
+    r = _fo(*a, **kw); stamps.append(time.perf_counter()); return r
+ix.index.finish_one = _fo_stamped
 wrap(ix.index, "finish_one", "wait in finish_one")
 wrap(ix.index, "search_async", "search_async (enqueue)")
 orig_ids = I.ids_to_str_rows
+id_stamps = []
 def ids_timed(ext):
-    t0 = time.perf_counter(); r = orig_ids(ext); acc["id strings"] = acc.get("id strings", 0.0) + time.perf_counter() - t0; return r
+    t0 = time.perf_counter(); r = orig_ids(ext); t1 = time.perf_counter(); acc["id strings"] = acc.get("id strings", 0.0) + t1 - t0; id_stamps.append((t0, t1, len(ext))); return r
 I.ids_to_str_rows = ids_timed
 print(f"cpus usable: {len(os.sched_getaffinity(0))}; _fastids extension: {F._fastids is not None}", flush=True)
 for rep in range(5):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ix.index.search_into(q, k, ps, pi)
     t_abi = time.perf_counter() - t0
-    acc.clear(); t0 = time.perf_counter()
+    res = None                                                      # the previous call's 410 k strings are freed OUTSIDE the timed region (3 ms of deallocation otherwise land in it)
+    acc.clear(); stamps.clear(); id_stamps.clear(); t0 = time.perf_counter()
     res = ix.search_knn(qh, k, verbose=False)
     t_knn = time.perf_counter() - t0
+    if rep == 4:
+        rel = [(s_ - t0) * 1e3 for s_ in stamps]
+        print("  id-string passes (start, end, rows): " + " ".join("%.1f-%.1f/%d" % ((a - t0) * 1e3, (b - t0) * 1e3, n_) for a, b, n_ in id_stamps) + f"; return at {t_knn * 1e3:.1f}", flush=True)
+        print("  block results final at (ms): " + " ".join("%.1f" % v for v in rel) + "; gaps " + " ".join("%.2f" % (b - a) for a, b in zip([0.0] + rel[:-1], rel)) + f"; tail after the last {t_knn * 1e3 - rel[-1]:.2f} ms", flush=True)
     if rep:
         other = t_knn - sum(acc.values())
         print(f"search_knn {t_knn * 1e3:.1f} ms vs C ABI {t_abi * 1e3:.1f} ms (ratio {t_abi / t_knn:.3f}): " + ", ".join(f"{k_} {v * 1e3:.1f}" for k_, v in acc.items()) + f", everything else {other * 1e3:.1f} ms", flush=True)
