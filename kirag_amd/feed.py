@@ -24,7 +24,7 @@ import struct
 import subprocess
 import sys
 import threading
-from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+from typing import Callable, Iterable, List, Optional, Tuple
 
 import itertools
 import logging
