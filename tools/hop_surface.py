@@ -89,3 +89,36 @@ if "--profile" in sys.argv:
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
     pstats.Stats(pr).sort_stats("tottime").print_stats(25)
+
+# stage by stage (perf_counter around the pieces batch_retrieve runs, 200 hops; the GPU work is asynchronous until search_knn waits for it)
+import statistics
+st = {k: [] for k in ("tokenize", "embed (enqueue)", "search_knn (incl. wait)", "check + parse", "total")}
+for _ in range(200):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    inputs = col.encode_query([query], max_length=256); t1 = time.perf_counter()
+    qv = dr.retriever.query(inputs).detach(); t2 = time.perf_counter()
+    knn = ix.search_knn(query_vectors=qv, top_docs=10, index_batch_size=1024, verbose=False); t3 = time.perf_counter()
+    dr._check_inputs(); out = dr.parse_indexer_output(knn); t4 = time.perf_counter()
+    for k, v in zip(st, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)): st[k].append(v * 1e3)
+print("  stages of the surface hop (median ms): " + " | ".join(f"{k} {statistics.median(v):.3f}" for k, v in st.items()))
+# the same GPU work from tokens already on the device, stage by stage
+st2 = {k: [] for k in ("forward (enqueue)", "search (incl. wait)", "total")}
+for _ in range(200):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    qv = enc._hip.forward(ids, mask, 0); t1 = time.perf_counter()
+    r = ix.index.search(qv, 10); t2 = time.perf_counter()
+    for k, v in zip(st2, (t1 - t0, t2 - t1, t2 - t0)): st2[k].append(v * 1e3)
+print("  stages of the C-ABI hop (median ms): " + " | ".join(f"{k} {statistics.median(v):.3f}" for k, v in st2.items()))
+def med(fn, reps=200):
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+    return statistics.median(ts)
+def manual():
+    inputs = col.encode_query([query], max_length=256)
+    qv = dr.retriever.query(inputs).detach()
+    knn = ix.search_knn(query_vectors=qv, top_docs=10, index_batch_size=1024, verbose=False)
+    dr._check_inputs(); return dr.parse_indexer_output(knn)
+print(f"  variants (median of 200, sync before each): dr([q], 10) {med(lambda: dr([query], 10)):.3f} | dr.batch_retrieve {med(lambda: dr.batch_retrieve([query], topk=10)):.3f} | "
+      f"dr._embed(on_device) + search_knn + parse {med(lambda: dr.parse_indexer_output(ix.search_knn(dr._embed([query], 'query', None, False, on_device=True), 10, verbose=False))):.3f} | manual pieces {med(manual):.3f} | "
+      f"manual with max_length=None {med(lambda: dr.parse_indexer_output(ix.search_knn(dr.retriever.query(col.encode_query([query])).detach(), 10, verbose=False))):.3f}")
